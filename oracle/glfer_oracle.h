@@ -1,0 +1,137 @@
+/* glfer_oracle.h -- CPU restatement of glfer's spectral-estimation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle for the HIP engine in
+ * glfer_amd/: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  Nothing under glfer_amd/ links or calls it.
+ *
+ * Every function restates one reference routine (file:line into the
+ * reference tree, glfer 0.4.2) with the same IEEE arithmetic in the same
+ * order, so that on one compiler/flag set the results are bit-identical to
+ * the reference objects built by oracle/Makefile into oracle/_ref/.
+ *
+ * Pinning status (see oracle/README.md):
+ *   - go_rfft_halfcomplex, go_dpss, go_avg_*, go_bessel_i0, go_svd are checked
+ *     BIT-EXACT against the reference's own fft_radix2.c, g-l_dpss.c, avg.c and
+ *     util.c compiled unmodified (tests/test_oracle_vs_ref.py).
+ *   - go_window, go_prepare, go_psd, go_mtm_frame, go_floor restate fft.c/mtm.c,
+ *     which cannot be compiled here (glfer.h needs <gtk/gtk.h>, absent from
+ *     this image); they are pinned by independent known answers (numpy rfft
+ *     in float64, scipy DPSS, Parseval) and by committed golden vectors.
+ */
+#ifndef GLFER_ORACLE_H
+#define GLFER_ORACLE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* window ids: same numbering as the enum at fft.h:67 */
+enum {
+  GO_WIN_HANNING = 0, GO_WIN_BLACKMAN, GO_WIN_GAUSSIAN, GO_WIN_WELCH,
+  GO_WIN_BARTLETT, GO_WIN_RECTANGULAR, GO_WIN_HAMMING, GO_WIN_KAISER
+};
+
+/* util.c:222-237 */
+double go_bessel_i0(double x);
+
+/* fft.c:309-360 compute_window(): shape in double, stored float, then
+ * divided by sqrt(sum w^2) with the sum held in float. */
+void go_window(int window_type, int n, float *w);
+
+/* hop length: fft.c:70  n_eff = N * (1.0 - overlap)  (double arithmetic on a
+ * float overlap, truncated toward zero). */
+int go_hop(int n, float overlap);
+
+/* Frame assembler state = the parts of fft_params_t (fft.h:52-63) that
+ * prepare_audio() touches. */
+typedef struct {
+  int n;               /* block size N                                   */
+  float overlap;       /* fraction of overlap                            */
+  int window_type;     /* GO_WIN_*                                       */
+  float a;             /* RA9MB parameter; >0 enables x/(a+x^2)          */
+  int limiter;         /* 1 = sign(x)*|x|^0.1                            */
+  int sub_mean;        /* subtract the mean of the NEW hop samples       */
+  float *window;       /* [n]                                            */
+  float *inbuf_audio;  /* [n] assembled frame; persists = overlap history */
+  float *inbuf_fft;    /* [n] processed frame, transformed in place      */
+} go_fft_state;
+
+void go_fft_state_init(go_fft_state *st, int n, float overlap, int window_type,
+                       float a, int limiter, int sub_mean);
+void go_fft_state_free(go_fft_state *st);
+
+/* fft.c:66-165 prepare_audio().  hop[] holds go_hop() new samples and is
+ * modified in place when sub_mean is set (the reference does the same to
+ * the caller's buffer).  first_buffer != 0 zeroes the history instead of
+ * sliding it (fft.c:99-108). */
+void go_prepare(go_fft_state *st, float *hop, int first_buffer);
+
+/* fft_radix2.c:75-177: in-place float32 radix-2 DIT real->halfcomplex,
+ * float trigonometric recurrence for the twiddles. */
+void go_rfft_halfcomplex(float *data, size_t n);
+
+/* fft.c:203-226 fft_psd() (power branch; phase is never requested). */
+void go_psd(const float *halfcomplex, int n, float *psd);
+
+/* fft.c:190-200 + fft.c:203-226: one periodogram frame. */
+void go_fft_frame(go_fft_state *st, float *hop, int first_buffer, float *psd);
+
+/* g-l_dpss.c:288-347 gl_dpss(): tapers [kmax+1][n] (row = taper, unlike the
+ * reference's 1-based [n][kmax+1] matrix) and sig[k] = lambda_k - 1. */
+int go_dpss(int n, int kmax, double nw, double *tapers, double *sig);
+
+/* mtm.c:154-239 mtm_do() output path (F-test side computation omitted: it
+ * has no observable result). */
+void go_mtm_frame(go_fft_state *st, const double *tapers, const double *sig,
+                  int kmax, float *hop, int first_buffer, float *psd);
+
+/* fft.c:240-294 compute_floor(). */
+void go_floor(const float *psd, int n, float *sig_pwr, float *floor_pwr,
+              float *peak_pwr, unsigned int *peak_bin);
+
+/* avg.c:28-36 avg_data_t, flat storage. */
+typedef struct {
+  int width, depth, effdepth;
+  double *avg;      /* [width]        */
+  double *cum;      /* [width]        */
+  double *ring;     /* [width][depth] shift registers */
+} go_avg;
+
+void go_avg_alloc(go_avg *a, int width, int depth);           /* avg.c:38-60   */
+void go_avg_free(go_avg *a);                                   /* avg.c:62-78   */
+double go_avg_plain(go_avg *a, int n, const float *psd, int minbin, int maxbin,
+                    int *peakbin);                             /* avg.c:108-159 */
+double go_avg_sumextreme(go_avg *a, int n, const float *psd, int max0,
+                         int minbin, int maxbin, int *peakbin);/* avg.c:161-219 */
+double go_avg_sumavg(go_avg *a, int n, const float *psd, int max0, int minbin,
+                     int maxbin, int *peakbin, double *variance); /* avg.c:222-298 */
+
+/* util.c:261-386 compute_svd(): one-sided Jacobi, A is [nrow][ncol] row-major
+ * float, Q is [ncol][ncol]. */
+int go_svd(float *A, int nrow, int ncol, float *S, float *Q);
+
+/* wav_fmt.c:104-117 sample conversion rules. */
+void go_pcm_u8_to_float(const unsigned char *in, size_t n, float *out);
+void go_pcm_s16_to_float(const short *in, size_t n, float *out);
+
+/* ---- whole-stream drivers: the loop of source.c:130-158 over a stream ---- */
+
+/* history_mode: 0 = zero history on frame 0 only (autoscale on: the drawer
+ * clears glfer.first_buffer after the first frame, g_main.c:1111-1120);
+ * 1 = zero history on every frame (autoscale off: nothing clears it). */
+size_t go_num_frames(size_t nsamples, int n, float overlap);
+
+void go_spectrogram_fft(const float *stream, size_t nsamples, int n,
+                        float overlap, int window_type, float a, int limiter,
+                        int sub_mean, int history_mode, float *psd_out);
+
+void go_spectrogram_mtm(const float *stream, size_t nsamples, int n,
+                        float overlap, double nw, int kmax, int sub_mean,
+                        int history_mode, float *psd_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

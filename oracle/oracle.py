@@ -1,0 +1,330 @@
+"""ctypes binding of the parity oracle (oracle/liboracle.so) and, when it has
+been built, of the reference's own objects (oracle/_ref/libglfer_ref.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Nothing under glfer_amd/ may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_REF = os.path.join(_HERE, "_ref", "libglfer_ref.so")
+
+WINDOWS = {"hanning": 0, "blackman": 1, "gaussian": 2, "welch": 3,
+           "bartlett": 4, "rectangular": 5, "hamming": 6, "kaiser": 7}
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build(ref=True):
+    """Compile liboracle.so (and _ref/ when the reference tree is present)."""
+    targets = ["all"] + (["ref"] if ref else [])
+    subprocess.run(["make", "-C", _HERE] + targets, check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+def _load():
+    if not os.path.exists(_LIB):
+        build(ref=False)
+    lib = C.CDLL(_LIB)
+    lib.go_bessel_i0.restype = C.c_double
+    lib.go_bessel_i0.argtypes = [C.c_double]
+    lib.go_window.argtypes = [C.c_int, C.c_int, _f32p]
+    lib.go_hop.restype = C.c_int
+    lib.go_hop.argtypes = [C.c_int, C.c_float]
+    lib.go_rfft_halfcomplex.argtypes = [_f32p, C.c_size_t]
+    lib.go_psd.argtypes = [_f32p, C.c_int, _f32p]
+    lib.go_dpss.restype = C.c_int
+    lib.go_dpss.argtypes = [C.c_int, C.c_int, C.c_double, _f64p, _f64p]
+    lib.go_floor.argtypes = [_f32p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                             C.POINTER(C.c_float), C.POINTER(C.c_uint)]
+    lib.go_num_frames.restype = C.c_size_t
+    lib.go_num_frames.argtypes = [C.c_size_t, C.c_int, C.c_float]
+    lib.go_spectrogram_fft.argtypes = [_f32p, C.c_size_t, C.c_int, C.c_float, C.c_int,
+                                       C.c_float, C.c_int, C.c_int, C.c_int, _f32p]
+    lib.go_spectrogram_mtm.argtypes = [_f32p, C.c_size_t, C.c_int, C.c_float, C.c_double,
+                                       C.c_int, C.c_int, C.c_int, _f32p]
+    lib.go_svd.restype = C.c_int
+    lib.go_svd.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p]
+    lib.go_pcm_u8_to_float.argtypes = [np.ctypeslib.ndpointer(np.uint8), C.c_size_t, _f32p]
+    lib.go_pcm_s16_to_float.argtypes = [np.ctypeslib.ndpointer(np.int16), C.c_size_t, _f32p]
+    return lib
+
+
+_lib = _load()
+
+
+class _GoAvg(C.Structure):
+    _fields_ = [("width", C.c_int), ("depth", C.c_int), ("effdepth", C.c_int),
+                ("avg", C.POINTER(C.c_double)), ("cum", C.POINTER(C.c_double)),
+                ("ring", C.POINTER(C.c_double))]
+
+
+_lib.go_avg_alloc.argtypes = [C.POINTER(_GoAvg), C.c_int, C.c_int]
+_lib.go_avg_free.argtypes = [C.POINTER(_GoAvg)]
+_lib.go_avg_plain.restype = C.c_double
+_lib.go_avg_plain.argtypes = [C.POINTER(_GoAvg), C.c_int, _f32p, C.c_int, C.c_int,
+                              C.POINTER(C.c_int)]
+_lib.go_avg_sumextreme.restype = C.c_double
+_lib.go_avg_sumextreme.argtypes = [C.POINTER(_GoAvg), C.c_int, _f32p, C.c_int, C.c_int,
+                                   C.c_int, C.POINTER(C.c_int)]
+_lib.go_avg_sumavg.restype = C.c_double
+_lib.go_avg_sumavg.argtypes = [C.POINTER(_GoAvg), C.c_int, _f32p, C.c_int, C.c_int, C.c_int,
+                               C.POINTER(C.c_int), C.POINTER(C.c_double)]
+
+
+def bessel_i0(x):
+    return _lib.go_bessel_i0(float(x))
+
+
+def window(window_type, n):
+    w = np.empty(n, np.float32)
+    _lib.go_window(int(window_type), n, w)
+    return w
+
+
+def hop(n, overlap):
+    return _lib.go_hop(n, C.c_float(overlap))
+
+
+def num_frames(nsamples, n, overlap):
+    return _lib.go_num_frames(nsamples, n, C.c_float(overlap))
+
+
+def rfft_halfcomplex(x):
+    d = np.ascontiguousarray(x, np.float32).copy()
+    _lib.go_rfft_halfcomplex(d, d.size)
+    return d
+
+
+def psd_from_halfcomplex(hc):
+    hc = np.ascontiguousarray(hc, np.float32)
+    out = np.empty(hc.size // 2 + 1, np.float32)
+    _lib.go_psd(hc, hc.size, out)
+    return out
+
+
+def dpss(n, kmax, nw):
+    """(tapers[kmax+1][n] float64, sig[kmax+1] float64 = lambda-1)."""
+    v = np.empty((kmax + 1, n), np.float64)
+    sig = np.empty(kmax + 1, np.float64)
+    err = _lib.go_dpss(n, kmax, float(nw), v, sig)
+    if err:
+        raise RuntimeError("go_dpss: Jacobi did not converge")
+    return v, sig
+
+
+def floor_stats(psd):
+    psd = np.ascontiguousarray(psd, np.float32)
+    s, f, p, b = C.c_float(), C.c_float(), C.c_float(), C.c_uint()
+    _lib.go_floor(psd, psd.size, C.byref(s), C.byref(f), C.byref(p), C.byref(b))
+    return s.value, f.value, p.value, b.value
+
+
+def spectrogram_fft(stream, n, overlap, window_type=0, a=0.0, limiter=0, sub_mean=0,
+                    history_mode=0):
+    stream = np.ascontiguousarray(stream, np.float32)
+    frames = num_frames(stream.size, n, overlap)
+    out = np.empty((frames, n // 2 + 1), np.float32)
+    _lib.go_spectrogram_fft(stream, stream.size, n, C.c_float(overlap), int(window_type),
+                            C.c_float(a), int(limiter), int(sub_mean), int(history_mode), out)
+    return out
+
+
+def spectrogram_mtm(stream, n, overlap, nw, kmax, sub_mean=0, history_mode=0):
+    stream = np.ascontiguousarray(stream, np.float32)
+    frames = num_frames(stream.size, n, overlap)
+    out = np.empty((frames, n // 2 + 1), np.float32)
+    _lib.go_spectrogram_mtm(stream, stream.size, n, C.c_float(overlap), float(nw), int(kmax),
+                            int(sub_mean), int(history_mode), out)
+    return out
+
+
+def svd(A):
+    A = np.ascontiguousarray(A, np.float32).copy()
+    nrow, ncol = A.shape
+    S = np.empty(ncol, np.float32)
+    Q = np.empty((ncol, ncol), np.float32)
+    rc = _lib.go_svd(A, nrow, ncol, S, Q)
+    return rc, A, S, Q
+
+
+def pcm_u8_to_float(b):
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.empty(b.size, np.float32)
+    _lib.go_pcm_u8_to_float(b, b.size, out)
+    return out
+
+
+def pcm_s16_to_float(s):
+    s = np.ascontiguousarray(s, np.int16)
+    out = np.empty(s.size, np.float32)
+    _lib.go_pcm_s16_to_float(s, s.size, out)
+    return out
+
+
+class Averager:
+    """avg.c state machine (go_avg); modes 'plain' | 'sumextreme' | 'sumavg'."""
+
+    def __init__(self, width, depth):
+        self._a = _GoAvg()
+        _lib.go_avg_alloc(C.byref(self._a), width, depth)
+        self.width = width
+
+    def __del__(self):
+        try:
+            _lib.go_avg_free(C.byref(self._a))
+        except Exception:
+            pass
+
+    def update(self, mode, psd, minbin, maxbin, max0=0, n=None):
+        psd = np.ascontiguousarray(psd, np.float32)
+        n = self.width if n is None else n
+        peak = C.c_int(-1)
+        var = C.c_double(0.0)
+        if mode == "plain":
+            r = _lib.go_avg_plain(C.byref(self._a), n, psd, minbin, maxbin, C.byref(peak))
+        elif mode == "sumextreme":
+            r = _lib.go_avg_sumextreme(C.byref(self._a), n, psd, max0, minbin, maxbin,
+                                       C.byref(peak))
+        elif mode == "sumavg":
+            r = _lib.go_avg_sumavg(C.byref(self._a), n, psd, max0, minbin, maxbin,
+                                   C.byref(peak), C.byref(var))
+        else:
+            raise ValueError(mode)
+        avg = np.ctypeslib.as_array(self._a.avg, shape=(self.width,))[:n].copy()
+        return r, avg, peak.value, var.value
+
+
+# ---------------------------------------------------------------------------
+# The reference's own objects (fft_radix2.c, g-l_dpss.c, avg.c, util.c compiled
+# unmodified into oracle/_ref/).  Present in the build container; travels to the
+# GPU box as a prebuilt .so; absent in a fresh clone without the reference tree.
+
+def have_ref():
+    return os.path.exists(_REF)
+
+
+class _RefAvg(C.Structure):           # avg.h:28-36
+    _fields_ = [("avgwidth", C.c_int), ("avgdepth", C.c_int), ("effdepth", C.c_int),
+                ("avg", C.POINTER(C.c_double)), ("cum", C.POINTER(C.c_double)),
+                ("avgarray", C.POINTER(C.POINTER(C.c_double)))]
+
+
+class Ref:
+    """Thin binding of the reference functions that build without GTK."""
+
+    def __init__(self):
+        if not have_ref():
+            raise FileNotFoundError(_REF)
+        r = C.CDLL(_REF)
+        r.fft_real_radix2_transform.argtypes = [_f32p, C.c_size_t]
+        r.bessel_I0.restype = C.c_double
+        r.bessel_I0.argtypes = [C.c_double]
+        r.dmatrix.restype = C.POINTER(C.POINTER(C.c_double))
+        r.dmatrix.argtypes = [C.c_long] * 4
+        r.free_dmatrix.argtypes = [C.POINTER(C.POINTER(C.c_double))] + [C.c_long] * 4
+        r.dvector.restype = C.POINTER(C.c_double)
+        r.dvector.argtypes = [C.c_long] * 2
+        r.free_dvector.argtypes = [C.POINTER(C.c_double)] + [C.c_long] * 2
+        r.matrix.restype = C.POINTER(C.POINTER(C.c_float))
+        r.matrix.argtypes = [C.c_long] * 4
+        r.free_matrix.argtypes = [C.POINTER(C.POINTER(C.c_float))] + [C.c_long] * 4
+        r.gl_dpss.restype = C.c_int
+        r.gl_dpss.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double,
+                              C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_double),
+                              C.POINTER(C.c_int)]
+        r.compute_svd.restype = C.c_int
+        r.compute_svd.argtypes = [C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int,
+                                  C.POINTER(C.c_float), C.POINTER(C.POINTER(C.c_float))]
+        r.init_avg.argtypes = [C.POINTER(_RefAvg)]
+        r.alloc_avg.argtypes = [C.POINTER(_RefAvg), C.c_int, C.c_int]
+        r.delete_avg.argtypes = [C.POINTER(_RefAvg)]
+        for name in ("update_avg_plain", "update_avg_sumextreme", "update_avg_sumavg"):
+            getattr(r, name).restype = C.c_double
+        r.update_avg_plain.argtypes = [C.POINTER(_RefAvg), C.c_int, _f32p, C.c_int, C.c_int,
+                                       C.POINTER(C.c_int)]
+        r.update_avg_sumextreme.argtypes = [C.POINTER(_RefAvg), C.c_int, _f32p, C.c_int,
+                                            C.c_int, C.c_int, C.POINTER(C.c_int)]
+        r.update_avg_sumavg.argtypes = [C.POINTER(_RefAvg), C.c_int, _f32p, C.c_int, C.c_int,
+                                        C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        self.r = r
+
+    def rfft_halfcomplex(self, x):
+        d = np.ascontiguousarray(x, np.float32).copy()
+        self.r.fft_real_radix2_transform(d, d.size)
+        return d
+
+    def bessel_i0(self, x):
+        return self.r.bessel_I0(float(x))
+
+    def dpss(self, n, kmax, nw):
+        v = self.r.dmatrix(1, n, 0, kmax)          # mtm.c:118
+        sig = self.r.dvector(0, kmax)              # mtm.c:119
+        it = C.c_int(0)
+        err = self.r.gl_dpss(n, kmax, n, float(nw), v, sig, C.byref(it))  # mtm.c:73
+        tap = np.empty((kmax + 1, n), np.float64)
+        for i in range(n):
+            row = v[i + 1]
+            for k in range(kmax + 1):
+                tap[k, i] = row[k]
+        s = np.array([sig[k] for k in range(kmax + 1)], np.float64)
+        self.r.free_dmatrix(v, 1, n, 0, kmax)
+        self.r.free_dvector(sig, 0, kmax)
+        return err, tap, s
+
+    def svd(self, A):
+        A = np.asarray(A, np.float32)
+        nrow, ncol = A.shape
+        m = self.r.matrix(0, nrow - 1, 0, ncol - 1)
+        q = self.r.matrix(0, ncol - 1, 0, ncol - 1)
+        S = (C.c_float * ncol)()
+        for i in range(nrow):
+            for j in range(ncol):
+                m[i][j] = float(A[i, j])
+        rc = self.r.compute_svd(m, nrow, ncol, S, q)
+        U = np.array([[m[i][j] for j in range(ncol)] for i in range(nrow)], np.float32)
+        Q = np.array([[q[i][j] for j in range(ncol)] for i in range(ncol)], np.float32)
+        Sv = np.array(list(S), np.float32)
+        self.r.free_matrix(m, 0, nrow - 1, 0, ncol - 1)
+        self.r.free_matrix(q, 0, ncol - 1, 0, ncol - 1)
+        return rc, U, Sv, Q
+
+    def averager(self, width, depth):
+        return _RefAverager(self.r, width, depth)
+
+
+class _RefAverager:
+    def __init__(self, r, width, depth):
+        self.r = r
+        self.a = _RefAvg()
+        r.init_avg(C.byref(self.a))
+        r.alloc_avg(C.byref(self.a), width, depth)
+        self.width = width
+
+    def __del__(self):
+        try:
+            self.r.delete_avg(C.byref(self.a))
+        except Exception:
+            pass
+
+    def update(self, mode, psd, minbin, maxbin, max0=0, n=None):
+        psd = np.ascontiguousarray(psd, np.float32)
+        n = self.width if n is None else n
+        peak = C.c_int(-1)
+        var = C.c_double(0.0)
+        if mode == "plain":
+            v = self.r.update_avg_plain(C.byref(self.a), n, psd, minbin, maxbin, C.byref(peak))
+        elif mode == "sumextreme":
+            v = self.r.update_avg_sumextreme(C.byref(self.a), n, psd, max0, minbin, maxbin,
+                                             C.byref(peak))
+        else:
+            v = self.r.update_avg_sumavg(C.byref(self.a), n, psd, max0, minbin, maxbin,
+                                         C.byref(peak), C.byref(var))
+        avg = np.ctypeslib.as_array(self.a.avg, shape=(self.width,))[:n].copy()
+        return v, avg, peak.value, var.value
