@@ -1,0 +1,253 @@
+"""Host-side binding of the C-ABI in include/glfer_hip.h (glfer_amd/lib/libglfer_hip.so).
+
+Everything computed here runs in the HIP library; torch is used only to own device
+memory and streams.  There is no CPU fallback: if the library is missing, or HIP cannot
+run, the calls raise.
+
+Names follow the reference's estimator interface (fft.h:77-83, mtm.h:47-49, avg.h:38-43):
+`FftParams` / `MtmParams` carry what change_params() copies out of `opt`
+(source.c:320-325, 343-350) and `Spectrogram` is the per-hop loop of source.c:130-158
+run over a whole stream.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libglfer_hip.so")
+
+MODE_FFT, MODE_MTM = 0, 1
+WINDOWS = {"hanning": 0, "blackman": 1, "gaussian": 2, "welch": 3,
+           "bartlett": 4, "rectangular": 5, "hamming": 6, "kaiser": 7}
+SAMPLES_F32, SAMPLES_S16, SAMPLES_U8 = 0, 1, 2
+HISTORY_ZERO_FIRST, HISTORY_ZERO_ALWAYS = 0, 1
+AVG_SUMAVG, AVG_PLAIN, AVG_SUMEXTREME = 1, 2, 3
+
+# every symbol include/glfer_hip.h declares
+EXPORTS = [
+    "glfer_hip_plan_create", "glfer_hip_plan_destroy", "glfer_hip_hop", "glfer_hip_bins",
+    "glfer_hip_num_tapers", "glfer_hip_num_frames", "glfer_hip_get_window", "glfer_hip_get_tapers",
+    "glfer_hip_make_window", "glfer_hip_make_dpss", "glfer_hip_spectrogram_device",
+    "glfer_hip_spectrum_device", "glfer_hip_spectrogram_host", "glfer_hip_floor_device",
+    "glfer_hip_avg_device", "glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version",
+]
+
+
+class GlferHipError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    """glfer_hip_config (include/glfer_hip.h)."""
+    _fields_ = [("mode", C.c_int), ("n", C.c_int), ("overlap", C.c_float),
+                ("window_type", C.c_int), ("limiter_a", C.c_float), ("enable_limiter", C.c_int),
+                ("sub_mean", C.c_int), ("history_mode", C.c_int), ("mtm_w", C.c_float),
+                ("mtm_k", C.c_int), ("sample_format", C.c_int), ("device", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libglfer_hip.so (built by __graft_entry__.build()); fail loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GlferHipError(
+            "HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C glfer_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.glfer_hip_plan_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.glfer_hip_plan_destroy.argtypes = [vp]
+    L.glfer_hip_plan_destroy.restype = None
+    for f in ("glfer_hip_hop", "glfer_hip_bins", "glfer_hip_num_tapers"):
+        getattr(L, f).argtypes = [vp]
+    L.glfer_hip_num_frames.argtypes = [vp, sz]
+    L.glfer_hip_num_frames.restype = sz
+    L.glfer_hip_get_window.argtypes = [vp, vp]
+    L.glfer_hip_get_tapers.argtypes = [vp, vp, vp]
+    L.glfer_hip_make_window.argtypes = [C.c_int, C.c_int, vp]
+    L.glfer_hip_make_dpss.argtypes = [C.c_int, C.c_int, C.c_double, vp, vp]
+    L.glfer_hip_spectrogram_device.argtypes = [vp, vp, sz, sz, sz, vp, vp]
+    L.glfer_hip_spectrum_device.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp]
+    L.glfer_hip_spectrogram_host.argtypes = [vp, vp, sz, vp, C.POINTER(sz)]
+    L.glfer_hip_floor_device.argtypes = [vp, sz, C.c_int, vp, vp]
+    L.glfer_hip_avg_device.argtypes = [C.c_int, vp, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, vp, vp, vp]
+    for f in ("glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version"):
+        getattr(L, f).restype = C.c_char_p
+    L.glfer_hip_strerror.argtypes = [C.c_int]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        L = lib()
+        raise GlferHipError("%s failed: %s (%s)" % (
+            what, L.glfer_hip_strerror(rc).decode(), L.glfer_hip_last_hip_error().decode()))
+
+
+def version():
+    return lib().glfer_hip_version().decode()
+
+
+def make_window(window_type, n):
+    """compute_window (fft.c:309-360), host code of the library."""
+    w = np.empty(n, np.float32)
+    _check(lib().glfer_hip_make_window(int(window_type), n, w.ctypes.data), "make_window")
+    return w
+
+
+def make_dpss(n, kmax, nw):
+    """gl_dpss (g-l_dpss.c:288-347), host code of the library: (tapers[kmax+1][n], sig)."""
+    v = np.empty((kmax + 1, n), np.float64)
+    s = np.empty(kmax + 1, np.float64)
+    _check(lib().glfer_hip_make_dpss(n, kmax, float(nw), v.ctypes.data, s.ctypes.data), "make_dpss")
+    return v, s
+
+
+class FftParams:
+    """What source.c:320-325 sets before fft_init(): n, window_type, overlap, a, limiter."""
+
+    def __init__(self, n=1024, window_type=7, overlap=0.0, a=0.0, limiter=0, sub_mean=0,
+                 history_mode=HISTORY_ZERO_FIRST, sample_format=SAMPLES_F32):
+        self.mode = MODE_FFT
+        self.n, self.window_type, self.overlap = n, window_type, overlap
+        self.a, self.limiter, self.sub_mean = a, limiter, sub_mean
+        self.history_mode, self.sample_format = history_mode, sample_format
+        self.w, self.kmax = 0.0, 0
+
+
+class MtmParams:
+    """What source.c:343-350 sets before mtm_init(): fft.{n,overlap}, w (=N*W), kmax."""
+
+    def __init__(self, n=1024, overlap=0.0, w=4.0, kmax=7, sub_mean=0,
+                 history_mode=HISTORY_ZERO_FIRST, sample_format=SAMPLES_F32):
+        self.mode = MODE_MTM
+        self.n, self.overlap, self.w, self.kmax = n, overlap, w, kmax
+        self.window_type = WINDOWS["rectangular"]       # source.c:344
+        self.a, self.limiter, self.sub_mean = 0.0, 0, sub_mean
+        self.history_mode, self.sample_format = history_mode, sample_format
+
+
+_TORCH_DTYPES = None
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Spectrogram:
+    """A plan (fft_init / mtm_init) bound to one GPU, plus the batched hot path."""
+
+    def __init__(self, params, device=0):
+        cfg = Config(params.mode, params.n, params.overlap, params.window_type, params.a,
+                     params.limiter, params.sub_mean, params.history_mode, params.w, params.kmax,
+                     params.sample_format, device)
+        self._h = C.c_void_p()
+        _check(lib().glfer_hip_plan_create(C.byref(cfg), C.byref(self._h)), "glfer_hip_plan_create")
+        self.params, self.device = params, device
+        self.n = params.n
+        self.hop = lib().glfer_hip_hop(self._h)
+        self.bins = lib().glfer_hip_bins(self._h)
+        self.ntapers = lib().glfer_hip_num_tapers(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().glfer_hip_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def num_frames(self, nsamples):
+        return lib().glfer_hip_num_frames(self._h, nsamples)
+
+    def window(self):
+        w = np.empty(self.n, np.float32)
+        _check(lib().glfer_hip_get_window(self._h, w.ctypes.data), "get_window")
+        return w
+
+    def tapers(self):
+        v = np.empty((self.ntapers, self.n), np.float64)
+        s = np.empty(self.ntapers, np.float64)
+        _check(lib().glfer_hip_get_tapers(self._h, v.ctypes.data, s.ctypes.data), "get_tapers")
+        return v, s
+
+    def _sample_dtype(self):
+        torch = _torch()
+        return {SAMPLES_F32: torch.float32, SAMPLES_S16: torch.int16,
+                SAMPLES_U8: torch.uint8}[self.params.sample_format]
+
+    def run(self, stream, first_frame=0, nframes=None, out=None, spectrum=False):
+        """stream: 1-D torch tensor on this GPU.  Returns psd [nframes][bins] (and the
+        halfcomplex spectra [nframes][n] when spectrum=True), launched on torch's current
+        stream."""
+        torch = _torch()
+        assert stream.is_cuda and stream.dim() == 1 and stream.is_contiguous()
+        assert stream.dtype == self._sample_dtype(), (stream.dtype, self._sample_dtype())
+        total = self.num_frames(stream.numel())
+        if nframes is None:
+            nframes = total - first_frame
+        if out is None:
+            out = torch.empty((nframes, self.bins), dtype=torch.float32, device=stream.device)
+        assert out.is_contiguous() and out.numel() >= nframes * self.bins
+        st = C.c_void_p(torch.cuda.current_stream(stream.device).cuda_stream)
+        if spectrum:
+            spec = torch.empty((nframes, self.n), dtype=torch.float32, device=stream.device)
+            _check(lib().glfer_hip_spectrum_device(self._h, stream.data_ptr(), stream.numel(),
+                                                   first_frame, nframes, out.data_ptr(),
+                                                   spec.data_ptr(), st), "glfer_hip_spectrum_device")
+            return out, spec
+        _check(lib().glfer_hip_spectrogram_device(self._h, stream.data_ptr(), stream.numel(),
+                                                  first_frame, nframes, out.data_ptr(), st),
+               "glfer_hip_spectrogram_device")
+        return out
+
+    def run_host(self, samples):
+        """samples: numpy array on the host; returns numpy psd [frames][bins]."""
+        want = {SAMPLES_F32: np.float32, SAMPLES_S16: np.int16, SAMPLES_U8: np.uint8}[
+            self.params.sample_format]
+        samples = np.ascontiguousarray(samples, want)
+        frames = self.num_frames(samples.size)
+        out = np.empty((frames, self.bins), np.float32)
+        nf = C.c_size_t(0)
+        _check(lib().glfer_hip_spectrogram_host(self._h, samples.ctypes.data, samples.size,
+                                                out.ctypes.data, C.byref(nf)),
+               "glfer_hip_spectrogram_host")
+        assert nf.value == frames
+        return out
+
+
+def compute_floor(psd):
+    """compute_floor (fft.c:240-294) for every row of a device PSD tensor.
+    Returns a [frames][4] float tensor: sig, floor, peak value, peak bin."""
+    torch = _torch()
+    assert psd.is_cuda and psd.dtype == torch.float32 and psd.is_contiguous() and psd.dim() == 2
+    out = torch.empty((psd.shape[0], 4), dtype=torch.float32, device=psd.device)
+    st = C.c_void_p(torch.cuda.current_stream(psd.device).cuda_stream)
+    _check(lib().glfer_hip_floor_device(psd.data_ptr(), psd.shape[0], psd.shape[1], out.data_ptr(), st),
+           "glfer_hip_floor_device")
+    return out
+
+
+def update_avg(mode, psd, depth, minbin, maxbin, max0=0, n_out=None):
+    """update_avg_{sumavg,plain,sumextreme} (avg.c:108-298) applied to consecutive rows of a
+    device PSD tensor, starting from an empty averaging state (alloc_avg, avg.c:38-60).
+    Returns (avg [frames][n_out] float64, ret [frames][4] float64 = value, peakbin, variance,
+    effdepth)."""
+    torch = _torch()
+    assert psd.is_cuda and psd.dtype == torch.float32 and psd.is_contiguous() and psd.dim() == 2
+    frames, bins = psd.shape
+    n_out = bins if n_out is None else n_out
+    avg = torch.empty((frames, n_out), dtype=torch.float64, device=psd.device)
+    ret = torch.empty((frames, 4), dtype=torch.float64, device=psd.device)
+    st = C.c_void_p(torch.cuda.current_stream(psd.device).cuda_stream)
+    _check(lib().glfer_hip_avg_device(int(mode), psd.data_ptr(), frames, bins, n_out, depth, minbin,
+                                      maxbin, int(max0), avg.data_ptr(), ret.data_ptr(), st),
+           "glfer_hip_avg_device")
+    return avg, ret

@@ -1,0 +1,110 @@
+// fft_inreg.hpp -- compile-time-unrolled complex FFTs on per-lane register arrays.
+//
+// Part of the MI355X spectral engine (replaces the butterfly nest of the
+// reference's fft_radix2.c:104-175).  Everything here is resolved at compile
+// time: register indices, twiddle constants and the trivial-twiddle special
+// cases, so a radix-R transform is a straight line of v_fma/v_add/v_sub on
+// VGPRs with no address arithmetic.
+//
+// Butterfly form: radix-2 decimation in time with the 6-FMA butterfly
+//     X  = a + w*b      (4 fma)         X' = 2a - X   (2 fma)
+// which costs 3*R*log2(R) VALU ops per R-point transform -- the same count as
+// a radix-4 kernel without FMA fusion -- and 4 ops where w is 1 or -i.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+namespace glfer {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
+
+// bit reversal of k in log2(R) bits
+constexpr int brev(int k, int R) {
+  int r = 0;
+  for (int b = 1; b < R; b <<= 1) {
+    r = (r << 1) | (k & 1);
+    k >>= 1;
+  }
+  return r;
+}
+
+// ---- compile-time unit roots, exact octant reduction + Taylor core ----
+constexpr double kPi = 3.141592653589793238462643383279502884;
+
+constexpr double sin_core(double x) {  // |x| <= pi/4
+  double x2 = x * x, term = x, sum = x;
+  for (int i = 1; i < 14; i++) {
+    term *= -x2 / double((2 * i) * (2 * i + 1));
+    sum += term;
+  }
+  return sum;
+}
+constexpr double cos_core(double x) {
+  double x2 = x * x, term = 1.0, sum = 1.0;
+  for (int i = 1; i < 14; i++) {
+    term *= -x2 / double((2 * i - 1) * (2 * i));
+    sum += term;
+  }
+  return sum;
+}
+struct cplx64 { double c, s; };
+// exp(+i*2*pi*j/R), R a power of two
+constexpr cplx64 unit_root(int j, int R) {
+  j %= R;
+  if (j < 0) j += R;
+  if (j == 0) return {1.0, 0.0};
+  if (2 * j == R) return {-1.0, 0.0};
+  if (4 * j == R) return {0.0, 1.0};
+  if (4 * j == 3 * R) return {0.0, -1.0};
+  if (2 * j > R) { cplx64 u = unit_root(R - j, R); return {u.c, -u.s}; }
+  if (4 * j > R) { cplx64 u = unit_root(R / 2 - j, R); return {-u.c, u.s}; }
+  if (8 * j > R) { cplx64 u = unit_root(R / 4 - j, R); return {u.s, u.c}; }
+  double a = 2.0 * kPi * double(j) / double(R);
+  return {cos_core(a), sin_core(a)};
+}
+
+// One DIT combine stage entry: a at index PA, b at PB, forward twiddle exp(-i 2 pi K / R).
+template <int R, int K, int PA, int PB>
+__device__ __forceinline__ void bfly(float (&re)[64], float (&im)[64]) {
+  const float ar = re[PA], ai = im[PA], br = re[PB], bi = im[PB];
+  if constexpr (K == 0) {
+    re[PA] = ar + br; im[PA] = ai + bi;
+    re[PB] = ar - br; im[PB] = ai - bi;
+  } else if constexpr (4 * K == R) {          // w = -i : t = (bi, -br)
+    re[PA] = ar + bi; im[PA] = ai - br;
+    re[PB] = ar - bi; im[PB] = ai + br;
+  } else {
+    constexpr cplx64 u = unit_root(K, R);
+    constexpr float wr = float(u.c), wi = float(-u.s);   // w = exp(-i theta)
+    const float xr = __builtin_fmaf(wr, br, __builtin_fmaf(-wi, bi, ar));
+    const float xi = __builtin_fmaf(wr, bi, __builtin_fmaf(wi, br, ai));
+    re[PA] = xr; im[PA] = xi;
+    re[PB] = __builtin_fmaf(2.0f, ar, -xr);
+    im[PB] = __builtin_fmaf(2.0f, ai, -xi);
+  }
+}
+
+// R-point forward DFT over the elements OFF + S*i (i = 0..R-1, natural order).
+// Result X[k] is left at index OFF + S*brev(k, R).
+template <int R, int S, int OFF>
+__device__ __forceinline__ void dit(float (&re)[64], float (&im)[64]) {
+  if constexpr (R >= 2) {
+    dit<R / 2, 2 * S, OFF>(re, im);
+    dit<R / 2, 2 * S, OFF + S>(re, im);
+    static_for<0, R / 2>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int pa = OFF + 2 * S * brev(k, R / 2);
+      bfly<R, k, pa, pa + S>(re, im);
+    });
+  }
+}
+
+}  // namespace glfer

@@ -1,0 +1,317 @@
+// glfer_hip.cpp -- the C-ABI of include/glfer_hip.h: plans, tables, launches.
+//
+// Host side of the drop-in boundary.  A plan is what fft_init()/mtm_init() build in the
+// reference (fft.c:168-187, mtm.c:88-151): window or DPSS tapers, here also uploaded to
+// HBM with the 1/N normalisation (fft.c:212-216), the eigenvalue weights 1/(1+sig_j)
+// (mtm.c:214-219) and the 1/2 of the re/im packing folded in, so the kernel's epilogue is
+// a single add.  No CPU fallback exists: every compute entry fails with GLFER_E_HIP when
+// HIP cannot run it.
+#include "../../include/glfer_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "host_tables.h"
+#include "spectro_params.h"
+
+extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int bins, int m, float *stats,
+                                         hipStream_t st);
+extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframes, int bins, int n_out,
+                                       int depth, int minbin, int maxbin, int max0, double *avg,
+                                       double *ret, hipStream_t st);
+
+static thread_local std::string g_hip_err;
+
+static int hip_fail(hipError_t e, const char *what) {
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  g_hip_err = buf;
+  return GLFER_E_HIP;
+}
+#define HIP_TRY(call)                                   \
+  do {                                                  \
+    hipError_t e_ = (call);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);   \
+  } while (0)
+
+struct glfer_hip_plan {
+  glfer_hip_config cfg;
+  int n, hop, keep, bins, ntapers, npairs, lanes;
+  std::vector<float> window;        // [n] as the reference stores it (unit power)
+  std::vector<double> tapers;       // [ntapers][n]
+  std::vector<double> sig;          // [ntapers]
+  float *d_taps = nullptr;          // [2*npairs][n] scaled tables
+  float2 *d_tw = nullptr;           // [64][lanes]
+  float *d_scratch = nullptr;       // sub_mean copy of the hops of one call
+  size_t scratch_floats = 0;
+  float spec_unscale = 1.0f;
+  bool nonlin = false;
+};
+
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+extern "C" {
+
+const char *glfer_hip_version(void) { return "glfer_hip 0.1 (gfx950, wave-per-frame radix-64x64)"; }
+
+const char *glfer_hip_strerror(int code) {
+  switch (code) {
+    case GLFER_OK: return "ok";
+    case GLFER_E_ARG: return "bad argument or unsupported configuration";
+    case GLFER_E_HIP: return "HIP runtime error";
+    case GLFER_E_NOMEM: return "out of memory";
+    case GLFER_E_NUMERIC: return "DPSS eigen-solve did not converge";
+  }
+  return "unknown error";
+}
+
+const char *glfer_hip_last_hip_error(void) { return g_hip_err.c_str(); }
+
+int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
+  if (!cfg || !out) return GLFER_E_ARG;
+  *out = nullptr;
+  const int n = cfg->n;
+  if (!is_pow2(n) || n < 256 || n > 4096) return GLFER_E_ARG;
+  if (!(cfg->overlap >= 0.0f) || !(cfg->overlap < 1.0f)) return GLFER_E_ARG;   // g_options.c:1030
+  if (cfg->mode != GLFER_MODE_FFT && cfg->mode != GLFER_MODE_MTM) return GLFER_E_ARG;
+  if (cfg->sample_format < 0 || cfg->sample_format > 2) return GLFER_E_ARG;
+  if (cfg->mode == GLFER_MODE_MTM && (cfg->mtm_k < 0 || cfg->mtm_k > 31 || !(cfg->mtm_w > 0.0f)))
+    return GLFER_E_ARG;
+  if (cfg->mode == GLFER_MODE_FFT && (cfg->window_type < 0 || cfg->window_type > 7)) return GLFER_E_ARG;
+
+  glfer_hip_plan *p = new (std::nothrow) glfer_hip_plan();
+  if (!p) return GLFER_E_NOMEM;
+  p->cfg = *cfg;
+  p->n = n;
+  p->hop = (int)(n * (1.0 - cfg->overlap));                        // fft.c:70
+  p->keep = n - p->hop;                                            // fft.c:71
+  p->bins = n / 2 + 1;
+  p->lanes = n / 64;
+  if (p->hop <= 0) { delete p; return GLFER_E_ARG; }
+
+  // --- host tables
+  p->window.assign(n, 1.0f);
+  std::vector<float> taps;
+  if (cfg->mode == GLFER_MODE_FFT) {
+    p->ntapers = 1;
+    p->npairs = 1;
+    glfer::make_window(cfg->window_type, n, p->window.data());
+    p->nonlin = (cfg->limiter_a > 0.0f) || (cfg->enable_limiter == 1);
+    // psd = |X|^2/N (fft.c:212-216); the pair packing contributes |Z_k|^2+|Z_{N-k}|^2 = 2|X_k|^2
+    const double scale = std::sqrt(1.0 / (2.0 * n));
+    p->spec_unscale = (float)scale;
+    taps.assign((size_t)2 * n, 0.0f);
+    const bool rect = (cfg->window_type == GLFER_WIN_RECTANGULAR);
+    for (int i = 0; i < n; i++) {
+      const double w = rect ? 1.0 : (double)p->window[i];          // fft.c:132,139: no multiply when rectangular
+      taps[i] = p->nonlin ? (float)w : (float)(w * scale);
+    }
+  } else {
+    p->ntapers = cfg->mtm_k + 1;                                   // mtm.c:189: j = 0..kmax inclusive
+    p->npairs = (p->ntapers + 1) / 2;
+    p->tapers.resize((size_t)p->ntapers * n);
+    p->sig.resize(p->ntapers);
+    if (!glfer::make_dpss(n, cfg->mtm_k, (double)cfg->mtm_w, p->tapers.data(), p->sig.data())) {
+      delete p;
+      return GLFER_E_NUMERIC;
+    }
+    taps.assign((size_t)2 * p->npairs * n, 0.0f);
+    for (int j = 0; j < p->ntapers; j++) {
+      // psd += |FFT(v_j x)|^2 / N / (1+sig_j)   (mtm.c:212-219), and the 1/2 of the packing
+      const double scale = std::sqrt(1.0 / (2.0 * n * (1.0 + p->sig[j])));
+      for (int i = 0; i < n; i++) taps[(size_t)j * n + i] = (float)(p->tapers[(size_t)j * n + i] * scale);
+    }
+    p->spec_unscale = 1.0f;
+  }
+  std::vector<float> tw((size_t)2 * 64 * p->lanes);
+  glfer::make_twiddles(n, p->lanes, tw.data());
+
+  // --- device tables
+  hipError_t e = hipSetDevice(cfg->device);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->d_taps, taps.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void **)&p->d_tw, tw.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(p->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    int rc = hip_fail(e, "plan_create");
+    glfer_hip_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return GLFER_OK;
+}
+
+void glfer_hip_plan_destroy(glfer_hip_plan *p) {
+  if (!p) return;
+  if (p->d_taps) (void)hipFree(p->d_taps);
+  if (p->d_tw) (void)hipFree(p->d_tw);
+  if (p->d_scratch) (void)hipFree(p->d_scratch);
+  delete p;
+}
+
+int glfer_hip_hop(const glfer_hip_plan *p) { return p ? p->hop : GLFER_E_ARG; }
+int glfer_hip_bins(const glfer_hip_plan *p) { return p ? p->bins : GLFER_E_ARG; }
+int glfer_hip_num_tapers(const glfer_hip_plan *p) { return p ? p->ntapers : GLFER_E_ARG; }
+size_t glfer_hip_num_frames(const glfer_hip_plan *p, size_t nsamples) {
+  return p ? nsamples / (size_t)p->hop : 0;
+}
+
+int glfer_hip_get_window(const glfer_hip_plan *p, float *w) {
+  if (!p || !w) return GLFER_E_ARG;
+  memcpy(w, p->window.data(), (size_t)p->n * sizeof(float));
+  return GLFER_OK;
+}
+
+int glfer_hip_get_tapers(const glfer_hip_plan *p, double *tapers, double *sig) {
+  if (!p || p->cfg.mode != GLFER_MODE_MTM) return GLFER_E_ARG;
+  if (tapers) memcpy(tapers, p->tapers.data(), p->tapers.size() * sizeof(double));
+  if (sig) memcpy(sig, p->sig.data(), p->sig.size() * sizeof(double));
+  return GLFER_OK;
+}
+
+int glfer_hip_make_window(int window_type, int n, float *window) {
+  if (!window || n < 2 || window_type < 0 || window_type > 7) return GLFER_E_ARG;
+  glfer::make_window(window_type, n, window);
+  return GLFER_OK;
+}
+
+int glfer_hip_make_dpss(int n, int kmax, double nw, double *tapers, double *sig) {
+  if (!tapers || !sig || n < 2 || kmax < 0 || kmax > 31 || !(nw > 0.0)) return GLFER_E_ARG;
+  return glfer::make_dpss(n, kmax, nw, tapers, sig) ? GLFER_OK : GLFER_E_NUMERIC;
+}
+
+static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
+  switch (n) {
+    case 256: return glfer_launch_spectro2_w4(&sp, st);
+    case 512: return glfer_launch_spectro2_w8(&sp, st);
+    case 1024: return glfer_launch_spectro2_w16(&sp, st);
+    case 2048: return glfer_launch_spectro2_w32(&sp, st);
+    case 4096: return glfer_launch_spectro2_w64(&sp, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+static int run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first,
+                      size_t nframes, float *d_psd, float *d_spec, void *hip_stream) {
+  if (!p || !d_stream || (!d_psd && nframes)) return GLFER_E_ARG;
+  if (nframes == 0) return GLFER_OK;
+  if ((first + nframes) > nsamples / (size_t)p->hop) return GLFER_E_ARG;   // frame past the stream
+  if (nframes > 0x7fffffffu) return GLFER_E_ARG;
+  if (d_spec && p->cfg.mode != GLFER_MODE_FFT) return GLFER_E_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(hipSetDevice(p->cfg.device));
+
+  SpectroParams sp;
+  memset(&sp, 0, sizeof sp);
+  sp.stream = d_stream;
+  sp.frame0 = (long long)first;
+  sp.nframes = (int)nframes;
+  sp.H = p->hop;
+  sp.R = p->keep;
+  sp.npairs = p->npairs;
+  sp.history_mode = p->cfg.history_mode ? 1 : 0;
+  sp.fmt = p->cfg.sample_format;
+  sp.nonlin = p->nonlin ? 1 : 0;
+  sp.limiter = (p->cfg.enable_limiter == 1);
+  sp.a = p->cfg.limiter_a;
+  sp.post_scale = p->spec_unscale;
+  sp.spec_unscale = p->spec_unscale;
+  sp.taps = p->d_taps;
+  sp.tw = p->d_tw;
+  sp.psd = d_psd;
+  sp.spec = d_spec;
+
+  if (p->cfg.sub_mean) {
+    // K0 (fft.c:86-96): the mean of each hop's NEW samples is removed before the hop enters
+    // the frame history, so every sample is corrected by the mean of the hop it arrived in.
+    // ZERO_ALWAYS frames see only their own hop; otherwise a frame reaches back ceil(R/H) hops
+    const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop);
+    size_t hop_lo = first;
+    if (!sp.history_mode) hop_lo = (first > hops_back) ? first - hops_back : 0;
+    const size_t nhops = first + nframes - hop_lo;
+    const size_t need = nhops * (size_t)p->hop;
+    if (need > p->scratch_floats) {
+      if (p->d_scratch) HIP_TRY(hipFree(p->d_scratch));
+      p->d_scratch = nullptr;
+      p->scratch_floats = 0;
+      HIP_TRY(hipMalloc((void **)&p->d_scratch, need * sizeof(float)));
+      p->scratch_floats = need;
+    }
+    const size_t esz = sp.fmt == GLFER_FMT_F32 ? 4 : (sp.fmt == GLFER_FMT_S16 ? 2 : 1);
+    const char *src = (const char *)d_stream + hop_lo * (size_t)p->hop * esz;
+    HIP_TRY(glfer_launch_submean(src, p->d_scratch, p->hop, (long long)nhops, sp.fmt, st));
+    sp.stream = p->d_scratch;
+    sp.fmt = GLFER_FMT_F32;
+    sp.frame0 = (long long)(first - hop_lo);
+  }
+  HIP_TRY(launch_by_n(sp, p->n, st));
+  return GLFER_OK;
+}
+
+int glfer_hip_spectrogram_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first,
+                                 size_t nframes, float *d_psd, void *hip_stream) {
+  return run_device(p, d_stream, nsamples, first, nframes, d_psd, nullptr, hip_stream);
+}
+
+int glfer_hip_spectrum_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first,
+                              size_t nframes, float *d_psd, float *d_spec, void *hip_stream) {
+  if (!d_spec) return GLFER_E_ARG;
+  return run_device(p, d_stream, nsamples, first, nframes, d_psd, d_spec, hip_stream);
+}
+
+int glfer_hip_spectrogram_host(glfer_hip_plan *p, const void *h_stream, size_t nsamples, float *h_psd,
+                               size_t *nframes_out) {
+  if (!p || !h_stream || !nframes_out) return GLFER_E_ARG;
+  const size_t frames = nsamples / (size_t)p->hop;
+  *nframes_out = frames;
+  if (frames == 0) return GLFER_OK;
+  if (!h_psd) return GLFER_E_ARG;
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  const size_t esz = p->cfg.sample_format == GLFER_SAMPLES_F32 ? 4 : (p->cfg.sample_format == GLFER_SAMPLES_S16 ? 2 : 1);
+  const size_t used = frames * (size_t)p->hop;
+  void *d_in = nullptr;
+  float *d_out = nullptr;
+  hipStream_t st = nullptr;
+  int rc = GLFER_OK;
+  hipError_t e = hipStreamCreate(&st);
+  if (e == hipSuccess) e = hipMalloc(&d_in, used * esz);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_out, frames * (size_t)p->bins * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in, h_stream, used * esz, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: staging");
+  if (rc == GLFER_OK) rc = run_device(p, d_in, used, 0, frames, d_out, nullptr, st);
+  if (rc == GLFER_OK) {
+    e = hipMemcpyAsync(h_psd, d_out, frames * (size_t)p->bins * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: copy back");
+  }
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}
+
+int glfer_hip_floor_device(const float *d_psd, size_t nframes, int bins, float *d_stats, void *hip_stream) {
+  if (!d_psd || !d_stats || bins < 1 || bins > 32769) return GLFER_E_ARG;
+  const int m = bins - (int)(bins * 0.95);                       // fft.c:271: i = N2*0.95 .. N2-1
+  HIP_TRY(glfer_launch_floor(d_psd, nframes, bins, m, d_stats, (hipStream_t)hip_stream));
+  return GLFER_OK;
+}
+
+int glfer_hip_avg_device(int avg_mode, const float *d_psd, size_t nframes, int bins, int n_out, int depth,
+                         int minbin, int maxbin, int max0, double *d_avg, double *d_ret, void *hip_stream) {
+  if (!d_psd || !d_avg || !d_ret) return GLFER_E_ARG;
+  if (avg_mode < GLFER_AVG_SUMAVG || avg_mode > GLFER_AVG_SUMEXTREME) return GLFER_E_ARG;
+  if (depth < 1 || minbin < 0 || maxbin <= minbin || maxbin > bins || maxbin > n_out || n_out < 1)
+    return GLFER_E_ARG;
+  HIP_TRY(glfer_launch_avg(avg_mode, d_psd, nframes, bins, n_out, depth, minbin, maxbin, max0 ? 1 : 0, d_avg,
+                           d_ret, (hipStream_t)hip_stream));
+  return GLFER_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,7 @@
+// host_tables.h -- once-per-plan host tables (window, DPSS tapers, twiddles).
+#pragma once
+namespace glfer {
+void make_window(int type, int n, float *w);                               // fft.c:309-360
+bool make_dpss(int n, int kmax, double nw, double *tapers, double *sig);   // g-l_dpss.c:288-347
+void make_twiddles(int n, int lanes, float *tw_re_im);                     // [64][lanes] (cos,sin)
+}  // namespace glfer

@@ -1,0 +1,42 @@
+/* spectro_params.h -- kernel argument block shared by the launchers and the C-ABI layer. */
+#ifndef GLFER_SPECTRO_PARAMS_H
+#define GLFER_SPECTRO_PARAMS_H
+
+#include <hip/hip_runtime.h>
+
+enum { GLFER_FMT_F32 = 0, GLFER_FMT_S16 = 1, GLFER_FMT_U8 = 2 };
+
+struct SpectroParams {
+  const void *stream;      /* device: sample stream (f32 / s16 / u8)                        */
+  long long frame0;        /* index of this launch's first frame in the whole stream        */
+  int nframes;             /* frames in this launch                                          */
+  int H;                   /* hop = (int)(N*(1.0-overlap))            fft.c:70               */
+  int R;                   /* N - H samples of history per frame      fft.c:71               */
+  int npairs;              /* ceil(T/2) complex transforms per frame                         */
+  int history_mode;        /* 0: zeros before sample 0 only; 1: history zeroed every frame   */
+  int fmt;                 /* GLFER_FMT_*                                                    */
+  int nonlin;              /* RA9MB / limiter path (periodogram only)                        */
+  int limiter;             /* fft.c:151-156                                                  */
+  float a;                 /* fft.c:127-136                                                  */
+  float post_scale;        /* nonlin path: sqrt(1/(2N)) applied after the limiter            */
+  float spec_unscale;      /* factor folded into taper 0 (undone for the spectrum output)    */
+  const float *taps;       /* device: [2*npairs][N] tapers/window, weights and 1/(2N) folded */
+  const float2 *tw;        /* device: [64][N/64] inter-pass twiddles W_N^(t*k1)              */
+  float *psd;              /* device: [nframes][N/2+1]                                       */
+  float *spec;             /* device, optional: [nframes][N] halfcomplex spectrum            */
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t glfer_launch_spectro2_w4(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro2_w8(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro2_w16(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro2_w32(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro2_w64(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_submean(const void *in, float *out, int H, long long nhops, int fmt,
+                                hipStream_t st);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,159 @@
+/* glfer_hip.h -- C-ABI of the MI355X spectral-estimation engine (libglfer_hip.so).
+ *
+ * This is the drop-in boundary for glfer's L2 "spectral estimator" layer: the calls
+ * that source.c:141-158 makes once per hop (fft_do + fft_psd, mtm_do) and that
+ * g_main.c:1109,1153-1183 makes once per drawn column (compute_floor, update_avg_*).
+ * The reference has no FFI; its boundary is that C function interface, so the
+ * replacement is (a) a batch API over a whole sample stream (this file) and (b)
+ * signature-compatible per-hop shims built on it (glfer_compat.h).
+ *
+ * Plain C types only: pointers, sizes, ints, floats.  Device pointers are HIP device
+ * addresses (hipMalloc / torch tensor data_ptr); `hip_stream` is a hipStream_t passed
+ * as void* (NULL = the default stream).  All functions return 0 on success or a
+ * negative GLFER_E_* code; glfer_hip_strerror() names it.  Nothing here falls back to
+ * the CPU: without a usable HIP device every compute entry point fails with
+ * GLFER_E_HIP.
+ */
+#ifndef GLFER_HIP_H
+#define GLFER_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* estimator: glfer.h:47  enum {MODE_NONE=-1, MODE_FFT, MODE_MTM, MODE_HPARMA, MODE_LMP} */
+#define GLFER_MODE_FFT 0
+#define GLFER_MODE_MTM 1
+
+/* window ids: fft.h:67 */
+#define GLFER_WIN_HANNING 0
+#define GLFER_WIN_BLACKMAN 1
+#define GLFER_WIN_GAUSSIAN 2
+#define GLFER_WIN_WELCH 3
+#define GLFER_WIN_BARTLETT 4
+#define GLFER_WIN_RECTANGULAR 5
+#define GLFER_WIN_HAMMING 6
+#define GLFER_WIN_KAISER 7
+
+/* sample formats of the stream: float [-1,1), or raw PCM converted on the device with
+ * the rules of wav_fmt.c:104-117 (u8: (x-128)/128, s16: x/32768) */
+#define GLFER_SAMPLES_F32 0
+#define GLFER_SAMPLES_S16 1
+#define GLFER_SAMPLES_U8 2
+
+/* history_mode: what the first N-H samples of a frame hold (fft.c:98-108).
+ * ZERO_FIRST : zeros before the first sample only (glfer.first_buffer cleared after
+ *              frame 0 -- what happens with opt.autoscale on, g_main.c:1111-1120)
+ * ZERO_ALWAYS: zeros in every frame (glfer.first_buffer never cleared -- what the
+ *              reference does with opt.autoscale off)                              */
+#define GLFER_HISTORY_ZERO_FIRST 0
+#define GLFER_HISTORY_ZERO_ALWAYS 1
+
+/* averaging modes: glfer.h:56-58 avgmode_t */
+#define GLFER_AVG_SUMAVG 1
+#define GLFER_AVG_PLAIN 2
+#define GLFER_AVG_SUMEXTREME 3
+
+#define GLFER_OK 0
+#define GLFER_E_ARG (-1)      /* bad argument / unsupported size             */
+#define GLFER_E_HIP (-2)      /* HIP runtime error (no device, launch, copy) */
+#define GLFER_E_NOMEM (-3)
+#define GLFER_E_NUMERIC (-4)  /* DPSS eigen-solve did not converge           */
+
+/* Everything the reference copies from `opt` into fft_params_t / mtm_params_t at
+ * change_params() time (source.c:320-325, source.c:343-350) plus the two globals the
+ * estimators read directly (opt.autoscale -> sub_mean, fft.c:186; glfer.first_buffer
+ * -> history_mode, fft.c:99). */
+typedef struct glfer_hip_config {
+  int mode;            /* GLFER_MODE_*                                                  */
+  int n;               /* opt.data_block_size; power of two, 256..4096 (round 1)        */
+  float overlap;       /* opt.data_blocks_overlap, [0,1)                                */
+  int window_type;     /* opt.window_type (FFT mode; MTM forces rectangular, source.c:344) */
+  float limiter_a;     /* opt.limiter_a  -> fft_params_t.a        (FFT mode only acts)  */
+  int enable_limiter;  /* opt.enable_limiter -> fft_params_t.limiter                    */
+  int sub_mean;        /* per-hop mean removal, fft.c:86-96                             */
+  int history_mode;    /* GLFER_HISTORY_*                                               */
+  float mtm_w;         /* opt.mtm_w = N*W time-bandwidth product (g-l_dpss.c:295-297)   */
+  int mtm_k;           /* opt.mtm_k = kmax; kmax+1 tapers are used (mtm.c:189)          */
+  int sample_format;   /* GLFER_SAMPLES_*                                               */
+  int device;          /* HIP device ordinal                                            */
+} glfer_hip_config;
+
+typedef struct glfer_hip_plan glfer_hip_plan;
+
+/* fft_init (fft.c:168-187) / mtm_init (mtm.c:88-151): builds the window or the DPSS
+ * tapers + eigenvalues on the host (double), uploads the device tables. */
+int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **plan_out);
+/* fft_close (fft.c:297-306) / mtm_close (mtm.c:242-265) */
+void glfer_hip_plan_destroy(glfer_hip_plan *plan);
+
+int glfer_hip_hop(const glfer_hip_plan *plan);      /* H = (int)(N*(1.0-overlap)), fft.c:70 */
+int glfer_hip_bins(const glfer_hip_plan *plan);     /* N/2+1, source.c:317                  */
+int glfer_hip_num_tapers(const glfer_hip_plan *plan);
+/* whole hops in nsamples (wav_fmt.c:119 hands out whole blocks only) */
+size_t glfer_hip_num_frames(const glfer_hip_plan *plan, size_t nsamples);
+
+/* Host copies of the tables, for inspection and parity tests.
+ * window: n floats (compute_window, fft.c:309-360; all ones in MTM mode).
+ * tapers: [kmax+1][n] doubles, unit energy (gl_dpss, g-l_dpss.c:288-347);
+ * sig   : kmax+1 doubles, lambda_k - 1 (g-l_dpss.c:342-344). */
+int glfer_hip_get_window(const glfer_hip_plan *plan, float *window);
+int glfer_hip_get_tapers(const glfer_hip_plan *plan, double *tapers, double *sig);
+
+/* The same two table generators without a plan or a device (pure host code): what
+ * fft_init()/mtm_init() compute before anything touches the GPU. */
+int glfer_hip_make_window(int window_type, int n, float *window);
+int glfer_hip_make_dpss(int n, int kmax, double nw, double *tapers, double *sig);
+
+/* THE hot path: frames [first_frame, first_frame+nframes) of a device-resident stream.
+ *   d_stream : device pointer to sample 0 of the stream (format = cfg.sample_format)
+ *   nsamples : samples in the stream (for bounds: frame f reads [f*H-(N-H), f*H+H))
+ *   d_psd    : device, [nframes][N/2+1] floats, row i = frame first_frame+i
+ * Equivalent to calling fft_do+fft_psd (source.c:143-144) or mtm_do (source.c:148)
+ * once per hop.  Asynchronous on hip_stream.  With sub_mean the per-hop means are
+ * removed from a device copy of the hops involved (the reference mutates the caller's
+ * buffer, fft.c:93-95; the device stream is left untouched). */
+int glfer_hip_spectrogram_device(glfer_hip_plan *plan, const void *d_stream, size_t nsamples,
+                                 size_t first_frame, size_t nframes, float *d_psd,
+                                 void *hip_stream);
+
+/* Same, also writing the halfcomplex spectrum of each tapered frame in the layout of
+ * fft_radix2.c:75-177 (data[k]=Re X_k, data[N-k]=Im X_k).  FFT mode only: this is
+ * what fft_do leaves in params->outbuf.  d_spec: [nframes][N] floats. */
+int glfer_hip_spectrum_device(glfer_hip_plan *plan, const void *d_stream, size_t nsamples,
+                              size_t first_frame, size_t nframes, float *d_psd, float *d_spec,
+                              void *hip_stream);
+
+/* Host-buffer convenience: stages h_stream through pinned memory to the device,
+ * runs the hot path and copies the PSD rows back; blocks until done.
+ * *nframes_out receives glfer_hip_num_frames(nsamples). */
+int glfer_hip_spectrogram_host(glfer_hip_plan *plan, const void *h_stream, size_t nsamples,
+                               float *h_psd, size_t *nframes_out);
+
+/* compute_floor (fft.c:240-294) for a batch of PSD rows on the device.
+ * d_stats: [nframes][4] floats = {sig (max bin), floor, peak value, peak bin as float}. */
+int glfer_hip_floor_device(const float *d_psd, size_t nframes, int bins, float *d_stats,
+                           void *hip_stream);
+
+/* update_avg_* (avg.c:108-298) over consecutive PSD rows: the sliding sum over the last
+ * `depth` frames per bin in [minbin,maxbin) and the three output normalisations.
+ * The state starts empty (alloc_avg, avg.c:38-60) at row 0 of the call.
+ *   d_avg  : [nframes][n_out] doubles (avgdata->avg after each frame; 1e-15 out of band)
+ *   d_ret  : [nframes][4] doubles = {return value, peak bin, variance (sumavg), effdepth}
+ */
+int glfer_hip_avg_device(int avg_mode, const float *d_psd, size_t nframes, int bins, int n_out,
+                         int depth, int minbin, int maxbin, int max0, double *d_avg,
+                         double *d_ret, void *hip_stream);
+
+const char *glfer_hip_strerror(int code);
+/* text of the last HIP error seen by this thread ("" if none) */
+const char *glfer_hip_last_hip_error(void);
+/* library / kernel build description, e.g. "glfer_hip 0.1 gfx950" */
+const char *glfer_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLFER_HIP_H */

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz -- golden input/output vectors for the hot path.
+
+The reference ships no fixtures.  These vectors come from the CPU oracle
+(oracle/glfer_oracle.c), run in the build container right after tests/test_oracle_vs_ref.py
+has shown it bit-identical to the reference's own fft_radix2.c / g-l_dpss.c / avg.c / util.c
+objects (oracle/_ref/).  Each file holds data only: parameters, the input samples and the
+expected outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle as O  # noqa: E402
+from _signals import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+W = O.WINDOWS
+
+
+def save(name, **kw):
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **kw)
+    print(name, {k: getattr(v, "shape", v) for k, v in kw.items()})
+
+
+def fft_case(name, n, overlap, window, frames, fs, seed, **opt):
+    h = O.hop(n, overlap)
+    x = synth(frames * h, fs=fs, seed=seed)
+    psd = O.spectrogram_fft(x, n, overlap, W[window], opt.get("a", 0.0), opt.get("limiter", 0),
+                            opt.get("sub_mean", 0), opt.get("history_mode", 0))
+    save(name, mode="fft", n=n, overlap=np.float32(overlap), window=W[window], fs=fs, seed=seed,
+         a=np.float32(opt.get("a", 0.0)), limiter=opt.get("limiter", 0),
+         sub_mean=opt.get("sub_mean", 0), history_mode=opt.get("history_mode", 0),
+         x=x, psd=psd, win=O.window(W[window], n))
+
+
+def mtm_case(name, n, overlap, nw, kmax, frames, fs, seed, **opt):
+    h = O.hop(n, overlap)
+    x = synth(frames * h, fs=fs, seed=seed)
+    psd = O.spectrogram_mtm(x, n, overlap, nw, kmax, opt.get("sub_mean", 0), opt.get("history_mode", 0))
+    v, sig = O.dpss(n, kmax, nw)
+    save(name, mode="mtm", n=n, overlap=np.float32(overlap), nw=nw, kmax=kmax, fs=fs, seed=seed,
+         sub_mean=opt.get("sub_mean", 0), history_mode=opt.get("history_mode", 0),
+         x=x, psd=psd, sig=sig, tapers_head=v[:, :64].copy(), tapers_sum=v.sum(axis=1))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # BASELINE.json configs 1-3 (+ C3 at 75 % overlap), seeds 0/1
+    fft_case("c1_fft1024_hann_ovl50_s0", 1024, 0.5, "hanning", 16, 8000.0, 0)
+    fft_case("c2_fft4096_hann_ovl75_s0", 4096, 0.75, "hanning", 12, 48000.0, 0)
+    mtm_case("c3_mtm4096_nw25_k4_ovl0_s0", 4096, 0.0, 2.5, 4, 6, 48000.0, 0)
+    mtm_case("c3_mtm4096_nw25_k4_ovl75_s1", 4096, 0.75, 2.5, 4, 10, 48000.0, 1)
+    # edge fixtures
+    fft_case("e_fft1024_kaiser_submean", 1024, 0.5, "kaiser", 10, 8000.0, 2, sub_mean=1)
+    fft_case("e_fft1024_hann_zero_always", 1024, 0.5, "hanning", 6, 8000.0, 2, history_mode=1)
+    fft_case("e_fft1024_blackman_ra9mb", 1024, 0.25, "blackman", 6, 8000.0, 1, a=0.001)
+    fft_case("e_fft1024_hamming_limiter", 1024, 0.0, "hamming", 4, 8000.0, 1, limiter=1)
+    fft_case("e_fft1024_rect_ovl90", 1024, 0.9, "rectangular", 40, 8000.0, 0)
+    fft_case("e_fft256_welch", 256, 0.5, "welch", 8, 8000.0, 0)
+    fft_case("e_fft2048_gauss", 2048, 0.5, "gaussian", 6, 48000.0, 0)
+    fft_case("e_fft512_bartlett", 512, 0.0, "bartlett", 5, 8000.0, 0)
+    mtm_case("e_mtm1024_nw4_k7_submean", 1024, 0.5, 4.0, 7, 8, 8000.0, 1, sub_mean=1)
+    # halfcomplex spectrum of one Hanning frame (what fft_do leaves in outbuf)
+    x = synth(4096, seed=3)
+    w = O.window(W["hanning"], 4096)
+    save("spec_fft4096_hann", x=x, win=w, halfcomplex=O.rfft_halfcomplex(w * x))
+    # averaging (avg.c) and floor (fft.c:240-294) on a C1-like PSD sequence
+    x = synth(20 * 512, fs=8000.0, seed=4)
+    psd = O.spectrogram_fft(x, 1024, 0.5, W["hanning"])
+    avg_out = {}
+    for mode in ("plain", "sumextreme", "sumavg"):
+        for max0 in (0, 1):
+            a = O.Averager(1024, 4)
+            rows, rets = [], []
+            for f in range(psd.shape[0]):
+                r, avg, peak, var = a.update(mode, psd[f], 25, 450, max0=max0, n=513)
+                rows.append(avg)
+                rets.append([r, peak, var])
+            avg_out["%s_max%d_avg" % (mode, max0)] = np.array(rows)
+            avg_out["%s_max%d_ret" % (mode, max0)] = np.array(rets)
+    fl = np.array([O.floor_stats(p) for p in psd], np.float64)
+    save("avg_floor_fft1024", psd=psd, depth=4, minbin=25, maxbin=450, floor=fl, **avg_out)
+
+
+if __name__ == "__main__":
+    main()
