@@ -14,6 +14,10 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#ifndef GLFER_BFLY_GROUP
+#define GLFER_BFLY_GROUP 4
+#endif
+
 namespace glfer {
 
 template <int I, int N, class F>
@@ -103,6 +107,10 @@ __device__ __forceinline__ void dit(float (&re)[64], float (&im)[64]) {
       constexpr int k = decltype(kc)::value;
       constexpr int pa = OFF + 2 * S * brev(k, R / 2);
       bfly<R, k, pa, pa + S>(re, im);
+      // keep at most GLFER_BFLY_GROUP butterflies in one scheduling region: left alone, the
+      // scheduler interleaves all R/2 independent butterflies and their temporaries spill
+      if constexpr (GLFER_BFLY_GROUP > 0 && (k % GLFER_BFLY_GROUP) == GLFER_BFLY_GROUP - 1)
+        __builtin_amdgcn_sched_barrier(0);
     });
   }
 }

@@ -21,7 +21,8 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int MODE>
-__global__ __launch_bounds__(256) void valu_kernel(float *out, int iters, float seed) {
+__global__ __launch_bounds__(256) void valu_kernel(float *out, int iters, float seed, unsigned long long *clk) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   // 16 independent accumulator chains
   v2f acc[16];
 #pragma unroll
@@ -49,6 +50,10 @@ __global__ __launch_bounds__(256) void valu_kernel(float *out, int iters, float 
 #pragma unroll
   for (int i = 0; i < 16; i++) s += acc[i].x + acc[i].y;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = __builtin_amdgcn_s_memtime() - t0;        // shader clocks
+    clk[1] = __builtin_amdgcn_s_memrealtime() - r0;    // 100 MHz ticks
+  }
 }
 
 template <int MODE>
@@ -58,18 +63,23 @@ static void run_valu(const char *name, int blocks_per_cu, float *d_out) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const int grid = 256 * blocks_per_cu;
-  hipLaunchKernelGGL(valu_kernel<MODE>, dim3(grid), dim3(256), 0, 0, d_out, 100, 1.0f);
+  static unsigned long long *d_clk = nullptr;
+  if (!d_clk) CK(hipMalloc((void **)&d_clk, 16));
+  hipLaunchKernelGGL(valu_kernel<MODE>, dim3(grid), dim3(256), 0, 0, d_out, 100, 1.0f, d_clk);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL(valu_kernel<MODE>, dim3(grid), dim3(256), 0, 0, d_out, iters, 1.0f);
+  hipLaunchKernelGGL(valu_kernel<MODE>, dim3(grid), dim3(256), 0, 0, d_out, iters, 1.0f, d_clk);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
   // lane-results per second: each loop iteration produces 32 float results per lane
   const double lane_ops = (double)grid * 256 * (double)iters * 32.0;
-  printf("valu %-14s waves/SIMD=%d  %.3f ms  %.2f T lane-results/s  (%.1f per clk per SIMD @2.4GHz)\n", name,
-         blocks_per_cu, ms, lane_ops / ms / 1e9, lane_ops / (ms * 1e-3) / (256.0 * 4 * 2.4e9));
+  unsigned long long clk[2];
+  CK(hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost));
+  const double mhz = (double)clk[0] / (double)clk[1] * 100.0;
+  printf("valu %-10s waves/SIMD=%d  %.3f ms  %.2f T lane-results/s  clock %.0f MHz  -> %.1f lanes/clk/SIMD\n", name,
+         blocks_per_cu, ms, lane_ops / ms / 1e9, mhz, lane_ops / (ms * 1e-3) / (256.0 * 4 * mhz * 1e6));
 }
 
 static std::vector<float> synth(size_t n) {
@@ -91,11 +101,10 @@ int main(int argc, char **argv) {
 
   float *d_out;
   CK(hipMalloc((void **)&d_out, 256 * 8 * 256 * sizeof(float)));
-  for (int w = 1; w <= 2; w++) {
+  const int wlist[] = {1, 2, 3, 4, 6, 8};
+  for (int w : wlist) {
     run_valu<0>("2x v_fma", w, d_out);
-    run_valu<1>("v_pk_fma", w, d_out);
-    run_valu<2>("v_pk_mul", w, d_out);
-    run_valu<3>("v_pk_add", w, d_out);
+    if (w <= 2) run_valu<1>("v_pk_fma", w, d_out);
     run_valu<4>("2x v_add", w, d_out);
   }
 
