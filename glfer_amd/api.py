@@ -54,6 +54,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (same soname as /opt/rocm's); load it first so that
+    # this process ends up with ONE runtime shared by torch tensors/streams and our kernels
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise GlferHipError(
             "HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
