@@ -76,8 +76,8 @@ constexpr cplx64 unit_root(int j, int R) {
 }
 
 // One DIT combine stage entry: a at index PA, b at PB, forward twiddle exp(-i 2 pi K / R).
-template <int R, int K, int PA, int PB>
-__device__ __forceinline__ void bfly(float (&re)[64], float (&im)[64]) {
+template <int R, int K, int PA, int PB, int LEN>
+__device__ __forceinline__ void bfly(float (&re)[LEN], float (&im)[LEN]) {
   const float ar = re[PA], ai = im[PA], br = re[PB], bi = im[PB];
   if constexpr (K == 0) {
     re[PA] = ar + br; im[PA] = ai + bi;
@@ -98,15 +98,15 @@ __device__ __forceinline__ void bfly(float (&re)[64], float (&im)[64]) {
 
 // R-point forward DFT over the elements OFF + S*i (i = 0..R-1, natural order).
 // Result X[k] is left at index OFF + S*brev(k, R).
-template <int R, int S, int OFF>
-__device__ __forceinline__ void dit(float (&re)[64], float (&im)[64]) {
+template <int R, int S, int OFF, int LEN>
+__device__ __forceinline__ void dit(float (&re)[LEN], float (&im)[LEN]) {
   if constexpr (R >= 2) {
-    dit<R / 2, 2 * S, OFF>(re, im);
-    dit<R / 2, 2 * S, OFF + S>(re, im);
+    dit<R / 2, 2 * S, OFF, LEN>(re, im);
+    dit<R / 2, 2 * S, OFF + S, LEN>(re, im);
     static_for<0, R / 2>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       constexpr int pa = OFF + 2 * S * brev(k, R / 2);
-      bfly<R, k, pa, pa + S>(re, im);
+      bfly<R, k, pa, pa + S, LEN>(re, im);
       // keep at most GLFER_BFLY_GROUP butterflies in one scheduling region: left alone, the
       // scheduler interleaves all R/2 independent butterflies and their temporaries spill
       if constexpr (GLFER_BFLY_GROUP > 0 && (k % GLFER_BFLY_GROUP) == GLFER_BFLY_GROUP - 1)

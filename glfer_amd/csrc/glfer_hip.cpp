@@ -58,7 +58,7 @@ static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 extern "C" {
 
-const char *glfer_hip_version(void) { return "glfer_hip 0.1 (gfx950, wave-per-frame radix-64x64)"; }
+const char *glfer_hip_version(void) { return "glfer_hip 0.2 (gfx950, 16 points/lane Stockham radix-16, LDS exchange)"; }
 
 const char *glfer_hip_strerror(int code) {
   switch (code) {
@@ -77,7 +77,7 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   if (!cfg || !out) return GLFER_E_ARG;
   *out = nullptr;
   const int n = cfg->n;
-  if (!is_pow2(n) || n < 256 || n > 4096) return GLFER_E_ARG;
+  if (!is_pow2(n) || n < 256 || n > 16384) return GLFER_E_ARG;
   if (!(cfg->overlap >= 0.0f) || !(cfg->overlap < 1.0f)) return GLFER_E_ARG;   // g_options.c:1030
   if (cfg->mode != GLFER_MODE_FFT && cfg->mode != GLFER_MODE_MTM) return GLFER_E_ARG;
   if (cfg->sample_format < 0 || cfg->sample_format > 2) return GLFER_E_ARG;
@@ -129,8 +129,11 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     }
     p->spec_unscale = 1.0f;
   }
-  std::vector<float> tw((size_t)2 * 64 * p->lanes);
-  glfer::make_twiddles(n, p->lanes, tw.data());
+  int logn = 0;
+  while ((1 << logn) < n) logn++;
+  p->lanes = n / 16;
+  std::vector<float> tw((size_t)2 * glfer::make_twiddles16(logn, nullptr) * p->lanes);
+  glfer::make_twiddles16(logn, tw.data());
 
   // --- device tables
   hipError_t e = hipSetDevice(cfg->device);
@@ -188,11 +191,13 @@ int glfer_hip_make_dpss(int n, int kmax, double nw, double *tapers, double *sig)
 
 static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   switch (n) {
-    case 256: return glfer_launch_spectro2_w4(&sp, st);
-    case 512: return glfer_launch_spectro2_w8(&sp, st);
-    case 1024: return glfer_launch_spectro2_w16(&sp, st);
-    case 2048: return glfer_launch_spectro2_w32(&sp, st);
-    case 4096: return glfer_launch_spectro2_w64(&sp, st);
+    case 256: return glfer_launch_spectro16_n8(&sp, st);
+    case 512: return glfer_launch_spectro16_n9(&sp, st);
+    case 1024: return glfer_launch_spectro16_n10(&sp, st);
+    case 2048: return glfer_launch_spectro16_n11(&sp, st);
+    case 4096: return glfer_launch_spectro16_n12(&sp, st);
+    case 8192: return glfer_launch_spectro16_n13(&sp, st);
+    case 16384: return glfer_launch_spectro16_n14(&sp, st);
   }
   return hipErrorInvalidValue;
 }

@@ -197,4 +197,38 @@ void make_twiddles(int n, int lanes, float *tw_re_im) {
     }
 }
 
+// Radix schedule of spectro16.hip (Plan16): 16, 16, then N/256 (N <= 4096) or 16, N/4096.
+int plan16_passes(int logn, int radix[4]) {
+  const int n = 1 << logn;
+  int np = logn <= 8 ? 2 : (logn <= 12 ? 3 : 4);
+  radix[0] = radix[1] = 16;
+  if (np == 3) radix[2] = n / 256;
+  if (np == 4) { radix[2] = 16; radix[3] = n / 4096; }
+  return np;
+}
+
+// Per-lane inter-pass twiddles of the Stockham passes, slot-major [slot][T] (cos, sin):
+// pass i >= 1, butterfly b, input q >= 1 -> W_(Ls*R)^(k*q) with k = (t + T*b) mod Ls.
+int make_twiddles16(int logn, float *tw_re_im) {
+  const int n = 1 << logn, T = n / 16;
+  int radix[4];
+  const int np = plan16_passes(logn, radix);
+  int slot = 0, ls = radix[0];
+  for (int i = 1; i < np; i++) {
+    const int R = radix[i], B = 16 / R;
+    for (int b = 0; b < B; b++)
+      for (int q = 1; q < R; q++, slot++)
+        for (int t = 0; t < T; t++) {
+          const long long k = (t + (long long)T * b) % ls;
+          const double ang = -2.0 * kPiD * (double)((k * q) % ((long long)ls * R)) / (double)((long long)ls * R);
+          if (tw_re_im) {
+            tw_re_im[2 * ((size_t)slot * T + t) + 0] = (float)std::cos(ang);
+            tw_re_im[2 * ((size_t)slot * T + t) + 1] = (float)std::sin(ang);
+          }
+        }
+    ls *= R;
+  }
+  return slot;
+}
+
 }  // namespace glfer

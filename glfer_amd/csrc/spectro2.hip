@@ -155,7 +155,7 @@ __device__ __forceinline__ void spectro2_body(const SpectroParams &p, float *lds
     });
 
     // ---- pass 1: 64-point DFT over r; X[k1] lands at register brev(k1,64)
-    dit<64, 1, 0>(zr, zi);
+    dit<64, 1, 0, 64>(zr, zi);
 
     if constexpr (W > 1) {
       // ---- twiddle W_N^(t*k1), in chunks of 16 rows of the [64][W] table
@@ -212,7 +212,7 @@ __device__ __forceinline__ void spectro2_body(const SpectroParams &p, float *lds
       // ---- pass 2: G transforms of length W over n2; X[k2] at g*W + brev(k2,W)
       static_for<0, G>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        dit<W, 1, g * W>(zr, zi);
+        dit<W, 1, g * W, 64>(zr, zi);
       });
     }
 
@@ -271,28 +271,6 @@ __global__ __launch_bounds__(256, WPS) void spectro2_kernel(SpectroParams p) {
   else spectro2_body<W, FMT, GEN, false>(p, lds);
 }
 
-// ---------------------------------------------------------------------------
-// K0: per-hop mean removal (fft.c:86-96).  One block per hop; writes a float copy
-// of the stream (the reference mutates the caller's hop buffer in place).
-template <int FMT>
-__global__ __launch_bounds__(256) void submean_kernel(const void *in, float *out, int H,
-                                                      long long nhops) {
-  __shared__ float part[256];
-  const long long hop = blockIdx.x;
-  if (hop >= nhops) return;
-  const long long base = hop * (long long)H;
-  float s = 0.0f;
-  for (int i = threadIdx.x; i < H; i += 256) s += load_sample<FMT>(in, base + i);
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-    __syncthreads();
-  }
-  const float mean = part[0] / (float)H;
-  for (int i = threadIdx.x; i < H; i += 256) out[base + i] = load_sample<FMT>(in, base + i) - mean;
-}
-
 }  // namespace glfer
 
 // ---------------------------------------------------------------------------
@@ -329,17 +307,5 @@ extern "C" hipError_t GLFER_CAT(glfer_launch_spectro2_w, GLFER_W)(const SpectroP
   return hipErrorInvalidValue;
 }
 
-#if GLFER_W == 64
-extern "C" hipError_t glfer_launch_submean(const void *in, float *out, int H, long long nhops,
-                                           int fmt, hipStream_t st) {
-  if (nhops <= 0) return hipSuccess;
-  switch (fmt) {
-    case GLFER_FMT_F32: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_F32>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
-    case GLFER_FMT_S16: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_S16>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
-    case GLFER_FMT_U8: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_U8>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-#endif
+
 #endif  // GLFER_NO_LAUNCHERS

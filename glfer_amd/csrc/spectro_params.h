@@ -21,7 +21,7 @@ struct SpectroParams {
   float post_scale;        /* nonlin path: sqrt(1/(2N)) applied after the limiter            */
   float spec_unscale;      /* factor folded into taper 0 (undone for the spectrum output)    */
   const float *taps;       /* device: [2*npairs][N] tapers/window, weights and 1/(2N) folded */
-  const float2 *tw;        /* device: [64][N/64] inter-pass twiddles W_N^(t*k1)              */
+  const float2 *tw;        /* device: [slots][N/16] per-lane inter-pass twiddles (cos,sin)    */
   float *psd;              /* device: [nframes][N/2+1]                                       */
   float *spec;             /* device, optional: [nframes][N] halfcomplex spectrum            */
 };
@@ -29,11 +29,13 @@ struct SpectroParams {
 #ifdef __cplusplus
 extern "C" {
 #endif
-hipError_t glfer_launch_spectro2_w4(const SpectroParams *p, hipStream_t st);
-hipError_t glfer_launch_spectro2_w8(const SpectroParams *p, hipStream_t st);
-hipError_t glfer_launch_spectro2_w16(const SpectroParams *p, hipStream_t st);
-hipError_t glfer_launch_spectro2_w32(const SpectroParams *p, hipStream_t st);
-hipError_t glfer_launch_spectro2_w64(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16_n8(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16_n9(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16_n10(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16_n11(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16_n12(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16_n13(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16_n14(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_submean(const void *in, float *out, int H, long long nhops, int fmt,
                                 hipStream_t st);
 #ifdef __cplusplus

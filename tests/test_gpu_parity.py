@@ -85,7 +85,7 @@ def test_all_windows(lib, oracle, torch_cuda, window):
     assert max(max(rel_err(got[f], want[f])) for f in range(12)) < TOL
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384])
 def test_block_sizes_fft_and_mtm(lib, oracle, torch_cuda, n):
     x = synth(9 * n, seed=n)
     sp, got = _run(lib, torch_cuda, lib.FftParams(n=n, window_type=0, overlap=0.0), x)

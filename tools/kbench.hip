@@ -14,6 +14,7 @@
 
 #define GLFER_NO_LAUNCHERS
 #include "spectro2.hip"
+#include "spectro16.hip"
 #include "host_tables.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -153,13 +154,48 @@ int main(int argc, char **argv) {
              ms, fps / 1e6, fps * (4.0 * H + 4.0 * P) / 1e9, fps * (4.0 * H + 4.0 * P) / 8e12 * 100);
     }
   }
+  // ---- v3: 16 points per lane, 256 lanes per frame, Stockham radix-16 with LDS exchange
+  std::vector<float> tw16((size_t)2 * glfer::make_twiddles16(12, nullptr) * (N / 16));
+  glfer::make_twiddles16(12, tw16.data());
+  float2 *d_tw16;
+  float *d_psd3;
+  CK(hipMalloc((void **)&d_tw16, tw16.size() * 4));
+  CK(hipMalloc((void **)&d_psd3, (size_t)nframes * P * 4));
+  CK(hipMemcpy(d_tw16, tw16.data(), tw16.size() * 4, hipMemcpyHostToDevice));
+  SpectroParams sq = sp;
+  sq.tw = d_tw16;
+  sq.psd = d_psd3;
+  for (int variant = 2; variant <= 4; variant++) {
+    for (int rep = 0; rep < 4; rep++) {
+      CK(hipEventRecord(e0));
+      if (variant == 2) hipLaunchKernelGGL((glfer::spectro16_kernel<12, GLFER_FMT_F32, false, 2>), dim3(nframes), dim3(256), 0, 0, sq);
+      else if (variant == 3) hipLaunchKernelGGL((glfer::spectro16_kernel<12, GLFER_FMT_F32, false, 3>), dim3(nframes), dim3(256), 0, 0, sq);
+      else hipLaunchKernelGGL((glfer::spectro16_kernel<12, GLFER_FMT_F32, false, 4>), dim3(nframes), dim3(256), 0, 0, sq);
+      CK(hipGetLastError());
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double fps = nframes / (ms * 1e-3);
+      printf("spectro16<12> WPS=%d rep %d: %.3f ms  %.2f Mframes/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)\n", variant, rep,
+             ms, fps / 1e6, fps * (4.0 * H + 4.0 * P) / 1e9, fps * (4.0 * H + 4.0 * P) / 8e12 * 100);
+    }
+  }
+  {
+    std::vector<float> a((size_t)64 * P), b((size_t)64 * P);
+    CK(hipMemcpy(a.data(), d_psd2, a.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(b.data(), d_psd3, b.size() * 4, hipMemcpyDeviceToHost));
+    double mx = 0, md = 0;
+    for (size_t i = 0; i < a.size(); i++) { mx = fmax(mx, fabs(a[i])); md = fmax(md, fabs(a[i] - b[i])); }
+    printf("spectro16 vs spectro2, first 64 frames: max|d|/max = %.3e\n", md / mx);
+  }
   // ---- correctness: frame 0 and frame 7 against a float64 DFT
   std::vector<float> g1(2 * P), g2(2 * P);
   double worst = 0;
   for (int fi = 0; fi < 2; fi++) {
     const int f = fi ? 7 : 0;
     CK(hipMemcpy(g1.data(), d_psd1 + (size_t)f * P, P * 4, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(g2.data(), d_psd2 + (size_t)f * P, P * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(g2.data(), d_psd3 + (size_t)f * P, P * 4, hipMemcpyDeviceToHost));
     std::vector<double> ref(P, 0.0);
     for (int j = 0; j < T; j++) {
       for (int k = 0; k < P; k += 37) {       // sampled bins
