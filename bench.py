@@ -151,7 +151,7 @@ def main():
                        "tapers": ntap, "sharding": "frame ranges, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "spectro2_kernel<64>", "kernel_ms": kernel_ms,
+                         "kernel": "spectro16_kernel<12>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_frame": b_alg,
                          "note": "MTM is FP32-VALU-bound on this chip (SURVEY 7): see valu_frac"},
             "hbm_gbs_aggregate": fps * b_alg / 1e9,

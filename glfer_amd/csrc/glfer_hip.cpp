@@ -46,7 +46,7 @@ struct glfer_hip_plan {
   std::vector<float> window;        // [n] as the reference stores it (unit power)
   std::vector<double> tapers;       // [ntapers][n]
   std::vector<double> sig;          // [ntapers]
-  float *d_taps = nullptr;          // [2*npairs][n] scaled tables
+  float *d_taps = nullptr;          // [npairs][n][2] scaled tables, taper pair interleaved
   float2 *d_tw = nullptr;           // [64][lanes]
   float *d_scratch = nullptr;       // sub_mean copy of the hops of one call
   size_t scratch_floats = 0;
@@ -106,11 +106,12 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     // psd = |X|^2/N (fft.c:212-216); the pair packing contributes |Z_k|^2+|Z_{N-k}|^2 = 2|X_k|^2
     const double scale = std::sqrt(1.0 / (2.0 * n));
     p->spec_unscale = (float)scale;
+    // device layout: taps[pair][i] = (taper 2*pair, taper 2*pair+1)[i], interleaved
     taps.assign((size_t)2 * n, 0.0f);
     const bool rect = (cfg->window_type == GLFER_WIN_RECTANGULAR);
     for (int i = 0; i < n; i++) {
       const double w = rect ? 1.0 : (double)p->window[i];          // fft.c:132,139: no multiply when rectangular
-      taps[i] = p->nonlin ? (float)w : (float)(w * scale);
+      taps[2 * (size_t)i] = p->nonlin ? (float)w : (float)(w * scale);
     }
   } else {
     p->ntapers = cfg->mtm_k + 1;                                   // mtm.c:189: j = 0..kmax inclusive
@@ -125,7 +126,8 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     for (int j = 0; j < p->ntapers; j++) {
       // psd += |FFT(v_j x)|^2 / N / (1+sig_j)   (mtm.c:212-219), and the 1/2 of the packing
       const double scale = std::sqrt(1.0 / (2.0 * n * (1.0 + p->sig[j])));
-      for (int i = 0; i < n; i++) taps[(size_t)j * n + i] = (float)(p->tapers[(size_t)j * n + i] * scale);
+      for (int i = 0; i < n; i++)
+        taps[((size_t)(j / 2) * n + i) * 2 + (j & 1)] = (float)(p->tapers[(size_t)j * n + i] * scale);
     }
     p->spec_unscale = 1.0f;
   }

@@ -24,8 +24,14 @@
 #include "fft_inreg.hpp"
 #include "spectro_params.h"
 
+#ifndef GLFER16_LAYOUT
+#define GLFER16_LAYOUT 0      /* 0: +1-per-16 padded exchange; 1: row/natural layouts */
+#endif
+#ifndef GLFER16_STAGGER
+#define GLFER16_STAGGER 8     /* start delay, in s_sleep units, per (blockIdx/256)%4 */
+#endif
 #ifndef GLFER16_WAVES_PER_SIMD
-#define GLFER16_WAVES_PER_SIMD 4
+#define GLFER16_WAVES_PER_SIMD 3
 #endif
 
 namespace glfer {
@@ -56,7 +62,6 @@ struct Plan16 {
   static constexpr int NTW = tw_offset(NPASS);                        // twiddles per lane
 };
 
-__device__ __forceinline__ int pad16(int a) { return a + (a >> 4); }
 
 // sample formats: wav_fmt.c:104-117
 template <int FMT>
@@ -93,75 +98,144 @@ __device__ __forceinline__ void frame_sync() {
   }
 }
 
-template <int LOGN, int FMT, bool GEN, bool FAST>
-__device__ __forceinline__ void spectro16_body(const SpectroParams &p, v2f32 *lds) {
+template <int LOGN>
+struct Launch16 {
+  static constexpr int T = Plan16<LOGN>::T;
+  static constexpr int FPB = T >= 256 ? 1 : 256 / T;          // frames per block
+  static constexpr int BLOCK = T * FPB;
+  static constexpr int PADN = Plan16<LOGN>::N + Plan16<LOGN>::N / 16;   // covers both exchange layouts
+  static constexpr int LDS_WORDS = FPB * PADN + 16 * 17;       // + pass-1 twiddle table [16][17] (padded rows)
+};
+
+// One kernel, persistent blocks.  The work of a block is a flat sequence of ROUNDS
+// (frame group, taper pair); the 48 loads of round r+1 (16 samples, 2x16 taper values per
+// lane) are issued right after round r has handed its data to LDS, so they fly under the
+// remaining two passes instead of stalling the next round.
+// ABL (timing ablations for tools/kbench only; results are wrong for ABL != 0):
+//   1 = skip the LDS exchanges and barriers, 2 = skip the butterflies and twiddles, 3 = skip the global gathers
+template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD, int ABL = 0, int LAY = GLFER16_LAYOUT, int STG = GLFER16_STAGGER>
+__global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(SpectroParams p) {
   using C = Plan16<LOGN>;
-  constexpr int N = C::N, T = C::T, NPASS = C::NPASS, NTW = C::NTW;
-  constexpr int FPB = T >= 256 ? 1 : 256 / T;
-  constexpr int PADN = N + N / 16;
+  using L = Launch16<LOGN>;
+  constexpr int N = C::N, T = C::T, NPASS = C::NPASS, FPB = L::FPB, PADN = L::PADN;
+  constexpr int TW1 = 15;                       // pass-1 (Ls=16) twiddles: shared LDS table
+  constexpr int NTWR = C::NTW - TW1;            // later passes: per lane, in registers
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  __shared__ v2f32 lds[L::LDS_WORDS];
 
   const unsigned tid = threadIdx.x;
   const unsigned t = tid % T;
   const unsigned fl = tid / T;
-  const long long fblk = (long long)blockIdx.x * FPB;
-  const long long f = fblk + fl;
-  const bool live = f < p.nframes;
-  const unsigned flc = live ? fl : (unsigned)(p.nframes - 1 - fblk);   // clamp: loads stay in range
   v2f32 *xb = lds + fl * PADN;
+  v2f32 *tw1 = lds + FPB * PADN;                // [k][q] = W_256^(k*q), k,q < 16
 
-  // Stream index of frame-relative sample j is sblk + flc*H + j with sblk wave-uniform.  The
-  // descriptor starts at sample max(sblk,0); samples before the stream (first frames only)
-  // get a negative offset, i.e. a huge unsigned one, and read 0 by the range check --
-  // the zero history of fft.c:103-108 without a branch.
-  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
-  const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
-  const long long sbase = sblk > 0 ? sblk : 0;
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sbase * (long long)esz, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(p.taps), 0, p.npairs * 2 * N * 4, 0x00020000);
-  const int lrel = (int)(sblk - sbase) + (int)(flc * (unsigned)p.H + t);   // lane's first sample, relative to sbase
-  const unsigned toff = t * 4u;
-
-  // ---- this lane's inter-pass twiddles, fixed for the launch
-  float twr[NTW], twi[NTW];
+  // ---- twiddles: pass 1's 16x16 table to LDS (same for every lane with equal t%16), the
+  // later passes' per-lane values to registers; both fixed for the launch
   {
     const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.tw);
+    if (tid < 256) {
+      const unsigned k = tid >> 4, q = tid & 15;
+      // rows padded to 17 entries: the 16 distinct rows a wave reads land in different banks
+      tw1[k * 17 + q] = q ? tw[(q - 1) * T + k] : v2f32{1.0f, 0.0f};     // slot q-1, lane k (k < 16 <= T)
+    }
+  }
+  float twr[NTWR > 0 ? NTWR : 1], twi[NTWR > 0 ? NTWR : 1];
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.tw) + t;
 #pragma unroll
-    for (int e = 0; e < NTW; e++) {
-      const v2f32 w = tw[e * T + t];
+    for (int e = 0; e < NTWR; e++) {
+      const v2f32 w = tw[(TW1 + e) * T];
       twr[e] = w.x;
       twi[e] = w.y;
     }
   }
+  __syncthreads();
+  const v2f32 *tw1row = tw1 + (t & 15) * 17;
+
+  const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.taps), 0, p.npairs * 2 * N * 4, 0x00020000);
+  const unsigned toff = t * 8u;
+  const long long stride = (long long)gridDim.x * FPB;
+
+  // ---- registers filled ahead of use: the frame's samples (once per frame) and the NEXT
+  // round's taper pair (tables are stored interleaved, taps[pair][j] = (taper 2p, taper 2p+1)[j],
+  // so one 8-byte load brings both)
+  float px[16];
+  v2f32 pt[16];
+  auto prefetch_x = [&](long long fblk) {
+    if constexpr (ABL == 3) {
+#pragma unroll
+      for (int m = 0; m < 16; m++) px[m] = 0.5f + m;
+      return;
+    }
+    // Stream index of frame-relative sample j is sblk + flc*H + j with sblk wave-uniform.  The
+    // descriptor starts at sample max(sblk,0); samples before the stream (first frames only)
+    // get a negative offset -- a huge unsigned one -- and read 0 by the range check: the
+    // zero history of fft.c:103-108 without a branch.
+    const long long f = fblk + fl;
+    const unsigned flc = f < p.nframes ? fl : (unsigned)(p.nframes - 1 - fblk);   // clamp: loads stay in range
+    const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
+    const long long sbase = sblk > 0 ? sblk : 0;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sbase * (long long)esz, 0, 0x7fffffff, 0x00020000);
+    const int lrel = (int)(sblk - sbase) + (int)(flc * (unsigned)p.H + t);   // lane's first sample, relative to sbase
+    if (sblk >= 0 && p.history_mode == 0) {        // wave-uniform: no per-element predicate needed
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        px[m] = buf_sample<FMT>(xrsrc, (unsigned)lrel * esz, (unsigned)(T * m) * esz);
+      });
+    } else {
+      // first frames of the stream, or history zeroed in every frame (fft.c:103-108 with
+      // glfer.first_buffer stuck): per-element offset, forced out of range where zero is due
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const int j = T * m + (int)t;
+        const int rel = lrel + T * m;
+        const bool ok = p.history_mode ? (j >= p.R) : (rel >= 0);
+        const float x = buf_sample<FMT>(xrsrc, ok ? (unsigned)rel * esz : 0x80000000u, 0u);
+        px[m] = ok ? x : 0.0f;             // raw 0 is not sample 0.0 for u8 ((0-128)/128)
+      });
+    }
+  };
+  auto prefetch_taps = [&](int pair) {
+    if constexpr (ABL == 3) {
+#pragma unroll
+      for (int m = 0; m < 16; m++) pt[m] = v2f32{0.25f, 0.125f * (float)pair};
+      return;
+    }
+    const unsigned tap_p = (unsigned)pair * (N * 8u);              // byte offset of this pair's table (uniform)
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      pt[m] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(trsrc, toff, tap_p + (unsigned)(T * m) * 8u, 0));
+    });
+  };
+
+  if constexpr (STG > 0) {
+    // de-phase co-resident blocks so that their VALU, LDS and load phases interleave
+    const unsigned ph = (blockIdx.x >> 8) & 3;
+    for (unsigned i = 0; i < ph; i++) __builtin_amdgcn_s_sleep(STG);
+  }
+  long long fblk = (long long)blockIdx.x * FPB;
+  if (fblk >= p.nframes) return;
+  int pair = 0;
+  prefetch_x(fblk);
+  prefetch_taps(0);
 
   float acc[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 
-  for (int pair = 0; pair < p.npairs; pair++) {
+  while (true) {
+    // ---- form the packed complex frame: re = x*taper(2*pair), im = x*taper(2*pair+1)
     float zr[16], zi[16];
-    const unsigned tap_a = (unsigned)(2 * pair) * (N * 4u);      // byte offset of taper 2*pair (uniform)
-    // ---- gather: lane t takes samples j = t + T*m (coalesced across the frame's lanes)
-    static_for<0, 16>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      float x;
-      if constexpr (FAST) {
-        x = buf_sample<FMT>(xrsrc, (unsigned)lrel * esz, (unsigned)(T * m) * esz);
-      } else {
-        // first frames of the stream, or history zeroed in every frame (fft.c:103-108 with
-        // glfer.first_buffer stuck): a per-element offset, forced out of range where zero is due
-        const int j = T * m + (int)t;
-        const int rel = lrel + T * m;
-        const bool ok = p.history_mode ? (j >= p.R) : (rel >= 0);
-        x = buf_sample<FMT>(xrsrc, ok ? (unsigned)rel * esz : 0x80000000u, 0u);
-      }
-      const float wa = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(trsrc, toff, tap_a + (unsigned)(T * m) * 4u, 0));
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      float x = px[m];
       if (GEN && p.nonlin) {
         // fft.c:127-156: RA9MB x/(a+x^2), window, then sign(y)*|y|^0.1; the unit-power
         // scale is applied afterwards (post_scale) because the limiter is not linear.
         if (p.a > 0.0f) x = x / (p.a + x * x);
-        float y = x * wa;
+        float y = x * pt[m].x;
         if (p.limiter) {
           const float mag = __expf(0.1f * __logf(fabsf(y)));
           y = (y > 0.0f) ? mag : -mag;
@@ -169,23 +243,41 @@ __device__ __forceinline__ void spectro16_body(const SpectroParams &p, v2f32 *ld
         zr[m] = y * p.post_scale;
         zi[m] = 0.0f;
       } else {
-        const float wb = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(trsrc, toff, tap_a + (unsigned)(N + T * m) * 4u, 0));
-        zr[m] = x * wa;
-        zi[m] = x * wb;
+        zr[m] = x * pt[m].x;
+        zi[m] = x * pt[m].y;
       }
-    });
+    }
+
+    // ---- which round comes next (wave-uniform)
+    int npair = pair + 1;
+    long long nfblk = fblk;
+    if (npair == p.npairs) {
+      npair = 0;
+      nfblk += stride;
+    }
+    const bool has_next = nfblk < p.nframes;
 
     // ---- Stockham passes
     static_for<0, NPASS>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       constexpr int R = C::radix(i), Ls = C::ls(i), B = 16 / R;
-      if constexpr (i > 0) {
+      if constexpr (ABL == 2) {
+      } else if constexpr (i == 1) {
+        // twiddle W_256^(k*q), k = t mod 16, from the shared LDS table
+        static_for<1, 16>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const v2f32 w = tw1row[q];
+          const float a = zr[q], c = zi[q];
+          zr[q] = __builtin_fmaf(a, w.x, -c * w.y);
+          zi[q] = __builtin_fmaf(a, w.y, c * w.x);
+        });
+      } else if constexpr (i > 1) {
         // twiddle W_(Ls*R)^(k*q), k = (t + T*b) mod Ls, on input q of butterfly b (register b + B*q)
         static_for<0, B>([&](auto bc) {
           constexpr int b = decltype(bc)::value;
           static_for<1, R>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            constexpr int e = C::tw_offset(i) + b * (R - 1) + (q - 1);
+            constexpr int e = C::tw_offset(i) - TW1 + b * (R - 1) + (q - 1);
             constexpr int m = b + B * q;
             const float a = zr[m], c = zi[m];
             zr[m] = __builtin_fmaf(a, twr[e], -c * twi[e]);
@@ -193,33 +285,99 @@ __device__ __forceinline__ void spectro16_body(const SpectroParams &p, v2f32 *ld
           });
         });
       }
-      static_for<0, B>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        dit<R, B, b, 16>(zr, zi);          // output q' at register b + B*brev(q', R)
-      });
-      if constexpr (i < NPASS - 1) {
-        frame_sync<T>();                   // everyone has finished reading the previous exchange
-        // Padded index pad16(a) = a + a/16 is LINEAR in q and m here (q*Ls and T*m are
-        // multiples of 16, or q < 16 on top of a multiple of 16), so each exchange costs one
-        // base address per butterfly and the rest goes into the DS immediate offset.
+      if constexpr (ABL != 2) {
         static_for<0, B>([&](auto bc) {
           constexpr int b = decltype(bc)::value;
-          const int j = (int)t + T * b;
-          const int k = j & (Ls - 1);
-          v2f32 *wbase = xb + pad16((j - k) * R + k);
-          constexpr int WS = Ls >= 16 ? Ls + Ls / 16 : 1;
-          static_for<0, R>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            constexpr int src = b + B * brev(q, R);
-            wbase[q * WS] = v2f32{zr[src], zi[src]};
-          });
+          dit<R, B, b, 16>(zr, zi);          // output q' at register b + B*brev(q', R)
         });
-        frame_sync<T>();
-        {
-          const v2f32 *rbase = xb + pad16((int)t);
+      }
+      if constexpr (i < NPASS - 1 && ABL == 1) {
+        if constexpr (i == 0) {
+          if (has_next) {
+              prefetch_taps(npair);
+              if (npair == 0) prefetch_x(nfblk);
+            }
+        }
+      } else if constexpr (i < NPASS - 1) {
+        frame_sync<T>();                   // everyone has finished reading the previous exchange
+        // Exchange layouts (8-byte (re,im) entries), both linear in the compile-time index so
+        // every access is base + immediate, and both free of bank conflicts for the 16-lane
+        // ds_write_b64 groups (32 banks) and the 32-lane ds_read_b64 groups (64 banks):
+        //  * after pass 0: row q' (stride T+2), column = producing lane.  The consumer
+        //    j = 16u+k reads row k at columns u + (T/16)*m; (T+2) mod 32 = 2 spreads the 16
+        //    rows a wave touches over distinct bank pairs.
+        //  * after later passes: natural Stockham order a = (j-k)*R + k + q*Ls (Ls >= 16:
+        //    16 consecutive lanes write 16 consecutive entries), read back at t + T*m.
+        if constexpr (LAY == 0) {
+          // +1-per-16 padded index a + a/16: linear in q and m here (q*Ls and T*m are multiples
+          // of 16, or q < 16 on top of a multiple of 16).  Write groups are conflict free; a
+          // 32-lane read group spans 66 dwords, i.e. one 2-way conflict, but consecutive reads
+          // are 2176 B apart, which keeps them single ds_read_b64 (not the slower ds_read2_b64).
+          static_for<0, B>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            const int j = (int)t + T * b;
+            const int k = j & (Ls - 1);
+            const int a0 = (j - k) * R + k;
+            v2f32 *wbase = xb + a0 + (a0 >> 4);
+            constexpr int WS = Ls >= 16 ? Ls + Ls / 16 : 1;
+            static_for<0, R>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              constexpr int src = b + B * brev(q, R);
+              wbase[q * WS] = v2f32{zr[src], zi[src]};
+            });
+          });
+          if constexpr (i == 0) {
+            if (has_next) {
+              prefetch_taps(npair);
+              if (npair == 0) prefetch_x(nfblk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          frame_sync<T>();
+          const v2f32 *rbase = xb + t + (t >> 4);
           static_for<0, 16>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
             const v2f32 v = rbase[m * (T + T / 16)];
+            zr[m] = v.x;
+            zi[m] = v.y;
+          });
+        } else if constexpr (i == 0) {
+          v2f32 *wbase = xb + t;
+          static_for<0, 16>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            wbase[q * (T + 2)] = v2f32{zr[brev(q, 16)], zi[brev(q, 16)]};
+          });
+          // the prefetch registers are free now: start the next round's loads
+          if (has_next) {
+              prefetch_taps(npair);
+              if (npair == 0) prefetch_x(nfblk);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          frame_sync<T>();
+          const v2f32 *rbase = xb + (t & 15) * (T + 2) + (t >> 4);
+          static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const v2f32 v = rbase[m * (T / 16)];
+            zr[m] = v.x;
+            zi[m] = v.y;
+          });
+        } else {
+          static_for<0, B>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            const int j = (int)t + T * b;
+            const int k = j & (Ls - 1);
+            v2f32 *wbase = xb + (j - k) * R + k;
+            static_for<0, R>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              constexpr int src = b + B * brev(q, R);
+              wbase[q * Ls] = v2f32{zr[src], zi[src]};
+            });
+          });
+          frame_sync<T>();
+          const v2f32 *rbase = xb + t;
+          static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const v2f32 v = rbase[m * T];
             zr[m] = v.x;
             zi[m] = v.y;
           });
@@ -228,6 +386,8 @@ __device__ __forceinline__ void spectro16_body(const SpectroParams &p, v2f32 *ld
     });
 
     // After the last pass register rho = b + B*brev(q',R) holds bin t + T*(b + B*q').
+    const long long f = fblk + fl;
+    const bool live = f < p.nframes;
     if constexpr (GEN) {
       // halfcomplex spectrum of the (single, real) tapered frame in fft_radix2.c's layout:
       // data[k] = Re X_k (k<=N/2), data[N-k] = Im X_k (0<k<N/2).  Compat/debug output.
@@ -247,47 +407,35 @@ __device__ __forceinline__ void spectro16_body(const SpectroParams &p, v2f32 *ld
 #pragma unroll
     for (int r = 0; r < 16; r++)
       acc[r] = __builtin_fmaf(zr[r], zr[r], __builtin_fmaf(zi[r], zi[r], acc[r]));
-  }
 
-  // ---- mirror fold through LDS: psd[k] = acc[k] + acc[(N-k) mod N]
-  float *fold = reinterpret_cast<float *>(xb);
-  frame_sync<T>();
-  {
-    constexpr int R = C::radix(NPASS - 1), B = 16 / R;
-    static_for<0, 16>([&](auto rc) {
-      constexpr int rho = decltype(rc)::value;
-      constexpr int b = rho % B, qp = brev(rho / B, R);
-      fold[(int)t + T * (b + B * qp)] = acc[rho];
-    });
-  }
-  frame_sync<T>();
-  if (live) {
-    float *o = p.psd + (size_t)f * (N / 2 + 1);
+    if (npair == 0) {
+      // ---- last pair of this frame: mirror fold through LDS, psd[k] = acc[k] + acc[(N-k) mod N]
+      float *fold = reinterpret_cast<float *>(xb);
+      frame_sync<T>();
+      {
+        constexpr int R = C::radix(NPASS - 1), B = 16 / R;
+        static_for<0, 16>([&](auto rc) {
+          constexpr int rho = decltype(rc)::value;
+          constexpr int b = rho % B, qp = brev(rho / B, R);
+          fold[(int)t + T * (b + B * qp)] = acc[rho];
+          acc[rho] = 0.0f;
+        });
+      }
+      frame_sync<T>();
+      if (live) {
+        float *o = p.psd + (size_t)f * (N / 2 + 1);
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const int k = T * m + (int)t;
-      o[k] = fold[k] + fold[(N - k) & (N - 1)];
+        for (int m = 0; m < 8; m++) {
+          const int k = T * m + (int)t;
+          o[k] = fold[k] + fold[(N - k) & (N - 1)];
+        }
+        if (t == 0) o[N / 2] = 2.0f * fold[N / 2];
+      }
     }
-    if (t == 0) o[N / 2] = 2.0f * fold[N / 2];
+    if (!has_next) break;
+    fblk = nfblk;
+    pair = npair;
   }
-}
-
-template <int LOGN>
-struct Launch16 {
-  static constexpr int T = Plan16<LOGN>::T;
-  static constexpr int FPB = T >= 256 ? 1 : 256 / T;
-  static constexpr int BLOCK = T * FPB;
-  static constexpr int LDS_WORDS = FPB * (Plan16<LOGN>::N + Plan16<LOGN>::N / 16);
-};
-
-template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD>
-__global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(SpectroParams p) {
-  __shared__ v2f32 lds[Launch16<LOGN>::LDS_WORDS];
-  // Blocks whose first frame starts at or after sample 0 and keep their history (all but the
-  // first few) need no per-element bounds predicate: wave-uniform choice of body.
-  const long long sblk = (p.frame0 + (long long)blockIdx.x * Launch16<LOGN>::FPB) * (long long)p.H - p.R;
-  if (sblk >= 0 && p.history_mode == 0) spectro16_body<LOGN, FMT, GEN, true>(p, lds);
-  else spectro16_body<LOGN, FMT, GEN, false>(p, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -331,8 +479,11 @@ template <int FMT>
 static hipError_t launch16_fmt(const SpectroParams &p, hipStream_t st) {
   constexpr int L = GLFER_LOGN;
   using LC = Launch16<L>;
-  const unsigned grid = (unsigned)((p.nframes + LC::FPB - 1) / LC::FPB);
-  if (grid == 0) return hipSuccess;
+  // persistent blocks: enough to fill every CU at the kernel's occupancy, never more than the work
+  const long long work = ((long long)p.nframes + LC::FPB - 1) / LC::FPB;
+  if (work == 0) return hipSuccess;
+  const long long resident = 256LL * ((GLFER16_WAVES_PER_SIMD * 256) / LC::BLOCK > 0 ? (GLFER16_WAVES_PER_SIMD * 256) / LC::BLOCK : 1);
+  const unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
   if (p.nonlin || p.spec)
     hipLaunchKernelGGL((spectro16_kernel<L, FMT, true>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   else

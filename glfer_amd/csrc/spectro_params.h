@@ -20,7 +20,7 @@ struct SpectroParams {
   float a;                 /* fft.c:127-136                                                  */
   float post_scale;        /* nonlin path: sqrt(1/(2N)) applied after the limiter            */
   float spec_unscale;      /* factor folded into taper 0 (undone for the spectrum output)    */
-  const float *taps;       /* device: [2*npairs][N] tapers/window, weights and 1/(2N) folded */
+  const float *taps;       /* device: [npairs][N][2] taper pairs interleaved, weights and 1/(2N) folded */
   const float2 *tw;        /* device: [slots][N/16] per-lane inter-pass twiddles (cos,sin)    */
   float *psd;              /* device: [nframes][N/2+1]                                       */
   float *spec;             /* device, optional: [nframes][N] halfcomplex spectrum            */

@@ -10,11 +10,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #define GLFER_NO_LAUNCHERS
 #include "spectro2.hip"
 #include "spectro16.hip"
+#include "spectro16_v3_snapshot.hip"
 #include "host_tables.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -162,25 +164,62 @@ int main(int argc, char **argv) {
   CK(hipMalloc((void **)&d_tw16, tw16.size() * 4));
   CK(hipMalloc((void **)&d_psd3, (size_t)nframes * P * 4));
   CK(hipMemcpy(d_tw16, tw16.data(), tw16.size() * 4, hipMemcpyHostToDevice));
+  std::vector<float> taps_il((size_t)2 * NP * N, 0.0f);
+  for (int j = 0; j < T; j++)
+    for (int i = 0; i < N; i++) taps_il[((size_t)(j / 2) * N + i) * 2 + (j & 1)] = taps[(size_t)j * N + i];
+  float *d_taps_il;
+  CK(hipMalloc((void **)&d_taps_il, taps_il.size() * 4));
+  CK(hipMemcpy(d_taps_il, taps_il.data(), taps_il.size() * 4, hipMemcpyHostToDevice));
   SpectroParams sq = sp;
   sq.tw = d_tw16;
   sq.psd = d_psd3;
-  for (int variant = 2; variant <= 4; variant++) {
+  for (int variant = 2; variant <= 3; variant++) {
+    float best = 1e9f;
     for (int rep = 0; rep < 4; rep++) {
       CK(hipEventRecord(e0));
-      if (variant == 2) hipLaunchKernelGGL((glfer::spectro16_kernel<12, GLFER_FMT_F32, false, 2>), dim3(nframes), dim3(256), 0, 0, sq);
-      else if (variant == 3) hipLaunchKernelGGL((glfer::spectro16_kernel<12, GLFER_FMT_F32, false, 3>), dim3(nframes), dim3(256), 0, 0, sq);
-      else hipLaunchKernelGGL((glfer::spectro16_kernel<12, GLFER_FMT_F32, false, 4>), dim3(nframes), dim3(256), 0, 0, sq);
+      if (variant == 2) hipLaunchKernelGGL((glfer_v3::spectro16_kernel<12, GLFER_FMT_F32, false, 2>), dim3(nframes), dim3(256), 0, 0, sq);
+      else hipLaunchKernelGGL((glfer_v3::spectro16_kernel<12, GLFER_FMT_F32, false, 3>), dim3(nframes), dim3(256), 0, 0, sq);
+      (void)0;
       CK(hipGetLastError());
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms;
       CK(hipEventElapsedTime(&ms, e0, e1));
-      const double fps = nframes / (ms * 1e-3);
-      printf("spectro16<12> WPS=%d rep %d: %.3f ms  %.2f Mframes/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)\n", variant, rep,
-             ms, fps / 1e6, fps * (4.0 * H + 4.0 * P) / 1e9, fps * (4.0 * H + 4.0 * P) / 8e12 * 100);
+      if (rep > 0) best = std::min(best, ms);
     }
+    printf("v3-snapshot<12> WPS=%d grid=%6d: %.3f ms  %.2f Mframes/s\n", variant, nframes, best, nframes / (best * 1e-3) / 1e6);
   }
+  // v4 (persistent, prefetch): WPS sweep at the persistent grid, then timing ablations at WPS=3
+  sq.taps = d_taps_il;      // from here on: the current kernel, interleaved taper pairs
+  auto time16 = [&](const char *label, auto launch) {
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; rep++) {
+      CK(hipEventRecord(e0));
+      launch();
+      CK(hipGetLastError());
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep > 0) best = std::min(best, ms);
+    }
+    const double fps = nframes / (best * 1e-3);
+    printf("spectro16<12> %-28s: %.3f ms  %.2f Mframes/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)\n", label, best, fps / 1e6,
+           fps * (4.0 * H + 4.0 * P) / 1e9, fps * (4.0 * H + 4.0 * P) / 8e12 * 100);
+  };
+  const unsigned gp = (unsigned)std::min(nframes, 256 * 12);
+#define K16(WPS, ABL, LAY, STG) glfer::spectro16_kernel<12, GLFER_FMT_F32, false, WPS, ABL, LAY, STG>
+  time16("WPS=2 lay0 grid=2048", [&] { hipLaunchKernelGGL((K16(2, 0, 0, 0)), dim3(2048), dim3(256), 0, 0, sq); });
+  time16("WPS=3 lay0 grid=3072", [&] { hipLaunchKernelGGL((K16(3, 0, 0, 0)), dim3(gp), dim3(256), 0, 0, sq); });
+  time16("WPS=3 lay1 grid=3072", [&] { hipLaunchKernelGGL((K16(3, 0, 1, 0)), dim3(gp), dim3(256), 0, 0, sq); });
+  time16("WPS=3 lay0 stagger 8", [&] { hipLaunchKernelGGL((K16(3, 0, 0, 8)), dim3(gp), dim3(256), 0, 0, sq); });
+  time16("WPS=3 lay0 stagger 24", [&] { hipLaunchKernelGGL((K16(3, 0, 0, 24)), dim3(gp), dim3(256), 0, 0, sq); });
+  time16("WPS=2 lay0 stagger 16", [&] { hipLaunchKernelGGL((K16(2, 0, 0, 16)), dim3(2048), dim3(256), 0, 0, sq); });
+  time16("WPS=4 lay0 grid=4096", [&] { hipLaunchKernelGGL((K16(4, 0, 0, 0)), dim3(4096), dim3(256), 0, 0, sq); });
+  time16("WPS=3 lay0 ABL1 no LDS", [&] { hipLaunchKernelGGL((K16(3, 1, 0, 0)), dim3(gp), dim3(256), 0, 0, sq); });
+  time16("WPS=3 lay0 ABL2 no bfly", [&] { hipLaunchKernelGGL((K16(3, 2, 0, 0)), dim3(gp), dim3(256), 0, 0, sq); });
+  time16("WPS=3 lay0 ABL3 no gather", [&] { hipLaunchKernelGGL((K16(3, 3, 0, 0)), dim3(gp), dim3(256), 0, 0, sq); });
+  time16("WPS=3 lay0 grid=3072 again", [&] { hipLaunchKernelGGL((K16(3, 0, 0, 0)), dim3(gp), dim3(256), 0, 0, sq); });
   {
     std::vector<float> a((size_t)64 * P), b((size_t)64 * P);
     CK(hipMemcpy(a.data(), d_psd2, a.size() * 4, hipMemcpyDeviceToHost));

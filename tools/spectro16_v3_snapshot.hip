@@ -1,0 +1,369 @@
+// SNAPSHOT of spectro16.hip at commit d86c8bc (kernel v3, non-persistent), kept only for A/B timing in kbench.
+// spectro16.hip -- fused frame -> taper(s) -> FFT -> |X|^2 -> taper-sum kernel (gfx950), v3.
+//
+// Replaces, per audio frame, the reference chain
+//   prepare_audio (fft.c:66-165) -> fft_real_radix2_transform (fft_radix2.c:75-177)
+//   -> fft_psd (fft.c:203-226) [-> the taper loop of mtm_do, mtm.c:189-220]
+// with ONE kernel that reads the overlapped sample stream and writes N/2+1 PSD bins.
+//
+// Layout: N/16 lanes per frame, 16 complex points per lane (two real tapered copies of the
+// frame packed as re/im of one complex N-point transform).  Stockham autosort passes of
+// radix 16 (last pass radix N/256 or N/4096), each pass a straight-line in-register DFT,
+// with the frame exchanged through LDS between passes as 8-byte (re,im) words in a
+// +1-per-16 padded layout that is bank-conflict free for both the scattered write and the
+// strided read.  All inter-pass twiddles of a lane are fixed for the whole launch and live
+// in registers (N <= 4096: at most 30 complex).  ~100 VGPRs => 4 waves/SIMD, which is what
+// the FP32 VALU needs to issue at rate on this chip (measured: 1 wave/SIMD issues a v_fma
+// every 8 clocks, 2 waves 78 %, 4 waves 83 %, 8 waves 87 % of 32 lanes/clk).
+//
+// Because taper weights and 1/N are folded into the tapers,
+//   sum_j w_j |Y_j[k]|^2 = sum_pairs (|Z_k|^2 + |Z_{N-k}|^2)/2,
+// so acc[k] += |Z_k|^2 per pair and one mirror-add through LDS per FRAME finishes the PSD.
+// No MFMA: there is no dense contraction on this path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fft_inreg.hpp"
+#include "spectro_params.h"
+
+#ifndef GLFER16_WAVES_PER_SIMD
+#define GLFER16_WAVES_PER_SIMD 4
+#endif
+
+namespace glfer_v3 {
+using glfer::static_for;
+using glfer::dit;
+using glfer::brev;
+
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+
+// Radix schedule for N = 2^LOGN with 16 points per lane.
+template <int LOGN>
+struct Plan16 {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int T = N / 16;                                   // lanes per frame
+  static constexpr int NPASS = LOGN <= 8 ? 2 : (LOGN <= 12 ? 3 : 4);
+  static constexpr int radix(int i) {
+    if (i < 2) return 16;
+    if (NPASS == 3) return N / 256;
+    return i == 2 ? 16 : N / 4096;
+  }
+  static constexpr int ls(int i) {                                    // product of earlier radices
+    int l = 1;
+    for (int j = 0; j < i; j++) l *= radix(j);
+    return l;
+  }
+  static constexpr int tw_offset(int i) {                             // first twiddle slot of pass i
+    int o = 0;
+    for (int j = 1; j < i; j++) o += (16 / radix(j)) * (radix(j) - 1);
+    return o;
+  }
+  static constexpr int NTW = tw_offset(NPASS);                        // twiddles per lane
+};
+
+__device__ __forceinline__ int pad16(int a) { return a + (a >> 4); }
+
+// sample formats: wav_fmt.c:104-117
+template <int FMT>
+__device__ __forceinline__ float cvt_sample(const void *ubase, unsigned elem_off) {
+  if constexpr (FMT == GLFER_FMT_F32) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + (size_t)(elem_off * 4u));
+  } else if constexpr (FMT == GLFER_FMT_S16) {
+    return (float)*reinterpret_cast<const short *>(reinterpret_cast<const char *>(ubase) + (size_t)(elem_off * 2u)) / 32768.0f;
+  } else {
+    return ((float)*(reinterpret_cast<const unsigned char *>(ubase) + (size_t)elem_off) - 128.0f) / 128.0f;
+  }
+}
+
+// Range-checked buffer load of one sample (raw buffer: out-of-range offsets read 0): one shared
+// VGPR byte offset + an SGPR/immediate offset, so gathering a frame costs no address VALU.
+template <int FMT>
+__device__ __forceinline__ float buf_sample(__amdgpu_buffer_rsrc_t rsrc, unsigned voff_bytes, unsigned soff_bytes) {
+  if constexpr (FMT == GLFER_FMT_F32) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, soff_bytes, 0));
+  } else if constexpr (FMT == GLFER_FMT_S16) {
+    return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff_bytes, soff_bytes, 0) / 32768.0f;
+  } else {
+    return ((float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsrc, voff_bytes, soff_bytes, 0) - 128.0f) / 128.0f;
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void frame_sync() {
+  if constexpr (T > 64) {
+    __syncthreads();
+  } else {                       // the frame lives in one wave: LDS ops of a wave are in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int LOGN, int FMT, bool GEN, bool FAST>
+__device__ __forceinline__ void spectro16_body(const SpectroParams &p, v2f32 *lds) {
+  using C = Plan16<LOGN>;
+  constexpr int N = C::N, T = C::T, NPASS = C::NPASS, NTW = C::NTW;
+  constexpr int FPB = T >= 256 ? 1 : 256 / T;
+  constexpr int PADN = N + N / 16;
+
+  const unsigned tid = threadIdx.x;
+  const unsigned t = tid % T;
+  const unsigned fl = tid / T;
+  const long long fblk = (long long)blockIdx.x * FPB;
+  const long long f = fblk + fl;
+  const bool live = f < p.nframes;
+  const unsigned flc = live ? fl : (unsigned)(p.nframes - 1 - fblk);   // clamp: loads stay in range
+  v2f32 *xb = lds + fl * PADN;
+
+  // Stream index of frame-relative sample j is sblk + flc*H + j with sblk wave-uniform.  The
+  // descriptor starts at sample max(sblk,0); samples before the stream (first frames only)
+  // get a negative offset, i.e. a huge unsigned one, and read 0 by the range check --
+  // the zero history of fft.c:103-108 without a branch.
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
+  const long long sbase = sblk > 0 ? sblk : 0;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sbase * (long long)esz, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.taps), 0, p.npairs * 2 * N * 4, 0x00020000);
+  const int lrel = (int)(sblk - sbase) + (int)(flc * (unsigned)p.H + t);   // lane's first sample, relative to sbase
+  const unsigned toff = t * 4u;
+
+  // ---- this lane's inter-pass twiddles, fixed for the launch
+  float twr[NTW], twi[NTW];
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.tw);
+#pragma unroll
+    for (int e = 0; e < NTW; e++) {
+      const v2f32 w = tw[e * T + t];
+      twr[e] = w.x;
+      twi[e] = w.y;
+    }
+  }
+
+  float acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+
+  for (int pair = 0; pair < p.npairs; pair++) {
+    float zr[16], zi[16];
+    const unsigned tap_a = (unsigned)(2 * pair) * (N * 4u);      // byte offset of taper 2*pair (uniform)
+    // ---- gather: lane t takes samples j = t + T*m (coalesced across the frame's lanes)
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      float x;
+      if constexpr (FAST) {
+        x = buf_sample<FMT>(xrsrc, (unsigned)lrel * esz, (unsigned)(T * m) * esz);
+      } else {
+        // first frames of the stream, or history zeroed in every frame (fft.c:103-108 with
+        // glfer.first_buffer stuck): a per-element offset, forced out of range where zero is due
+        const int j = T * m + (int)t;
+        const int rel = lrel + T * m;
+        const bool ok = p.history_mode ? (j >= p.R) : (rel >= 0);
+        x = buf_sample<FMT>(xrsrc, ok ? (unsigned)rel * esz : 0x80000000u, 0u);
+      }
+      const float wa = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(trsrc, toff, tap_a + (unsigned)(T * m) * 4u, 0));
+      if (GEN && p.nonlin) {
+        // fft.c:127-156: RA9MB x/(a+x^2), window, then sign(y)*|y|^0.1; the unit-power
+        // scale is applied afterwards (post_scale) because the limiter is not linear.
+        if (p.a > 0.0f) x = x / (p.a + x * x);
+        float y = x * wa;
+        if (p.limiter) {
+          const float mag = __expf(0.1f * __logf(fabsf(y)));
+          y = (y > 0.0f) ? mag : -mag;
+        }
+        zr[m] = y * p.post_scale;
+        zi[m] = 0.0f;
+      } else {
+        const float wb = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(trsrc, toff, tap_a + (unsigned)(N + T * m) * 4u, 0));
+        zr[m] = x * wa;
+        zi[m] = x * wb;
+      }
+    });
+
+    // ---- Stockham passes
+    static_for<0, NPASS>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int R = C::radix(i), Ls = C::ls(i), B = 16 / R;
+      if constexpr (i > 0) {
+        // twiddle W_(Ls*R)^(k*q), k = (t + T*b) mod Ls, on input q of butterfly b (register b + B*q)
+        static_for<0, B>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          static_for<1, R>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int e = C::tw_offset(i) + b * (R - 1) + (q - 1);
+            constexpr int m = b + B * q;
+            const float a = zr[m], c = zi[m];
+            zr[m] = __builtin_fmaf(a, twr[e], -c * twi[e]);
+            zi[m] = __builtin_fmaf(a, twi[e], c * twr[e]);
+          });
+        });
+      }
+      static_for<0, B>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        dit<R, B, b, 16>(zr, zi);          // output q' at register b + B*brev(q', R)
+      });
+      if constexpr (i < NPASS - 1) {
+        frame_sync<T>();                   // everyone has finished reading the previous exchange
+        // Padded index pad16(a) = a + a/16 is LINEAR in q and m here (q*Ls and T*m are
+        // multiples of 16, or q < 16 on top of a multiple of 16), so each exchange costs one
+        // base address per butterfly and the rest goes into the DS immediate offset.
+        static_for<0, B>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          const int j = (int)t + T * b;
+          const int k = j & (Ls - 1);
+          v2f32 *wbase = xb + pad16((j - k) * R + k);
+          constexpr int WS = Ls >= 16 ? Ls + Ls / 16 : 1;
+          static_for<0, R>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int src = b + B * brev(q, R);
+            wbase[q * WS] = v2f32{zr[src], zi[src]};
+          });
+        });
+        frame_sync<T>();
+        {
+          const v2f32 *rbase = xb + pad16((int)t);
+          static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const v2f32 v = rbase[m * (T + T / 16)];
+            zr[m] = v.x;
+            zi[m] = v.y;
+          });
+        }
+      }
+    });
+
+    // After the last pass register rho = b + B*brev(q',R) holds bin t + T*(b + B*q').
+    if constexpr (GEN) {
+      // halfcomplex spectrum of the (single, real) tapered frame in fft_radix2.c's layout:
+      // data[k] = Re X_k (k<=N/2), data[N-k] = Im X_k (0<k<N/2).  Compat/debug output.
+      if (live && p.spec) {
+        float *o = p.spec + (size_t)f * N;
+        const float inv = 1.0f / p.spec_unscale;
+        constexpr int R = C::radix(NPASS - 1), B = 16 / R;
+        static_for<0, 16>([&](auto rc) {
+          constexpr int rho = decltype(rc)::value;
+          constexpr int b = rho % B, qp = brev(rho / B, R);
+          const int k = (int)t + T * (b + B * qp);
+          if (k <= N / 2) o[k] = zr[rho] * inv;
+          if (k > 0 && k < N / 2) o[N - k] = zi[rho] * inv;
+        });
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+      acc[r] = __builtin_fmaf(zr[r], zr[r], __builtin_fmaf(zi[r], zi[r], acc[r]));
+  }
+
+  // ---- mirror fold through LDS: psd[k] = acc[k] + acc[(N-k) mod N]
+  float *fold = reinterpret_cast<float *>(xb);
+  frame_sync<T>();
+  {
+    constexpr int R = C::radix(NPASS - 1), B = 16 / R;
+    static_for<0, 16>([&](auto rc) {
+      constexpr int rho = decltype(rc)::value;
+      constexpr int b = rho % B, qp = brev(rho / B, R);
+      fold[(int)t + T * (b + B * qp)] = acc[rho];
+    });
+  }
+  frame_sync<T>();
+  if (live) {
+    float *o = p.psd + (size_t)f * (N / 2 + 1);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int k = T * m + (int)t;
+      o[k] = fold[k] + fold[(N - k) & (N - 1)];
+    }
+    if (t == 0) o[N / 2] = 2.0f * fold[N / 2];
+  }
+}
+
+template <int LOGN>
+struct Launch16 {
+  static constexpr int T = Plan16<LOGN>::T;
+  static constexpr int FPB = T >= 256 ? 1 : 256 / T;
+  static constexpr int BLOCK = T * FPB;
+  static constexpr int LDS_WORDS = FPB * (Plan16<LOGN>::N + Plan16<LOGN>::N / 16);
+};
+
+template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD>
+__global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(SpectroParams p) {
+  __shared__ v2f32 lds[Launch16<LOGN>::LDS_WORDS];
+  // Blocks whose first frame starts at or after sample 0 and keep their history (all but the
+  // first few) need no per-element bounds predicate: wave-uniform choice of body.
+  const long long sblk = (p.frame0 + (long long)blockIdx.x * Launch16<LOGN>::FPB) * (long long)p.H - p.R;
+  if (sblk >= 0 && p.history_mode == 0) spectro16_body<LOGN, FMT, GEN, true>(p, lds);
+  else spectro16_body<LOGN, FMT, GEN, false>(p, lds);
+}
+
+// ---------------------------------------------------------------------------
+// K0: per-hop mean removal (fft.c:86-96).  One block per hop; writes a float copy of the
+// stream (the reference mutates the caller's hop buffer in place).
+template <int FMT>
+__global__ __launch_bounds__(256) void submean_kernel(const void *in, float *out, int H, long long nhops) {
+  __shared__ float part[256];
+  const long long hop = blockIdx.x;
+  if (hop >= nhops) return;
+  constexpr int esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  const char *src = reinterpret_cast<const char *>(in) + hop * (long long)H * esz;   // wave-uniform
+  float *dst = out + hop * (long long)H;
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < H; i += 256) s += cvt_sample<FMT>(src, (unsigned)i);
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  const float mean = part[0] / (float)H;
+  for (int i = threadIdx.x; i < H; i += 256) dst[i] = cvt_sample<FMT>(src, (unsigned)i) - mean;
+}
+
+}  // namespace glfer
+
+// ---------------------------------------------------------------------------
+// host-side launchers (called from glfer_hip.cpp).  One translation unit per LOGN
+// (-DGLFER_LOGN=...) so the size variants compile in parallel.
+#if 0
+
+
+#ifndef GLFER_LOGN
+#error "compile with -DGLFER_LOGN=<log2 of the block size>"
+#endif
+#define GLFER_CAT2(a, b) a##b
+#define GLFER_CAT(a, b) GLFER_CAT2(a, b)
+
+template <int FMT>
+static hipError_t launch16_fmt(const SpectroParams &p, hipStream_t st) {
+  constexpr int L = GLFER_LOGN;
+  using LC = Launch16<L>;
+  const unsigned grid = (unsigned)((p.nframes + LC::FPB - 1) / LC::FPB);
+  if (grid == 0) return hipSuccess;
+  if (p.nonlin || p.spec)
+    hipLaunchKernelGGL((spectro16_kernel<L, FMT, true>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+  else
+    hipLaunchKernelGGL((spectro16_kernel<L, FMT, false>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16_n, GLFER_LOGN)(const SpectroParams *p, hipStream_t st) {
+  switch (p->fmt) {
+    case GLFER_FMT_F32: return launch16_fmt<GLFER_FMT_F32>(*p, st);
+    case GLFER_FMT_S16: return launch16_fmt<GLFER_FMT_S16>(*p, st);
+    case GLFER_FMT_U8: return launch16_fmt<GLFER_FMT_U8>(*p, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+#if GLFER_LOGN == 12
+extern "C" hipError_t glfer_launch_submean(const void *in, float *out, int H, long long nhops, int fmt,
+                                           hipStream_t st) {
+  if (nhops <= 0) return hipSuccess;
+  switch (fmt) {
+    case GLFER_FMT_F32: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_F32>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
+    case GLFER_FMT_S16: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_S16>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
+    case GLFER_FMT_U8: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_U8>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+#endif
+#endif  // GLFER_NO_LAUNCHERS
