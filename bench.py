@@ -95,22 +95,17 @@ def main():
     sp = G.Spectrogram(params, device=local)
     hop, bins = sp.hop, sp.bins
     frames = args.frames
-    # this rank's shard of the global frame range [rank*frames, (rank+1)*frames): samples of
-    # its hops plus the N-H history halo on the left (zeros for rank 0, as fft.c:103-108)
-    halo = n - hop
-    shard = synth_on_device(torch, frames * hop + halo, dev, seed=rank)
-    if rank == 0 and halo:
-        shard[:halo] = 0.0
-    first = halo // hop if halo % hop == 0 else None
-    psd = torch.empty((frames, bins), dtype=torch.float32, device=dev)
+    # Weak scaling: the job is world*frames frames of one long stream; this rank owns the
+    # contiguous frame range frame_range() gives it and holds only the samples of its window
+    # (its hops + the N-H history halo on the left; the stream starts with zero history).
+    from glfer_amd.shard import frame_range, run_shard, sample_window
+    first, count = frame_range(frames * world, rank, world)
+    begin, end = sample_window(first, count, hop, n)
+    shard = synth_on_device(torch, end - begin, dev, seed=rank)
+    psd = torch.empty((count, bins), dtype=torch.float32, device=dev)
 
     def step():
-        if halo == 0:
-            sp.run(shard, 0, frames, out=psd)
-        elif first is not None:
-            sp.run(shard, first, frames, out=psd)     # frames whose history lies inside the halo
-        else:
-            sp.run(shard[halo % hop:], halo // hop + 1, frames - 1, out=psd)
+        run_shard(sp, shard, begin, first, count, out=psd)
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,6 +136,15 @@ def main():
         b_alg = 4 * hop + 4 * bins                      # compulsory read of H new samples + P bins out
         achieved = frames * b_alg / (kernel_ms * 1e-3) / 1e9
         ntap = sp.ntapers
+        # measured HBM bytes per frame of this kernel, from the committed rocprofv3 PMC passes
+        # (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is) -- see profiles/
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            if args.workload == "mtm":
+                traffic = prof["hbm_traffic_bytes_per_frame_corrected"] * frames
+        except Exception:
+            pass
         line = {
             "metric": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4" if args.workload == "mtm"
                       else "spectrogram frames/sec + achieved HBM GB/s, N=4096 periodogram",
@@ -150,7 +154,9 @@ def main():
             "config": {"workload": name, "frames_per_gpu_per_step": frames, "n": n, "hop": hop,
                        "tapers": ntap, "sharding": "frame ranges, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch, rocprofv3 PMC (profiles/r01_hbm_traffic.json)",
+                         "algorithmic_bytes_per_launch": frames * b_alg,
                          "kernel": "spectro16_kernel<12>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_frame": b_alg,
                          "note": "MTM is FP32-VALU-bound on this chip (SURVEY 7): see valu_frac"},

@@ -29,7 +29,8 @@ EXPORTS = [
     "glfer_hip_plan_create", "glfer_hip_plan_destroy", "glfer_hip_hop", "glfer_hip_bins",
     "glfer_hip_num_tapers", "glfer_hip_num_frames", "glfer_hip_get_window", "glfer_hip_get_tapers",
     "glfer_hip_make_window", "glfer_hip_make_dpss", "glfer_hip_spectrogram_device",
-    "glfer_hip_spectrum_device", "glfer_hip_spectrogram_host", "glfer_hip_floor_device",
+    "glfer_hip_spectrum_device", "glfer_hip_spectrogram_host", "glfer_hip_submean_device",
+    "glfer_hip_floor_device",
     "glfer_hip_avg_device", "glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version",
 ]
 
@@ -80,6 +81,7 @@ def lib():
     L.glfer_hip_spectrogram_device.argtypes = [vp, vp, sz, sz, sz, vp, vp]
     L.glfer_hip_spectrum_device.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp]
     L.glfer_hip_spectrogram_host.argtypes = [vp, vp, sz, vp, C.POINTER(sz)]
+    L.glfer_hip_submean_device.argtypes = [vp, vp, C.c_int, sz, C.c_int, vp]
     L.glfer_hip_floor_device.argtypes = [vp, sz, C.c_int, vp, vp]
     L.glfer_hip_avg_device.argtypes = [C.c_int, vp, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, vp, vp, vp]

@@ -303,6 +303,13 @@ int glfer_hip_spectrogram_host(glfer_hip_plan *p, const void *h_stream, size_t n
   return rc;
 }
 
+int glfer_hip_submean_device(const void *d_in, float *d_out, int hop, size_t nhops, int sample_format,
+                             void *hip_stream) {
+  if (!d_in || !d_out || hop < 1 || sample_format < 0 || sample_format > 2) return GLFER_E_ARG;
+  HIP_TRY(glfer_launch_submean(d_in, d_out, hop, (long long)nhops, sample_format, (hipStream_t)hip_stream));
+  return GLFER_OK;
+}
+
 int glfer_hip_floor_device(const float *d_psd, size_t nframes, int bins, float *d_stats, void *hip_stream) {
   if (!d_psd || !d_stats || bins < 1 || bins > 32769) return GLFER_E_ARG;
   const int m = bins - (int)(bins * 0.95);                       // fft.c:271: i = N2*0.95 .. N2-1

@@ -1,0 +1,44 @@
+"""Frame-range sharding of a spectrogram over the GPUs of one node.
+
+Frame f depends only on samples [f*H - (N-H), f*H + H) (fft.c:98-113), so the frame index
+range is cut into contiguous blocks, one per rank, each rank reading its hops plus a left halo
+of N-H samples (zeros for rank 0, as fft.c:103-108).  There is no exchange step: no collective
+on the data path, only the outputs' row ranges are disjoint.
+"""
+
+
+def frame_range(total_frames, rank, world):
+    """(first, count) of this rank's contiguous block; the remainder goes to the low ranks."""
+    base, rem = divmod(total_frames, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def sample_window(first, count, hop, n, history_mode=0):
+    """[begin, end) of the stream samples the frames [first, first+count) read.
+    history_mode 1 (history zeroed in every frame) needs no halo."""
+    if count == 0:
+        return 0, 0
+    halo = 0 if history_mode else n - hop
+    begin = max(0, first * hop - halo)
+    return begin, (first + count) * hop
+
+
+def run_shard(sp, local, begin, first, count, out=None):
+    """Frames [first, first+count) from `local`, a device tensor holding stream samples
+    [begin, begin+len(local)) as sample_window() prescribes.  The C-ABI addresses samples
+    relative to sample 0 of the stream, so it is handed the virtual base local - begin."""
+    import ctypes as C
+    import torch
+    from . import api
+    esz = local.element_size()
+    if out is None:
+        out = torch.empty((count, sp.bins), dtype=torch.float32, device=local.device)
+    if count == 0:
+        return out
+    st = C.c_void_p(torch.cuda.current_stream(local.device).cuda_stream)
+    api._check(api.lib().glfer_hip_spectrogram_device(
+        sp._h, C.c_void_p(local.data_ptr() - begin * esz), begin + local.numel(), first, count,
+        out.data_ptr(), st), "glfer_hip_spectrogram_device")
+    return out

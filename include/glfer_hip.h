@@ -132,6 +132,13 @@ int glfer_hip_spectrum_device(glfer_hip_plan *plan, const void *d_stream, size_t
 int glfer_hip_spectrogram_host(glfer_hip_plan *plan, const void *h_stream, size_t nsamples,
                                float *h_psd, size_t *nframes_out);
 
+/* K0 on its own: per-hop mean removal (fft.c:86-96).  d_out[i] = sample(d_in[i]) - mean of the
+ * hop i belongs to; nhops hops of `hop` samples each.  (The spectrogram entries apply it
+ * themselves when cfg.sub_mean is set; this entry serves the per-hop shims, which must hand
+ * the corrected hop back to the caller as the reference does.) */
+int glfer_hip_submean_device(const void *d_in, float *d_out, int hop, size_t nhops, int sample_format,
+                             void *hip_stream);
+
 /* compute_floor (fft.c:240-294) for a batch of PSD rows on the device.
  * d_stats: [nframes][4] floats = {sig (max bin), floor, peak value, peak bin as float}. */
 int glfer_hip_floor_device(const float *d_psd, size_t nframes, int bins, float *d_stats,

@@ -1,0 +1,143 @@
+"""GPU tests of libglfer_compat.so: glfer's own entry points (fft.h:77-83, mtm.h:47-49,
+avg.h:38-43), driven hop by hop the way source.c:130-158 and g_main.c:1109-1183 drive them,
+checked against the CPU oracle run over the same stream."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from _signals import rel_err, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-5
+
+
+class FftParams(C.Structure):       # fft.h:52-63
+    _fields_ = [("inbuf_audio", C.POINTER(C.c_float)), ("inbuf_fft", C.POINTER(C.c_float)),
+                ("outbuf", C.POINTER(C.c_float)), ("n", C.c_int), ("window", C.POINTER(C.c_float)),
+                ("window_type", C.c_int), ("overlap", C.c_float), ("a", C.c_float), ("limiter", C.c_int),
+                ("sub_mean", C.c_int)]
+
+
+class MtmParams(C.Structure):       # mtm.h:36-44
+    _fields_ = [("fft", FftParams), ("window", C.POINTER(C.POINTER(C.c_double))), ("sig", C.POINTER(C.c_double)),
+                ("w", C.c_float), ("kmax", C.c_int)]
+
+
+class AvgData(C.Structure):         # avg.h:28-36
+    _fields_ = [("avgwidth", C.c_int), ("avgdepth", C.c_int), ("effdepth", C.c_int), ("avg", C.POINTER(C.c_double)),
+                ("cum", C.POINTER(C.c_double)), ("avgarray", C.POINTER(C.POINTER(C.c_double)))]
+
+
+@pytest.fixture(scope="module")
+def compat(lib):
+    import torch
+    assert torch.cuda.is_available()
+    L = C.CDLL(os.path.join(ROOT, "glfer_amd", "lib", "libglfer_compat.so"))
+    L.update_avg_plain.restype = C.c_double
+    L.update_avg_sumextreme.restype = C.c_double
+    L.update_avg_sumavg.restype = C.c_double
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _set(compat, name, value):
+    C.c_int.in_dll(compat, name).value = value
+
+
+@pytest.mark.parametrize("autoscale", [1, 0])
+def test_fft_do_hop_by_hop(compat, oracle, autoscale):
+    n, ovl, win = 1024, 0.5, 0          # Hanning
+    h = oracle.hop(n, ovl)
+    x = synth(12 * h, fs=8000.0, seed=3) + np.float32(0.05)
+    _set(compat, "glfer_compat_autoscale", autoscale)        # opt.autoscale -> sub_mean (fft.c:186)
+    _set(compat, "glfer_compat_first_buffer", 1)             # g_main.c:990
+    p = FftParams(n=n, window_type=win, overlap=ovl, a=0.0, limiter=0)
+    compat.fft_init(C.byref(p))
+    assert p.sub_mean == autoscale
+    assert np.array_equal(np.ctypeslib.as_array(p.window, (n,)), oracle.window(win, n))
+    psd = np.empty(n // 2 + 1, np.float32)
+    got = []
+    for f in range(12):
+        hop = x[f * h:(f + 1) * h].copy()
+        compat.fft_do(_fp(hop), C.byref(p))
+        compat.fft_psd(_fp(psd), None, C.byref(p))
+        got.append(psd.copy())
+        if autoscale:                                        # the drawer clears it only then (g_main.c:1111-1120)
+            _set(compat, "glfer_compat_first_buffer", 0)
+    want = oracle.spectrogram_fft(x, n, ovl, win, sub_mean=autoscale, history_mode=0 if autoscale else 1)
+    worst = max(max(rel_err(g, w)) for g, w in zip(got, want))
+    assert worst < TOL, worst
+    # what fft_do leaves in outbuf: the halfcomplex spectrum of the last windowed frame
+    hc = np.ctypeslib.as_array(p.outbuf, (n,)).copy()
+    chk = np.empty(n // 2 + 1, np.float32)
+    chk[0] = hc[0] ** 2 / n
+    chk[1:n // 2] = (hc[1:n // 2] ** 2 + hc[n - 1:n // 2:-1] ** 2) / n
+    chk[n // 2] = hc[n // 2] ** 2 / n
+    assert max(rel_err(chk, want[-1])) < TOL
+    compat.fft_close(C.byref(p))
+    assert not p.window and not p.inbuf_audio
+
+
+def test_mtm_do_hop_by_hop(compat, oracle):
+    n, ovl, nw, kmax = 4096, 0.75, 2.5, 4
+    h = oracle.hop(n, ovl)
+    x = synth(9 * h, seed=8)
+    _set(compat, "glfer_compat_autoscale", 0)
+    _set(compat, "glfer_compat_first_buffer", 1)
+    p = MtmParams()
+    p.fft.n, p.fft.window_type, p.fft.overlap, p.fft.a, p.fft.limiter = n, 5, ovl, 0.0, 0   # source.c:343-347
+    p.w, p.kmax = nw, kmax
+    compat.mtm_init(C.byref(p))
+    v, sig = oracle.dpss(n, kmax, nw)
+    assert np.array_equal(np.array([p.sig[k] for k in range(kmax + 1)]), sig)
+    assert all(p.window[i + 1][j] == v[j, i] for i in (0, 1, 2047, 4095) for j in range(kmax + 1))   # [1..n][0..kmax]
+    psd = np.empty(n // 2 + 1, np.float32)
+    got = []
+    for f in range(9):
+        hop = x[f * h:(f + 1) * h].copy()
+        compat.mtm_do(_fp(hop), _fp(psd), None, C.byref(p))
+        got.append(psd.copy())
+        _set(compat, "glfer_compat_first_buffer", 0)
+    want = oracle.spectrogram_mtm(x, n, ovl, nw, kmax)
+    assert max(max(rel_err(g, w)) for g, w in zip(got, want)) < TOL
+    compat.mtm_close(C.byref(p))
+
+
+def test_compute_floor_and_update_avg(compat, oracle):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "avg_floor_fft1024.npz"))
+    psd = g["psd"]
+    s, fl, pk, pb = C.c_float(), C.c_float(), C.c_float(), C.c_uint()
+    for f in range(psd.shape[0]):
+        row = psd[f].copy()
+        compat.compute_floor(_fp(row), 513, C.byref(s), C.byref(fl), C.byref(pk), C.byref(pb))
+        w = g["floor"][f]
+        assert s.value == w[0] and pk.value == w[2] and pb.value == w[3]
+        assert abs(fl.value / w[1] - 1) < 2e-6
+    depth, lo, hi = int(g["depth"]), int(g["minbin"]), int(g["maxbin"])
+    for mode, fn in (("plain", compat.update_avg_plain), ("sumextreme", compat.update_avg_sumextreme),
+                     ("sumavg", compat.update_avg_sumavg)):
+        a = AvgData()
+        compat.init_avg(C.byref(a))
+        compat.alloc_avg(C.byref(a), 1024, depth)             # width = data_block_size (source.c:312)
+        peak, var = C.c_int(-1), C.c_double(0)
+        for f in range(psd.shape[0]):
+            row = psd[f].copy()
+            if mode == "plain":
+                r = fn(C.byref(a), 513, _fp(row), lo, hi, C.byref(peak))
+            elif mode == "sumextreme":
+                r = fn(C.byref(a), 513, _fp(row), 1, lo, hi, C.byref(peak))
+            else:
+                r = fn(C.byref(a), 513, _fp(row), 1, lo, hi, C.byref(peak), C.byref(var))
+            want_avg = g["%s_max%d_avg" % (mode, 0 if mode == "plain" else 1)][f]
+            want_ret = g["%s_max%d_ret" % (mode, 0 if mode == "plain" else 1)][f]
+            got_avg = np.ctypeslib.as_array(a.avg, (513,))
+            assert np.allclose(got_avg, want_avg, rtol=1e-11, atol=0)
+            assert abs(r / want_ret[0] - 1) < 1e-11 and peak.value == want_ret[1]
+            assert a.effdepth == min(f + 1, depth)
+        compat.delete_avg(C.byref(a))

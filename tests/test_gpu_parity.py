@@ -216,3 +216,24 @@ def test_moving_average(lib, torch_cuda, mode_name, mode_id, max0):
     assert np.array_equal(ret[:, 1], want_ret[:, 1])
     if mode_name == "sumavg":
         assert np.allclose(ret[:, 2], want_ret[:, 2], rtol=1e-12)
+
+
+def test_shards_reproduce_the_full_run(lib, torch_cuda):
+    """glfer_amd.shard: frame ranges computed from each rank's own sample window (hops + left
+    halo, addressed through a virtual base pointer) give exactly the rows of the full run."""
+    from glfer_amd.shard import frame_range, run_shard, sample_window
+    torch = torch_cuda
+    for params, frames in ((lib.FftParams(n=4096, window_type=0, overlap=0.75), 50),
+                           (lib.MtmParams(n=4096, overlap=0.0, w=2.5, kmax=4), 13),
+                           (lib.FftParams(n=1024, window_type=7, overlap=0.9), 333)):
+        sp = lib.Spectrogram(params)
+        x = torch.from_numpy(synth(frames * sp.hop, seed=21)).cuda()
+        full = sp.run(x)
+        for world in (2, 3, 8):
+            parts = []
+            for rank in range(world):
+                first, count = frame_range(frames, rank, world)
+                begin, end = sample_window(first, count, sp.hop, sp.n)
+                local = x[begin:end].clone()             # a rank holds only its window
+                parts.append(run_shard(sp, local, begin, first, count))
+            assert torch.equal(torch.cat(parts), full)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof/ tree (rocprofv3 --kernel-trace --stats and --pmc passes over
+bench.py) into the small summaries kept under profiles/.   usage: summarize_prof.py <round-tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof = os.path.join(root, "gpurun_out", "prof")
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+
+
+def one(pattern):
+    return sorted(glob.glob(os.path.join(prof, pattern)))[-1]
+
+
+rows = list(csv.DictReader(open(one("stats/*/*_kernel_stats.csv"))))
+with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for r in rows:
+        w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
+                    r["MaxNs"], r["StdDev"]])
+k = [r for r in rows if "spectro16" in r["Name"]][0]
+
+
+def pmc(path, name):
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+         if "spectro16" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return sum(v) / len(v)
+
+
+fetch = pmc(one("fetch/*/*_counter_collection.csv"), "FETCH_SIZE")
+write = pmc(one("write/*/*_counter_collection.csv"), "WRITE_SIZE")
+sq = collections.defaultdict(list)
+for r in csv.DictReader(open(one("sq/*/*_counter_collection.csv"))):
+    if "spectro16" in r["Kernel_Name"]:
+        sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
+sq = {n: sum(v) / len(v) for n, v in sq.items()}
+frames, hop, bins = 262144, 4096, 2049
+alg = frames * (4 * hop + 4 * bins)
+# MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports exactly half
+# the bytes of a coalesced streaming read -> doubled here; WRITE_SIZE reads the bytes exactly.
+traffic = (2 * fetch + write) * 1024
+summary = {
+    "command": "rocprofv3 --kernel-trace {--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*} "
+               "-- python3 bench.py --steps K --warmup 1 --no-cpu-baseline   (separate passes)",
+    "workload": "C3 MTM N=4096 NW=2.5 mtm_k=4 overlap 0, %d frames per launch" % frames,
+    "kernel": k["Name"], "kernel_avg_ns_profiled": float(k["AverageNs"]), "kernel_calls": int(k["Calls"]),
+    "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
+    "hbm_traffic_bytes_per_launch_corrected": traffic,
+    "hbm_traffic_bytes_per_frame_corrected": traffic / frames,
+    "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_frame": alg / frames,
+    "traffic_over_algorithmic": traffic / alg,
+    "sq_counters_per_launch": sq, "frames_per_launch": frames,
+}
+json.dump(summary, open(os.path.join(out, tag + "_hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
