@@ -249,7 +249,8 @@ void alloc_avg(avg_data_t *a, int width, int depth) {              // avg.c:38-6
   a->cum = (double *)calloc(width, sizeof(double));
   a->avgarray = nullptr;        // the shift registers live on the device
   AvgDev d;
-  hipck(hipMalloc((void **)&d.d_rows, (size_t)(depth + 1) * width * sizeof(float)), "hipMalloc avg rows");
+  hipck(hipMalloc((void **)&d.d_rows, (size_t)2 * (depth + 1) * width * sizeof(float)), "hipMalloc avg rows");
+  hipck(hipMemset(d.d_rows, 0, (size_t)2 * (depth + 1) * width * sizeof(float)), "hipMemset avg rows");
   hipck(hipMalloc((void **)&d.d_avg, (size_t)(depth + 1) * width * sizeof(double)), "hipMalloc avg out");
   hipck(hipMalloc((void **)&d.d_ret, (size_t)(depth + 1) * 4 * sizeof(double)), "hipMalloc avg ret");
   g_avg[a] = d;
@@ -273,20 +274,27 @@ static double avg_step(int mode, avg_data_t *a, int N, float *psd, int max0, int
   if (it == g_avg.end()) { fprintf(stderr, "glfer_compat: update_avg before alloc_avg\n"); exit(-1); }
   AvgDev &d = it->second;
   const int depth = a->avgdepth, width = a->avgwidth;
-  // keep the last depth+1 rows (row width = avgwidth floats, N of them used)
-  if (d.rows == depth + 1) {
-    hipck(hipMemcpy(d.d_rows, d.d_rows + width, (size_t)depth * width * sizeof(float), hipMemcpyDeviceToDevice), "shift rows");
+  // Keep the last depth+1 rows contiguous and in time order (row width = avgwidth floats, N
+  // of them used).  The buffer holds 2*(depth+1) rows; when it is full the newest `depth`
+  // rows move to the front (source and destination do not overlap).
+  const int cap = 2 * (depth + 1);
+  if (d.rows == cap) {
+    hipck(hipMemcpy(d.d_rows, d.d_rows + (size_t)(cap - depth) * width, (size_t)depth * width * sizeof(float),
+                    hipMemcpyDeviceToDevice), "slide rows");
     d.rows = depth;
   }
   hipck(hipMemcpy(d.d_rows + (size_t)d.rows * width, psd, (size_t)N * sizeof(float), hipMemcpyHostToDevice), "H2D psd");
   d.rows++;
-  // the sliding sum over the last `depth` rows is what a run from an empty state over these
-  // depth+1 rows leaves in its last row (avg.c:116-127)
-  int rc = glfer_hip_avg_device(mode, d.d_rows, (size_t)d.rows, width, width, depth, minbin, maxbin, max0, d.d_avg, d.d_ret, nullptr);
+  // the sliding sum over the last `depth` rows is what a run from an empty state over the
+  // last depth+1 rows leaves in its last row (avg.c:116-127)
+  const int first = d.rows > depth + 1 ? d.rows - (depth + 1) : 0;
+  const int nrows = d.rows - first;
+  int rc = glfer_hip_avg_device(mode, d.d_rows + (size_t)first * width, (size_t)nrows, width, width, depth, minbin, maxbin,
+                                max0, d.d_avg, d.d_ret, nullptr);
   if (rc) die("update_avg", rc);
   double ret[4];
-  hipck(hipMemcpy(a->avg, d.d_avg + (size_t)(d.rows - 1) * width, (size_t)N * sizeof(double), hipMemcpyDeviceToHost), "D2H avg");
-  hipck(hipMemcpy(ret, d.d_ret + (size_t)(d.rows - 1) * 4, sizeof ret, hipMemcpyDeviceToHost), "D2H ret");
+  hipck(hipMemcpy(a->avg, d.d_avg + (size_t)(nrows - 1) * width, (size_t)N * sizeof(double), hipMemcpyDeviceToHost), "D2H avg");
+  hipck(hipMemcpy(ret, d.d_ret + (size_t)(nrows - 1) * 4, sizeof ret, hipMemcpyDeviceToHost), "D2H ret");
   if (a->effdepth < depth) a->effdepth++;                          // avg.c:138-139
   if (ret[1] >= 0) *peakbin = (int)ret[1];                         // left untouched when nothing exceeds psd[minbin]
   if (variance) *variance = ret[2];

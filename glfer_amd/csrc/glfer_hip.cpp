@@ -46,7 +46,7 @@ struct glfer_hip_plan {
   std::vector<float> window;        // [n] as the reference stores it (unit power)
   std::vector<double> tapers;       // [ntapers][n]
   std::vector<double> sig;          // [ntapers]
-  float *d_taps = nullptr;          // [npairs][n][2] scaled tables, taper pair interleaved
+  float *d_taps = nullptr;          // [npairs][8][n/16][4] scaled tables (tap_slot)
   float2 *d_tw = nullptr;           // [64][lanes]
   float *d_scratch = nullptr;       // sub_mean copy of the hops of one call
   size_t scratch_floats = 0;
@@ -55,6 +55,15 @@ struct glfer_hip_plan {
 };
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// Device layout of the taper tables, the order the kernel's lanes read them in: sample i of a
+// frame belongs to lane t = i mod T at register m = i / T (T = n/16 lanes per frame); a lane
+// fetches registers m, m+1 of both tapers of a pair with one 16-byte load:
+//   taps[pair][m/2][t][4] = { taper 2p @m, taper 2p+1 @m, taper 2p @m+1, taper 2p+1 @m+1 }
+static size_t tap_slot(int n, int pair, int i, int which) {
+  const int T = n / 16, t = i % T, m = i / T;
+  return (size_t)pair * n * 2 + ((size_t)(m / 2) * T + t) * 4 + (size_t)(m & 1) * 2 + which;
+}
 
 extern "C" {
 
@@ -111,7 +120,7 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     const bool rect = (cfg->window_type == GLFER_WIN_RECTANGULAR);
     for (int i = 0; i < n; i++) {
       const double w = rect ? 1.0 : (double)p->window[i];          // fft.c:132,139: no multiply when rectangular
-      taps[2 * (size_t)i] = p->nonlin ? (float)w : (float)(w * scale);
+      taps[tap_slot(n, 0, i, 0)] = p->nonlin ? (float)w : (float)(w * scale);
     }
   } else {
     p->ntapers = cfg->mtm_k + 1;                                   // mtm.c:189: j = 0..kmax inclusive
@@ -127,7 +136,7 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
       // psd += |FFT(v_j x)|^2 / N / (1+sig_j)   (mtm.c:212-219), and the 1/2 of the packing
       const double scale = std::sqrt(1.0 / (2.0 * n * (1.0 + p->sig[j])));
       for (int i = 0; i < n; i++)
-        taps[((size_t)(j / 2) * n + i) * 2 + (j & 1)] = (float)(p->tapers[(size_t)j * n + i] * scale);
+        taps[tap_slot(n, j / 2, i, j & 1)] = (float)(p->tapers[(size_t)j * n + i] * scale);
     }
     p->spec_unscale = 1.0f;
   }

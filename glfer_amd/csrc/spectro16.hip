@@ -154,7 +154,7 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
 
   const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(p.taps), 0, p.npairs * 2 * N * 4, 0x00020000);
-  const unsigned toff = t * 8u;
+  const unsigned toff = t * 16u;
   const long long stride = (long long)gridDim.x * FPB;
 
   // ---- registers filled ahead of use: the frame's samples (once per frame) and the NEXT
@@ -203,10 +203,15 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
       for (int m = 0; m < 16; m++) pt[m] = v2f32{0.25f, 0.125f * (float)pair};
       return;
     }
+    // table layout [pair][m/2][lane][4] = (taper 2p, taper 2p+1) at samples t+T*m and t+T*(m+1):
+    // one 16-byte load per lane brings two complex points' worth of tapers (8 loads per round)
     const unsigned tap_p = (unsigned)pair * (N * 8u);              // byte offset of this pair's table (uniform)
-    static_for<0, 16>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      pt[m] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(trsrc, toff, tap_p + (unsigned)(T * m) * 8u, 0));
+    static_for<0, 8>([&](auto mc) {
+      constexpr int mh = decltype(mc)::value;
+      typedef float v4f32 __attribute__((ext_vector_type(4)));
+      const v4f32 q = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(trsrc, toff, tap_p + (unsigned)(T * mh) * 16u, 0));
+      pt[2 * mh] = v2f32{q.x, q.y};
+      pt[2 * mh + 1] = v2f32{q.z, q.w};
     });
   };
 

@@ -166,7 +166,10 @@ int main(int argc, char **argv) {
   CK(hipMemcpy(d_tw16, tw16.data(), tw16.size() * 4, hipMemcpyHostToDevice));
   std::vector<float> taps_il((size_t)2 * NP * N, 0.0f);
   for (int j = 0; j < T; j++)
-    for (int i = 0; i < N; i++) taps_il[((size_t)(j / 2) * N + i) * 2 + (j & 1)] = taps[(size_t)j * N + i];
+    for (int i = 0; i < N; i++) {
+      const int TT = N / 16, tt = i % TT, mm = i / TT;
+      taps_il[(size_t)(j / 2) * N * 2 + ((size_t)(mm / 2) * TT + tt) * 4 + (size_t)(mm & 1) * 2 + (j & 1)] = taps[(size_t)j * N + i];
+    }
   float *d_taps_il;
   CK(hipMalloc((void **)&d_taps_il, taps_il.size() * 4));
   CK(hipMemcpy(d_taps_il, taps_il.data(), taps_il.size() * 4, hipMemcpyHostToDevice));
