@@ -29,7 +29,8 @@ EXPORTS = [
     "glfer_hip_plan_create", "glfer_hip_plan_destroy", "glfer_hip_hop", "glfer_hip_bins",
     "glfer_hip_num_tapers", "glfer_hip_num_frames", "glfer_hip_get_window", "glfer_hip_get_tapers",
     "glfer_hip_make_window", "glfer_hip_make_dpss", "glfer_hip_spectrogram_device",
-    "glfer_hip_spectrum_device", "glfer_hip_spectrogram_host", "glfer_hip_submean_device",
+    "glfer_hip_spectrum_device", "glfer_hip_spectrogram_host", "glfer_hip_wav_probe",
+    "glfer_hip_spectrogram_wav", "glfer_hip_submean_device",
     "glfer_hip_floor_device",
     "glfer_hip_avg_device", "glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version",
 ]
@@ -45,6 +46,12 @@ class Config(C.Structure):
                 ("window_type", C.c_int), ("limiter_a", C.c_float), ("enable_limiter", C.c_int),
                 ("sub_mean", C.c_int), ("history_mode", C.c_int), ("mtm_w", C.c_float),
                 ("mtm_k", C.c_int), ("sample_format", C.c_int), ("device", C.c_int)]
+
+
+class WavInfo(C.Structure):
+    """glfer_wav_info (include/glfer_hip.h): the header fields of wav_fmt.h:34-52 that are used."""
+    _fields_ = [("format", C.c_int), ("channels", C.c_int), ("sample_rate", C.c_int),
+                ("bits_per_sample", C.c_int), ("data_offset", C.c_size_t), ("nsamples", C.c_size_t)]
 
 
 _lib = None
@@ -81,6 +88,8 @@ def lib():
     L.glfer_hip_spectrogram_device.argtypes = [vp, vp, sz, sz, sz, vp, vp]
     L.glfer_hip_spectrum_device.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp]
     L.glfer_hip_spectrogram_host.argtypes = [vp, vp, sz, vp, C.POINTER(sz)]
+    L.glfer_hip_wav_probe.argtypes = [C.c_char_p, C.POINTER(WavInfo)]
+    L.glfer_hip_spectrogram_wav.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz), sz]
     L.glfer_hip_submean_device.argtypes = [vp, vp, C.c_int, sz, C.c_int, vp]
     L.glfer_hip_floor_device.argtypes = [vp, sz, C.c_int, vp, vp]
     L.glfer_hip_avg_device.argtypes = [C.c_int, vp, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -216,6 +225,18 @@ class Spectrogram:
                "glfer_hip_spectrogram_device")
         return out
 
+    def run_wav(self, path, chunk_frames=0, max_frames=None):
+        """Whole WAV file -> numpy psd [frames][bins], streamed through pinned buffers."""
+        info = wav_probe(path)
+        frames = info.nsamples // self.hop
+        if max_frames is not None:
+            frames = min(frames, max_frames)
+        out = np.empty((frames, self.bins), np.float32)
+        nf = C.c_size_t(0)
+        _check(lib().glfer_hip_spectrogram_wav(self._h, os.fsencode(path), out.ctypes.data, frames,
+                                               C.byref(nf), chunk_frames), "glfer_hip_spectrogram_wav")
+        return out[:nf.value]
+
     def run_host(self, samples):
         """samples: numpy array on the host; returns numpy psd [frames][bins]."""
         want = {SAMPLES_F32: np.float32, SAMPLES_S16: np.int16, SAMPLES_U8: np.uint8}[
@@ -229,6 +250,13 @@ class Spectrogram:
                "glfer_hip_spectrogram_host")
         assert nf.value == frames
         return out
+
+
+def wav_probe(path):
+    """open_wav_file()'s header parse (wav_fmt.c:45-80) with fixed-width fields."""
+    info = WavInfo()
+    _check(lib().glfer_hip_wav_probe(os.fsencode(path), C.byref(info)), "glfer_hip_wav_probe")
+    return info
 
 
 def compute_floor(psd):

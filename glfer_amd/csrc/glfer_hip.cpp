@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -306,6 +307,111 @@ int glfer_hip_spectrogram_host(glfer_hip_plan *p, const void *h_stream, size_t n
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: copy back");
   }
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}
+
+// ---- ingest (wav_fmt.c:45-121, source.c:118-128) ------------------------------------------
+static unsigned rd_u16(const unsigned char *b) { return b[0] | (b[1] << 8); }
+static unsigned rd_u32(const unsigned char *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24); }
+
+int glfer_hip_wav_probe(const char *path, glfer_wav_info *info) {
+  if (!path || !info) return GLFER_E_ARG;
+  FILE *f = fopen(path, "rb");
+  if (!f) return GLFER_E_ARG;                                    // wav_fmt.c:53-56 exits; we report
+  unsigned char hd[44];
+  const size_t got = fread(hd, 1, sizeof hd, f);
+  long end = 0;
+  if (fseek(f, 0, SEEK_END) == 0) end = ftell(f);
+  fclose(f);
+  if (got < sizeof hd) return GLFER_E_ARG;                       // "input file less than 20 bytes long", wav_fmt.c:61-62
+  if (memcmp(hd, "RIFF", 4) != 0) return GLFER_E_ARG;            // "input file not in WAV format", wav_fmt.c:63-64
+  info->format = (int)rd_u16(hd + 20);                           // wav_fmt.h:42
+  info->channels = (int)rd_u16(hd + 22);                         // wav_fmt.h:43
+  info->sample_rate = (int)rd_u32(hd + 24);                      // wav_fmt.h:44  -> *speed, wav_fmt.c:70
+  info->bits_per_sample = (int)rd_u16(hd + 34);                  // wav_fmt.h:47  -> bits, wav_fmt.c:71
+  info->data_offset = 44;
+  if (info->format != 1) return GLFER_E_ARG;                     // "input is not a PCM WAV file", wav_fmt.c:68-69
+  if (info->bits_per_sample != 8 && info->bits_per_sample != 16) return GLFER_E_ARG;   // wav_fmt.c:87-96 handles only these
+  const size_t avail = end > 44 ? (size_t)(end - 44) : 0;
+  info->nsamples = avail / (size_t)(info->bits_per_sample / 8);  // the reference reads until read() returns 0
+  return GLFER_OK;
+}
+
+int glfer_hip_spectrogram_wav(glfer_hip_plan *p, const char *path, float *h_psd, size_t max_frames,
+                              size_t *nframes_out, size_t chunk_frames) {
+  if (!p || !path || !nframes_out) return GLFER_E_ARG;
+  glfer_wav_info wi;
+  int rc = glfer_hip_wav_probe(path, &wi);
+  if (rc) return rc;
+  const int fmt = wi.bits_per_sample == 8 ? GLFER_SAMPLES_U8 : GLFER_SAMPLES_S16;
+  if (p->cfg.sample_format != fmt) return GLFER_E_ARG;
+  const size_t esz = (size_t)wi.bits_per_sample / 8, hop = (size_t)p->hop, bins = (size_t)p->bins;
+  size_t frames = wi.nsamples / hop;                             // whole blocks only, wav_fmt.c:119
+  if (frames > max_frames) frames = max_frames;
+  *nframes_out = frames;
+  if (frames == 0) return GLFER_OK;
+  if (!h_psd) return GLFER_E_ARG;
+  // history kept on the device between chunks: whole hops covering the N-H overlap
+  const size_t halo = (size_t)((p->keep + p->hop - 1) / p->hop) * hop;
+  if (chunk_frames == 0) chunk_frames = 16384;
+  if (chunk_frames < 2 * (halo / hop)) chunk_frames = 2 * (halo / hop);     // halo copy must not overlap itself
+  if (chunk_frames < 1) chunk_frames = 1;
+  if (chunk_frames > frames) chunk_frames = frames;
+  FILE *f = fopen(path, "rb");
+  if (!f) return GLFER_E_ARG;
+  if (fseek(f, (long)wi.data_offset, SEEK_SET) != 0) { fclose(f); return GLFER_E_ARG; }
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  unsigned char *h_in[2] = {nullptr, nullptr};
+  float *h_out = nullptr, *d_out = nullptr;
+  unsigned char *d_in = nullptr;
+  hipStream_t st = nullptr;
+  hipEvent_t up_done[2] = {nullptr, nullptr};
+  const size_t chunk_bytes = chunk_frames * hop * esz;
+  hipError_t e = hipStreamCreate(&st);
+  for (int b = 0; b < 2 && e == hipSuccess; b++) {
+    e = hipHostMalloc((void **)&h_in[b], chunk_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreate(&up_done[b]);
+  }
+  if (e == hipSuccess) e = hipHostMalloc((void **)&h_out, chunk_frames * bins * sizeof(float), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_in, (halo + chunk_frames * hop) * esz);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_out, chunk_frames * bins * sizeof(float));
+  rc = (e == hipSuccess) ? GLFER_OK : hip_fail(e, "spectrogram_wav: allocate");
+  size_t done = 0, nread = 0;
+  int cur = 0;
+  if (rc == GLFER_OK) nread = fread(h_in[0], 1, std::min(chunk_frames, frames) * hop * esz, f) / (hop * esz);
+  while (rc == GLFER_OK && done < frames && nread > 0) {
+    const size_t nf = nread;
+    // chunk samples land behind the halo; sample 0 of the file sits at d_in + halo - done*hop
+    e = hipMemcpyAsync(d_in + halo * esz, h_in[cur], nf * hop * esz, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(up_done[cur], st);
+    if (e != hipSuccess) { rc = hip_fail(e, "spectrogram_wav: upload"); break; }
+    const unsigned char *vbase = d_in + halo * esz - done * hop * esz;   // virtual address of file sample 0
+    rc = run_device(p, vbase, (done + nf) * hop, done, nf, d_out, nullptr, st);
+    if (rc) break;
+    e = hipMemcpyAsync(h_out, d_out, nf * bins * sizeof(float), hipMemcpyDeviceToHost, st);
+    // keep the last `halo` samples of this chunk in front of the next one (only a full chunk is
+    // ever followed by another, and a full chunk is at least one halo long)
+    if (e == hipSuccess && halo && done + nf < frames)
+      e = hipMemcpyAsync(d_in, d_in + nf * hop * esz, halo * esz, hipMemcpyDeviceToDevice, st);
+    // read the next block from the file while the GPU works
+    const size_t want = std::min(chunk_frames, frames - done - nf);
+    nread = want ? fread(h_in[cur ^ 1], 1, want * hop * esz, f) / (hop * esz) : 0;
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { rc = hip_fail(e, "spectrogram_wav: chunk"); break; }
+    memcpy(h_psd + done * bins, h_out, nf * bins * sizeof(float));
+    done += nf;
+    cur ^= 1;
+  }
+  *nframes_out = done;
+  fclose(f);
+  for (int b = 0; b < 2; b++) {
+    if (h_in[b]) (void)hipHostFree(h_in[b]);
+    if (up_done[b]) (void)hipEventDestroy(up_done[b]);
+  }
+  if (h_out) (void)hipHostFree(h_out);
   if (d_in) (void)hipFree(d_in);
   if (d_out) (void)hipFree(d_out);
   if (st) (void)hipStreamDestroy(st);

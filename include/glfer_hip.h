@@ -132,6 +132,30 @@ int glfer_hip_spectrum_device(glfer_hip_plan *plan, const void *d_stream, size_t
 int glfer_hip_spectrogram_host(glfer_hip_plan *plan, const void *h_stream, size_t nsamples,
                                float *h_psd, size_t *nframes_out);
 
+/* ---- ingest: the file source of source.c:118-128 / wav_fmt.c:45-121 ------------------------
+ * The canonical 44-byte RIFF/WAVE header of wav_fmt.h:34-52, read with fixed-width fields
+ * (the reference's struct uses u_long and mis-parses every file on LP64 hosts).  As in the
+ * reference only PCM (format 1) with 8 or 16 bits per sample is accepted and the channel
+ * count is not interpreted: interleaved channels are treated as one sample stream. */
+typedef struct glfer_wav_info {
+  int format;            /* 1 = PCM                                  wav_fmt.h:42 */
+  int channels;          /* "modus": 1 mono, 2 stereo                wav_fmt.h:43 */
+  int sample_rate;       /* sample_fq                                wav_fmt.h:44 */
+  int bits_per_sample;   /* bit_p_spl: 8 or 16                       wav_fmt.h:47 */
+  size_t data_offset;    /* 44                                                     */
+  size_t nsamples;       /* samples present after the header                      */
+} glfer_wav_info;
+int glfer_hip_wav_probe(const char *path, glfer_wav_info *info);
+
+/* Whole-file spectrogram: reads `path` hop block by hop block through two pinned host
+ * buffers (the next block is read from the file while the GPU works on the current one),
+ * uploads the raw PCM with hipMemcpyAsync -- the conversion of wav_fmt.c:104-117 happens in
+ * the kernel's gather -- and writes frame rows to h_psd ([max_frames][N/2+1], host).
+ * plan->sample_format must match the file (8 bit: GLFER_SAMPLES_U8, 16 bit: _S16).
+ * chunk_frames = frames per upload (0 = default 16384). */
+int glfer_hip_spectrogram_wav(glfer_hip_plan *plan, const char *path, float *h_psd, size_t max_frames,
+                              size_t *nframes_out, size_t chunk_frames);
+
 /* K0 on its own: per-hop mean removal (fft.c:86-96).  d_out[i] = sample(d_in[i]) - mean of the
  * hop i belongs to; nhops hops of `hop` samples each.  (The spectrogram entries apply it
  * themselves when cfg.sub_mean is set; this entry serves the per-hop shims, which must hand

@@ -237,3 +237,47 @@ def test_shards_reproduce_the_full_run(lib, torch_cuda):
                 local = x[begin:end].clone()             # a rank holds only its window
                 parts.append(run_shard(sp, local, begin, first, count))
             assert torch.equal(torch.cat(parts), full)
+
+
+def _write_wav(path, samples, rate):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(samples.dtype.itemsize)
+        w.setframerate(rate)
+        w.writeframes(samples.tobytes())
+
+
+@pytest.mark.parametrize("bits", [16, 8])
+def test_wav_file_ingest(lib, oracle, torch_cuda, tmp_path, bits):
+    """source.c:118-128 + wav_fmt.c:45-121: header parse, PCM conversion in the gather, streamed
+    in several chunks with the N-H history carried on the device between them."""
+    x = synth(1024 * 61 + 300, fs=8000.0, seed=6)
+    raw = np.round(x * 32767).astype(np.int16) if bits == 16 else np.clip(np.round(x * 127 + 128), 0, 255).astype(np.uint8)
+    path = tmp_path / ("t%d.wav" % bits)
+    _write_wav(path, raw, 8000)
+    info = lib.wav_probe(str(path))
+    assert (info.format, info.channels, info.sample_rate, info.bits_per_sample, info.nsamples) == (1, 1, 8000, bits, raw.size)
+    conv = oracle.pcm_s16_to_float if bits == 16 else oracle.pcm_u8_to_float
+    fmt = lib.SAMPLES_S16 if bits == 16 else lib.SAMPLES_U8
+    for params, want in (
+            (lib.FftParams(n=1024, window_type=0, overlap=0.75, sample_format=fmt, sub_mean=1),
+             oracle.spectrogram_fft(conv(raw), 1024, 0.75, 0, sub_mean=1)),
+            (lib.MtmParams(n=1024, overlap=0.5, w=2.5, kmax=4, sample_format=fmt),
+             oracle.spectrogram_mtm(conv(raw), 1024, 0.5, 2.5, 4)),
+            (lib.FftParams(n=4096, window_type=7, overlap=0.0, sample_format=fmt),
+             oracle.spectrogram_fft(conv(raw), 4096, 0.0, 7))):
+        sp = lib.Spectrogram(params)
+        for chunk in (0, 7, 64):
+            got = sp.run_wav(str(path), chunk_frames=chunk)
+            assert got.shape == want.shape
+            assert max(max(rel_err(got[f], want[f])) for f in range(want.shape[0])) < TOL
+    # errors: wrong sample format for the file, not a WAV file, missing file
+    with pytest.raises(lib.GlferHipError, match="bad argument"):
+        lib.Spectrogram(lib.FftParams(n=1024, sample_format=lib.SAMPLES_F32)).run_wav(str(path))
+    junk = tmp_path / "junk.wav"
+    junk.write_bytes(b"not a wav file at all, but longer than forty-four bytes....")
+    with pytest.raises(lib.GlferHipError, match="bad argument"):
+        lib.wav_probe(str(junk))
+    with pytest.raises(lib.GlferHipError, match="bad argument"):
+        lib.wav_probe(str(tmp_path / "missing.wav"))

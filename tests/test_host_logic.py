@@ -73,3 +73,35 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("the oracle", "").replace("not the oracle", ""), os.path.join(dirpath, f)
+
+
+def test_wav_header_parse_fixed_width(lib, tmp_path):
+    """open_wav_file (wav_fmt.c:45-80) restated with fixed-width fields: host code, no GPU."""
+    import struct
+    import wave
+    p = tmp_path / "a.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(48000)
+        w.writeframes(np.arange(1000, dtype=np.int16).tobytes())
+    info = lib.wav_probe(str(p))
+    assert (info.format, info.channels, info.sample_rate, info.bits_per_sample) == (1, 2, 48000, 16)
+    assert info.data_offset == 44 and info.nsamples == 1000     # channels are not interpreted (wav_fmt.c ignores modus)
+    # the same 44 bytes, field by field as wav_fmt.h:34-52 lays them out
+    hd = open(p, "rb").read(44)
+    riff, _, wavetag, fmt_, sc_len, fmt, modus, fq, bps, bpspl, bits, data, dlen = struct.unpack("<4sI4s4sIHHIIHH4sI", hd)
+    assert (riff, wavetag, fmt_, data) == (b"RIFF", b"WAVE", b"fmt ", b"data") and sc_len == 16
+    assert (fmt, modus, fq, bits, dlen) == (1, 2, 48000, 16, 2000)
+    # rejected: float WAV (format 3), 24-bit PCM
+    bad = bytearray(hd)
+    bad[20:22] = struct.pack("<H", 3)
+    q = tmp_path / "float.wav"
+    q.write_bytes(bytes(bad) + b"\0" * 64)
+    with pytest.raises(lib.GlferHipError, match="bad argument"):
+        lib.wav_probe(str(q))
+    bad = bytearray(hd)
+    bad[34:36] = struct.pack("<H", 24)
+    q.write_bytes(bytes(bad) + b"\0" * 64)
+    with pytest.raises(lib.GlferHipError, match="bad argument"):
+        lib.wav_probe(str(q))
