@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libglfer_hip.so")
 
-MODE_FFT, MODE_MTM = 0, 1
+MODE_FFT, MODE_MTM, MODE_HPARMA = 0, 1, 2
 WINDOWS = {"hanning": 0, "blackman": 1, "gaussian": 2, "welch": 3,
            "bartlett": 4, "rectangular": 5, "hamming": 6, "kaiser": 7}
 SAMPLES_F32, SAMPLES_S16, SAMPLES_U8 = 0, 1, 2
@@ -45,7 +45,8 @@ class Config(C.Structure):
     _fields_ = [("mode", C.c_int), ("n", C.c_int), ("overlap", C.c_float),
                 ("window_type", C.c_int), ("limiter_a", C.c_float), ("enable_limiter", C.c_int),
                 ("sub_mean", C.c_int), ("history_mode", C.c_int), ("mtm_w", C.c_float),
-                ("mtm_k", C.c_int), ("sample_format", C.c_int), ("device", C.c_int)]
+                ("mtm_k", C.c_int), ("sample_format", C.c_int), ("device", C.c_int),
+                ("hparma_t", C.c_int), ("hparma_p_e", C.c_int)]
 
 
 class WavInfo(C.Structure):
@@ -151,6 +152,19 @@ class MtmParams:
         self.history_mode, self.sample_format = history_mode, sample_format
 
 
+class HparmaParams:
+    """What source.c:368-376 sets before hparma_init(): fft.{n,overlap}, t, p_e (q_e = -1)."""
+
+    def __init__(self, n=4096, overlap=0.0, t=96, p_e=16, sub_mean=0, history_mode=HISTORY_ZERO_FIRST,
+                 sample_format=SAMPLES_F32):
+        self.mode = MODE_HPARMA
+        self.n, self.overlap, self.t, self.p_e = n, overlap, t, p_e
+        self.window_type = WINDOWS["rectangular"]       # source.c:369
+        self.a, self.limiter, self.sub_mean = 0.0, 0, sub_mean
+        self.history_mode, self.sample_format = history_mode, sample_format
+        self.w, self.kmax = 0.0, 0
+
+
 _TORCH_DTYPES = None
 
 
@@ -165,7 +179,7 @@ class Spectrogram:
     def __init__(self, params, device=0):
         cfg = Config(params.mode, params.n, params.overlap, params.window_type, params.a,
                      params.limiter, params.sub_mean, params.history_mode, params.w, params.kmax,
-                     params.sample_format, device)
+                     params.sample_format, device, getattr(params, "t", 0), getattr(params, "p_e", 0))
         self._h = C.c_void_p()
         _check(lib().glfer_hip_plan_create(C.byref(cfg), C.byref(self._h)), "glfer_hip_plan_create")
         self.params, self.device = params, device

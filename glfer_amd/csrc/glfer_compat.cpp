@@ -229,6 +229,41 @@ void mtm_close(mtm_params_t *p) {                                  // mtm.c:242-
   free(p->sig); p->sig = nullptr;
 }
 
+// ---- hparma.h ---------------------------------------------------------------------------
+void hparma_init(hparma_params_t *p) {                             // hparma.c:45-71
+  const int n = p->fft.n;
+  p->fft.inbuf_audio = (float *)calloc(n, sizeof(float));
+  p->fft.inbuf_fft = (float *)calloc(n, sizeof(float));
+  p->fft.outbuf = p->fft.inbuf_fft;
+  p->fft.sub_mean = glfer_compat_get_autoscale();                  // hparma.c:62
+  if (p->q_e != -1) { fprintf(stderr, "glfer_compat: hparma q_e = %d unsupported (source.c:375 sets -1)\n", p->q_e); exit(-1); }
+  glfer_hip_config cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.mode = GLFER_MODE_HPARMA;
+  cfg.n = n;
+  cfg.overlap = 0.0f;
+  cfg.hparma_t = p->t;
+  cfg.hparma_p_e = p->p_e;
+  engine_open(p, cfg, false);
+}
+
+void hparma_do(float *audio_buf, float *psd_buf, float *phase_buf, hparma_params_t *p) {   // hparma.c:74-157
+  (void)phase_buf;
+  Engine &e = engine_for(p);
+  assemble(audio_buf, &p->fft);
+  hipck(hipMemcpy(e.d_frame, p->fft.inbuf_audio, (size_t)p->fft.n * sizeof(float), hipMemcpyHostToDevice), "H2D frame");
+  int rc = glfer_hip_spectrogram_device(e.plan, e.d_frame, (size_t)p->fft.n, 0, 1, e.d_psd, nullptr);
+  if (rc) die("hparma_do", rc);
+  hipck(hipMemcpy(psd_buf, e.d_psd, e.psd.size() * sizeof(float), hipMemcpyDeviceToHost), "D2H psd");
+}
+
+void hparma_close(hparma_params_t *p) {                            // hparma.c:160-179
+  engine_close(p);
+  free(p->fft.inbuf_audio); p->fft.inbuf_audio = nullptr;
+  free(p->fft.inbuf_fft); p->fft.inbuf_fft = nullptr;
+  p->fft.outbuf = nullptr;
+}
+
 // ---- avg.h ------------------------------------------------------------------------------
 namespace {
 struct AvgDev {

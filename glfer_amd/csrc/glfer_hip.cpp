@@ -9,9 +9,11 @@
 #include "../../include/glfer_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -21,6 +23,8 @@
 #include "host_tables.h"
 #include "spectro_params.h"
 
+extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const uint16_t *lagmap,
+                                          const float2 *unit, hipStream_t st);
 extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int bins, int m, float *stats,
                                          hipStream_t st);
 extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframes, int bins, int n_out,
@@ -49,6 +53,8 @@ struct glfer_hip_plan {
   std::vector<double> sig;          // [ntapers]
   float *d_taps = nullptr;          // [npairs][8][n/16][4] scaled tables (tap_slot)
   float2 *d_tw = nullptr;           // [64][lanes]
+  uint16_t *d_lagmap = nullptr;     // HP-ARMA: [t][p_e+1] lag held by each matrix cell
+  float2 *d_unit = nullptr;         // HP-ARMA: [n/2+1] exp(-2 pi i k/n)
   float *d_scratch = nullptr;       // sub_mean copy of the hops of one call
   size_t scratch_floats = 0;
   float spec_unscale = 1.0f;
@@ -89,7 +95,13 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   const int n = cfg->n;
   if (!is_pow2(n) || n < 256 || n > 16384) return GLFER_E_ARG;
   if (!(cfg->overlap >= 0.0f) || !(cfg->overlap < 1.0f)) return GLFER_E_ARG;   // g_options.c:1030
-  if (cfg->mode != GLFER_MODE_FFT && cfg->mode != GLFER_MODE_MTM) return GLFER_E_ARG;
+  if (cfg->mode != GLFER_MODE_FFT && cfg->mode != GLFER_MODE_MTM && cfg->mode != GLFER_MODE_HPARMA) return GLFER_E_ARG;
+  if (cfg->mode == GLFER_MODE_HPARMA) {
+    const int t = cfg->hparma_t, ncol = cfg->hparma_p_e + 1;
+    if (t < 2 || ncol < 2 || ncol > t || t > n || ncol > 256 || t > 65535) return GLFER_E_ARG;   // p_e+1 <= t (hparma.c:107)
+    const size_t big = (size_t)n > (size_t)t * ncol ? (size_t)n : (size_t)t * ncol;
+    if ((big + (size_t)ncol * ncol + t + 2 * ncol) * sizeof(float) > 160 * 1024) return GLFER_E_ARG;
+  }
   if (cfg->sample_format < 0 || cfg->sample_format > 2) return GLFER_E_ARG;
   if (cfg->mode == GLFER_MODE_MTM && (cfg->mtm_k < 0 || cfg->mtm_k > 31 || !(cfg->mtm_w > 0.0f)))
     return GLFER_E_ARG;
@@ -123,6 +135,10 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
       const double w = rect ? 1.0 : (double)p->window[i];          // fft.c:132,139: no multiply when rectangular
       taps[tap_slot(n, 0, i, 0)] = p->nonlin ? (float)w : (float)(w * scale);
     }
+  } else if (cfg->mode == GLFER_MODE_HPARMA) {
+    p->ntapers = 0;
+    p->npairs = 0;
+    taps.assign(4, 0.0f);
   } else {
     p->ntapers = cfg->mtm_k + 1;                                   // mtm.c:189: j = 0..kmax inclusive
     p->npairs = (p->ntapers + 1) / 2;
@@ -147,12 +163,41 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   std::vector<float> tw((size_t)2 * glfer::make_twiddles16(logn, nullptr) * p->lanes);
   glfer::make_twiddles16(logn, tw.data());
 
+  // --- HP-ARMA tables: which lag each cell of the t x (p_e+1) matrix holds after the
+  // reference's fill (hparma.c:89-102).  r_xx is matrix(0,t,0,p_e) (hparma.c:64): its rows
+  // are contiguous (util.c:153-160), lags 0..t-1 are written into row 0 past its p_e+1
+  // columns, and the Toeplitz loop then copies cells that it may already have rewritten.
+  // Simulated here with lag labels instead of values.
+  std::vector<uint16_t> lagmap;
+  std::vector<float> unit;
+  if (cfg->mode == GLFER_MODE_HPARMA) {
+    const int t = cfg->hparma_t, ncol = cfg->hparma_p_e + 1;
+    std::vector<int> flat((size_t)(t + 1) * ncol, -1);
+    for (int i = 0; i < t; i++) flat[i] = i;                       // r_xx[0][i] = r(i)
+    for (int i = 1; i < t; i++)
+      for (int j = 0; j < ncol; j++) flat[(size_t)i * ncol + j] = flat[std::abs(j - i)];
+    lagmap.resize((size_t)t * ncol);
+    for (size_t i = 0; i < lagmap.size(); i++) lagmap[i] = (uint16_t)(flat[i] < 0 ? 0 : flat[i]);
+    unit.resize((size_t)2 * (n / 2 + 1));
+    for (int k = 0; k <= n / 2; k++) {
+      const double ang = -2.0 * 3.14159265358979323846 * k / n;
+      unit[2 * k] = (float)std::cos(ang);
+      unit[2 * k + 1] = (float)std::sin(ang);
+    }
+  }
+
   // --- device tables
   hipError_t e = hipSetDevice(cfg->device);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_taps, taps.size() * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_tw, tw.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(p->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !lagmap.empty()) {
+    e = hipMalloc((void **)&p->d_lagmap, lagmap.size() * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_unit, unit.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->d_lagmap, lagmap.data(), lagmap.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_unit, unit.data(), unit.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     int rc = hip_fail(e, "plan_create");
     glfer_hip_plan_destroy(p);
@@ -167,6 +212,8 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (p->d_taps) (void)hipFree(p->d_taps);
   if (p->d_tw) (void)hipFree(p->d_tw);
   if (p->d_scratch) (void)hipFree(p->d_scratch);
+  if (p->d_lagmap) (void)hipFree(p->d_lagmap);
+  if (p->d_unit) (void)hipFree(p->d_unit);
   delete p;
 }
 
@@ -267,7 +314,10 @@ static int run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, 
     sp.fmt = GLFER_FMT_F32;
     sp.frame0 = (long long)(first - hop_lo);
   }
-  HIP_TRY(launch_by_n(sp, p->n, st));
+  if (p->cfg.mode == GLFER_MODE_HPARMA)
+    HIP_TRY(glfer_launch_hparma(&sp, p->n, p->cfg.hparma_t, p->cfg.hparma_p_e + 1, p->d_lagmap, p->d_unit, st));
+  else
+    HIP_TRY(launch_by_n(sp, p->n, st));
   return GLFER_OK;
 }
 

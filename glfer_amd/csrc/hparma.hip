@@ -1,0 +1,241 @@
+// hparma.hip -- batched HP-ARMA estimator (BASELINE config 5), one wavefront per frame.
+//
+// Replaces hparma_do (hparma.c:74-157) + compute_svd (util.c:261-386) for a batch of frames:
+//   autocorrelation of the (unwindowed) frame for lags 0..t-1, the t x (p_e+1) "Toeplitz" matrix
+//   with the reference's row-0 overflow reproduced through a host-built lag map, one-sided
+//   Jacobi SVD in the reference's cyclic column order, rank from the cumulative sigma^2, AR
+//   vector from the noise subspace, |A(f)|^2/N on N/2+1 bins and its reciprocal below Nyquist.
+// This is latency/compute bound (thousands of dependent plane rotations per frame), not HBM
+// bound: frames are independent, so the launch simply keeps every SIMD busy with its own frame.
+// The matrix lives in LDS column-major (a column pair is two conflict-free strided reads per
+// lane), inner products are double as in the reference, the three sums of a rotation are reduced
+// across the wave with DPP, and every lane repeats the scalar part so all branches are uniform.
+// Compiled with -ffp-contract=off: a*c + b*s must round as the reference's two multiplies + add.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "spectro_params.h"
+
+namespace glfer {
+
+// sum of v over the 64 lanes, result in every lane
+__device__ __forceinline__ double wave_sum(double v) {
+  auto dpp = [](double x, auto ctrl) -> double {
+    constexpr int C = decltype(ctrl)::value;
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, C, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), C, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror: every lane holds its row's sum
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  double tot = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 16 * r);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 16 * r);
+    tot += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  }
+  return tot;
+}
+
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct HparmaParams {
+  SpectroParams s;          // stream, frame0, nframes, H, R, history_mode, fmt, psd (taps/tw unused)
+  int n;                    // block size N
+  int t;                    // equations (rows)
+  int ncol;                 // p_e + 1
+  const uint16_t *lagmap;   // [t][ncol]: which autocorrelation lag each matrix cell ends up holding
+  const float2 *unit;       // [N/2+1]: exp(-2 pi i k / N)
+};
+
+template <int FMT>
+__device__ __forceinline__ float hp_sample(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  if constexpr (FMT == GLFER_FMT_F32) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));
+  else if constexpr (FMT == GLFER_FMT_S16) return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, 0, 0) / 32768.0f;
+  else return ((float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsrc, voff, 0, 0) - 128.0f) / 128.0f;
+}
+
+template <int FMT>
+__global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
+  extern __shared__ float smem[];
+  const SpectroParams &p = hp.s;
+  const int N = hp.n, t = hp.t, ncol = hp.ncol;
+  const int lane = threadIdx.x;
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  // LDS: [x (N floats) overlaid later by A (t*ncol floats)] [Q ncol*ncol] [r t] [S ncol] [a ncol]
+  const int big = N > t * ncol ? N : t * ncol;
+  float *x = smem, *A = smem, *Q = smem + big, *rl = Q + ncol * ncol, *S = rl + t, *ar = S + ncol;
+
+  for (long long f = blockIdx.x; f < p.nframes; f += gridDim.x) {
+    // ---- K1: the assembled frame (prepare_audio, fft.c:98-113), unwindowed (source.c:369)
+    {
+      const long long s0 = (p.frame0 + f) * (long long)p.H - p.R;
+      const long long sbase = s0 > 0 ? s0 : 0;
+      const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sbase * (long long)esz, 0, 0x7fffffff, 0x00020000);
+      const int rel0 = (int)(s0 - sbase);
+      for (int j = lane; j < N; j += 64) {
+        const int rel = rel0 + j;
+        const bool ok = p.history_mode ? (j >= p.R) : (rel >= 0);
+        const float v = hp_sample<FMT>(xrsrc, ok ? (unsigned)rel * esz : 0x80000000u);
+        x[j] = ok ? v : 0.0f;
+      }
+    }
+    wave_fence();
+    // ---- autocorrelation (hparma.c:89-95): float products summed in double, k ascending
+    for (int i = lane; i < t; i += 64) {
+      double s = 0.0;
+      const int len = N - i;
+      for (int k = 0; k < len; k++) s += (double)(x[k + i] * x[k]);
+      rl[i] = (float)(s / (double)len);
+    }
+    wave_fence();
+    // ---- the t x ncol matrix, column-major A[j*t + i]; cell (i,j) holds lag lagmap[i][j]
+    // (hparma.c:94,98-102 incl. the row-0 overflow), and Q = I (util.c:286-291)
+    for (int i = lane; i < t; i += 64)
+      for (int j = 0; j < ncol; j++) A[j * t + i] = rl[hp.lagmap[i * ncol + j]];
+    for (int i = lane; i < ncol; i += 64)
+      for (int j = 0; j < ncol; j++) Q[j * ncol + i] = (i == j) ? 1.0f : 0.0f;
+    wave_fence();
+
+    // ---- one-sided Jacobi (util.c:294-356), cyclic by columns, same order as the reference
+    const int sweepmax = ncol > 12 ? ncol : 12;
+    int count = 1, sweep = 0;
+    while (count > 0 && sweep <= sweepmax) {
+      count = ncol * (ncol - 1) / 2;
+      for (int j = 0; j < ncol - 1; j++) {
+        for (int k = j + 1; k < ncol; k++) {
+          double pp = 0.0, qq = 0.0, rr = 0.0;
+          for (int i = lane; i < t; i += 64) {
+            const double aj = A[j * t + i], ak = A[k * t + i];
+            pp += aj * ak;
+            qq += aj * aj;
+            rr += ak * ak;
+          }
+          pp = wave_sum(pp);
+          qq = wave_sum(qq);
+          rr = wave_sum(rr);
+          if (qq * rr < 2.22e-16) { count--; continue; }            // util.c:316-320
+          if (pp * pp / (qq * rr) < 1.0e-12) { count--; continue; } // util.c:321-325
+          double cs, sn;
+          if (qq < rr) {                                            // util.c:327-335
+            cs = 0.0;
+            sn = 1.0;
+          } else {
+            qq -= rr;
+            const double v = sqrt(4.0 * pp * pp + qq * qq);
+            cs = sqrt((v + qq) / (2.0 * v));
+            sn = pp / (v * cs);
+          }
+          for (int i = lane; i < t; i += 64) {                      // util.c:338-343
+            const double ak = A[k * t + i], aj = A[j * t + i];
+            A[j * t + i] = (float)(aj * cs + ak * sn);
+            A[k * t + i] = (float)(-aj * sn + ak * cs);
+          }
+          for (int i = lane; i < ncol; i += 64) {                   // util.c:345-350
+            const double qj = Q[j * ncol + i], qk = Q[k * ncol + i];
+            Q[j * ncol + i] = (float)(qj * cs + qk * sn);
+            Q[k * ncol + i] = (float)(-qj * sn + qk * cs);
+          }
+          wave_fence();
+        }
+      }
+      sweep++;
+    }
+    // ---- singular values (util.c:365-373)
+    for (int j = 0; j < ncol; j++) {
+      double q = 0.0;
+      for (int i = lane; i < t; i += 64) {
+        const double a = A[j * t + i];
+        q += a * a;
+      }
+      q = wave_sum(q);
+      if (lane == 0) S[j] = (float)sqrt(q);
+    }
+    wave_fence();
+    // ---- rank (hparma.c:106-122) -- every lane repeats it, in the reference's order
+    double sum_sigma2 = 0.0;
+    for (int i = 0; i < ncol; i++) sum_sigma2 += (double)(S[i] * S[i]);
+    int prank = 4;
+    {
+      double acc = 0.0;
+      for (int i = 0; i < ncol; i++) {
+        acc += (double)(S[i] * S[i]);
+        if (sqrt(acc / sum_sigma2) > 0.995) { prank = i; break; }
+      }
+    }
+    // ---- AR vector from the noise subspace (hparma.c:125-138); v[i][k] = Q[k*ncol + i]
+    const int p_e = ncol - 1;
+    for (int i = lane; i < ncol; i += 64) {
+      double num = 0.0, den = 0.0;
+      for (int k = prank + 1; k <= p_e; k++) {
+        num += (double)(Q[k * ncol + 0] * Q[k * ncol + i]);
+        den += (double)(Q[k * ncol + 0] * Q[k * ncol + 0]);
+      }
+      ar[i] = (prank < p_e) ? (float)(num / den) : (i == 0 ? 1.0f : 0.0f);
+    }
+    wave_fence();
+    // ---- |A(f)|^2/N by Horner at z = exp(-2 pi i k/N) (what the zero-padded N-point FFT of
+    // hparma.c:140-153 evaluates), reciprocal below Nyquist (hparma.c:154-156)
+    float *o = p.psd + (size_t)f * (N / 2 + 1);
+    for (int k = lane; k <= N / 2; k += 64) {
+      const float2 z = hp.unit[k];
+      // double Horner: the reciprocal below magnifies evaluation error at the spectral peaks
+      const double zx = z.x, zy = z.y;
+      double re = ar[p_e], im = 0.0;
+      for (int m = p_e - 1; m >= 0; m--) {
+        const double nr = re * zx - im * zy + (double)ar[m];
+        im = re * zy + im * zx;
+        re = nr;
+      }
+      const float ps = (float)((re * re + im * im) / (double)N);
+      o[k] = (k < N / 2) ? (float)(1.0 / (double)ps) : ps;
+    }
+    wave_fence();
+  }
+}
+
+}  // namespace glfer
+
+using namespace glfer;
+
+extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const uint16_t *lagmap,
+                                          const float2 *unit, hipStream_t st) {
+  if (sp->nframes <= 0) return hipSuccess;
+  HparmaParams hp;
+  hp.s = *sp;
+  hp.n = n;
+  hp.t = t;
+  hp.ncol = ncol;
+  hp.lagmap = lagmap;
+  hp.unit = unit;
+  const int big = n > t * ncol ? n : t * ncol;
+  const size_t shmem = (size_t)(big + ncol * ncol + t + 2 * ncol) * sizeof(float);
+  const long long resident = 256LL * (shmem ? (160 * 1024) / shmem : 8);
+  const unsigned grid = (unsigned)(sp->nframes < resident ? sp->nframes : resident);
+  hipError_t e = hipSuccess;
+  switch (sp->fmt) {
+    case GLFER_FMT_F32:
+      e = hipFuncSetAttribute((const void *)hparma_kernel<GLFER_FMT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<GLFER_FMT_F32>), dim3(grid), dim3(64), shmem, st, hp);
+      break;
+    case GLFER_FMT_S16:
+      e = hipFuncSetAttribute((const void *)hparma_kernel<GLFER_FMT_S16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<GLFER_FMT_S16>), dim3(grid), dim3(64), shmem, st, hp);
+      break;
+    case GLFER_FMT_U8:
+      e = hipFuncSetAttribute((const void *)hparma_kernel<GLFER_FMT_U8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<GLFER_FMT_U8>), dim3(grid), dim3(64), shmem, st, hp);
+      break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}

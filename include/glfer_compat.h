@@ -47,6 +47,14 @@ typedef struct {
   int kmax;
 } mtm_params_t;
 
+/* hparma.h:25-32 */
+typedef struct {
+  fft_params_t fft;
+  int t;
+  int p_e;
+  int q_e;                      /* only -1 is supported (what source.c:375 sets) */
+} hparma_params_t;
+
 /* avg.h:28-36 */
 typedef struct {
   int    avgwidth;
@@ -70,6 +78,11 @@ void compute_floor(float *psd_buf, int n, float *sig_pwr_p, float *floor_pwr_p, 
 void mtm_init(mtm_params_t *params);
 void mtm_do(float *audio_buf, float *psd_buf, float *phase_buf, mtm_params_t *params);
 void mtm_close(mtm_params_t *params);
+
+/* hparma.h:34-38 */
+void hparma_init(hparma_params_t *params);
+void hparma_do(float *audio_buf, float *psd_buf, float *phase_buf, hparma_params_t *params);
+void hparma_close(hparma_params_t *params);
 
 /* avg.h:38-43 */
 void init_avg(avg_data_t *avgdata);

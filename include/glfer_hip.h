@@ -26,6 +26,7 @@ extern "C" {
 /* estimator: glfer.h:47  enum {MODE_NONE=-1, MODE_FFT, MODE_MTM, MODE_HPARMA, MODE_LMP} */
 #define GLFER_MODE_FFT 0
 #define GLFER_MODE_MTM 1
+#define GLFER_MODE_HPARMA 2
 
 /* window ids: fft.h:67 */
 #define GLFER_WIN_HANNING 0
@@ -79,12 +80,17 @@ typedef struct glfer_hip_config {
   int mtm_k;           /* opt.mtm_k = kmax; kmax+1 tapers are used (mtm.c:189)          */
   int sample_format;   /* GLFER_SAMPLES_*                                               */
   int device;          /* HIP device ordinal                                            */
+  int hparma_t;        /* opt.hparma_t: number of equations (rows), HP-ARMA mode (source.c:373) */
+  int hparma_p_e;      /* opt.hparma_p_e: number of poles (source.c:374); q_e is fixed to -1 (source.c:375) */
 } glfer_hip_config;
 
 typedef struct glfer_hip_plan glfer_hip_plan;
 
-/* fft_init (fft.c:168-187) / mtm_init (mtm.c:88-151): builds the window or the DPSS
- * tapers + eigenvalues on the host (double), uploads the device tables. */
+/* fft_init (fft.c:168-187) / mtm_init (mtm.c:88-151) / hparma_init (hparma.c:45-71): builds the
+ * window or the DPSS tapers + eigenvalues on the host (double), uploads the device tables.
+ * HP-ARMA mode (BASELINE config 5): hparma_do (hparma.c:74-157) per frame -- autocorrelation,
+ * the t x (p_e+1) matrix with the reference's row-0 overflow, one-sided Jacobi SVD (util.c:261-386),
+ * AR spectrum; window forced rectangular, a/limiter without effect (source.c:369-372). */
 int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **plan_out);
 /* fft_close (fft.c:297-306) / mtm_close (mtm.c:242-265) */
 void glfer_hip_plan_destroy(glfer_hip_plan *plan);

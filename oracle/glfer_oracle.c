@@ -719,6 +719,96 @@ int go_svd(float *A, int nrow, int ncol, float *S, float *Q)
 }
 
 /* ------------------------------------------------------------------ */
+/* hparma.c:74-157 hparma_do (q_e = -1, source.c:375) */
+void go_hparma_frame(go_fft_state *st, int t, int p_e, float *hop, int first_buffer, float *psd,
+                     float *a_out, int *rank_out)
+{
+  const int n = st->n, ncol = p_e + 1, q_e = -1;
+  /* matrix(0,t,0,p_e) (hparma.c:64): t+1 rows of ncol floats in ONE block, row r at r*ncol */
+  float *R = (float *)calloc((size_t)(t + 1) * ncol + 1, sizeof(float));
+  float *S = (float *)calloc((size_t)t + 1, sizeof(float));          /* vector(0,t)        hparma.c:66 */
+  float *V = (float *)calloc((size_t)ncol * ncol, sizeof(float));    /* matrix(0,p_e,0,p_e) hparma.c:67 */
+  float *a = (float *)calloc((size_t)ncol, sizeof(float));           /* vector(0,p_e)      hparma.c:69 */
+
+  go_prepare(st, hop, first_buffer);                                  /* hparma.c:86 */
+
+  for (int i = 0; i <= q_e + t; i++) {                                /* hparma.c:89-95 */
+    double s = 0.0;
+    for (int k = 0; k < n - i; k++)
+      s += st->inbuf_audio[k + i] * st->inbuf_audio[k];
+    R[i] = s / (n - i);                /* r_xx[0][i]: runs past column p_e into the next rows */
+  }
+  for (int i = 1; i < t; i++)                                         /* hparma.c:98-102 */
+    for (int j = 0; j <= p_e; j++)
+      R[i * ncol + j] = R[abs(j - i)]; /* r_xx[0][|j-i|], possibly a cell this loop already rewrote */
+
+  go_svd(R, t, ncol, S, V);                                           /* hparma.c:104 */
+
+  double sum_sigma2 = 0.0;                                            /* hparma.c:108-111 */
+  for (int i = 0; i < ncol; i++)
+    sum_sigma2 += S[i] * S[i];
+  int p = 4;                                                          /* hparma.c:84 */
+  {
+    double acc = 0.0;                                                 /* hparma.c:113-122 */
+    for (int i = 0; i < ncol; i++) {
+      acc += S[i] * S[i];
+      double nu = sqrt(acc / sum_sigma2);
+      if (nu > 0.995) {
+        p = i;
+        break;
+      }
+    }
+  }
+  for (int i = 0; i <= p_e; i++) {                                    /* hparma.c:125-138 */
+    double num = 0.0, den = 0.0;
+    for (int k = p + 1; k <= p_e; k++) {
+      num += V[0 * ncol + k] * V[i * ncol + k];
+      den += V[0 * ncol + k] * V[0 * ncol + k];
+    }
+    if (p < p_e)
+      a[i] = num / den;
+    else
+      a[i] = (i == 0 ? 1.0 : 0.0);
+  }
+  for (int i = 0; i <= p_e; i++)                                      /* hparma.c:140-145 */
+    st->inbuf_fft[i] = a[i];
+  for (int i = p_e + 1; i < n; i++)
+    st->inbuf_fft[i] = 0.0f;
+  go_rfft_halfcomplex(st->inbuf_fft, (size_t)n);                      /* hparma.c:150 */
+  go_psd(st->inbuf_fft, n, psd);                                      /* hparma.c:153 */
+  for (int i = 0; i < n / 2; i++)                                     /* hparma.c:154-156 */
+    psd[i] = 1.0 / psd[i];
+
+  if (a_out)
+    memcpy(a_out, a, (size_t)ncol * sizeof(float));
+  if (rank_out)
+    *rank_out = p;
+  free(R);
+  free(S);
+  free(V);
+  free(a);
+}
+
+/* source.c:130-156 over a whole stream, HP-ARMA mode (window forced rectangular, source.c:369) */
+void go_spectrogram_hparma(const float *stream, size_t nsamples, int n, float overlap, int t,
+                           int p_e, int sub_mean, int history_mode, float *psd_out)
+{
+  go_fft_state st;
+  go_fft_state_init(&st, n, overlap, GO_WIN_RECTANGULAR, 0.0f, 0, sub_mean);
+  const int h = go_hop(n, overlap);
+  const size_t frames = go_num_frames(nsamples, n, overlap);
+  const size_t nb = (size_t)n / 2 + 1;
+  float *hop = (float *)malloc((size_t)h * sizeof(float));
+  for (size_t f = 0; f < frames; f++) {
+    memcpy(hop, stream + f * h, (size_t)h * sizeof(float));
+    int first = (history_mode == 1) ? 1 : (f == 0);
+    go_hparma_frame(&st, t, p_e, hop, first, psd_out + f * nb, NULL, NULL);
+  }
+  free(hop);
+  go_fft_state_free(&st);
+}
+
+/* ------------------------------------------------------------------ */
 /* wav_fmt.c:104-117 */
 void go_pcm_u8_to_float(const unsigned char *in, size_t n, float *out)
 {

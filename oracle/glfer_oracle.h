@@ -112,6 +112,19 @@ double go_avg_sumavg(go_avg *a, int n, const float *psd, int max0, int minbin,
  * float, Q is [ncol][ncol]. */
 int go_svd(float *A, int nrow, int ncol, float *S, float *Q);
 
+/* hparma.c:74-157 hparma_do() for one frame (q_e = -1 as set at source.c:375): autocorrelation
+ * lags 0..t-1 written into ROW 0 of the (t+1) x (p_e+1) Numerical-Recipes matrix -- past its
+ * p_e+1 columns, i.e. into the following rows (util.c:153-160 lays the rows out contiguously) --
+ * Toeplitz fill from those (partly overwritten) cells, one-sided Jacobi SVD, rank by
+ * sqrt(cumulative sigma^2 / total) > 0.995, AR vector from the noise subspace, N-point FFT of
+ * the zero-padded AR vector, psd[i] = 1/psd[i] for i < N/2 (the Nyquist bin is not inverted).
+ * a_out (optional): the p_e+1 AR coefficients; rank_out (optional): the rank p. */
+void go_hparma_frame(go_fft_state *st, int t, int p_e, float *hop, int first_buffer, float *psd,
+                     float *a_out, int *rank_out);
+
+void go_spectrogram_hparma(const float *stream, size_t nsamples, int n, float overlap, int t,
+                           int p_e, int sub_mean, int history_mode, float *psd_out);
+
 /* wav_fmt.c:104-117 sample conversion rules. */
 void go_pcm_u8_to_float(const unsigned char *in, size_t n, float *out);
 void go_pcm_s16_to_float(const short *in, size_t n, float *out);

@@ -49,6 +49,11 @@ def _load():
                                        C.c_float, C.c_int, C.c_int, C.c_int, _f32p]
     lib.go_spectrogram_mtm.argtypes = [_f32p, C.c_size_t, C.c_int, C.c_float, C.c_double,
                                        C.c_int, C.c_int, C.c_int, _f32p]
+    lib.go_spectrogram_hparma.argtypes = [_f32p, C.c_size_t, C.c_int, C.c_float, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, _f32p]
+    lib.go_hparma_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, _f32p, C.c_int, _f32p, _f32p, C.POINTER(C.c_int)]
+    lib.go_fft_state_init.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int]
+    lib.go_fft_state_free.argtypes = [C.c_void_p]
     lib.go_svd.restype = C.c_int
     lib.go_svd.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p]
     lib.go_pcm_u8_to_float.argtypes = [np.ctypeslib.ndpointer(np.uint8), C.c_size_t, _f32p]
@@ -142,6 +147,40 @@ def spectrogram_mtm(stream, n, overlap, nw, kmax, sub_mean=0, history_mode=0):
     out = np.empty((frames, n // 2 + 1), np.float32)
     _lib.go_spectrogram_mtm(stream, stream.size, n, C.c_float(overlap), float(nw), int(kmax),
                             int(sub_mean), int(history_mode), out)
+    return out
+
+
+def spectrogram_hparma(stream, n, overlap, t, p_e, sub_mean=0, history_mode=0):
+    stream = np.ascontiguousarray(stream, np.float32)
+    frames = num_frames(stream.size, n, overlap)
+    out = np.empty((frames, n // 2 + 1), np.float32)
+    _lib.go_spectrogram_hparma(stream, stream.size, n, C.c_float(overlap), int(t), int(p_e),
+                               int(sub_mean), int(history_mode), out)
+    return out
+
+
+class _GoFftState(C.Structure):
+    _fields_ = [("n", C.c_int), ("overlap", C.c_float), ("window_type", C.c_int), ("a", C.c_float),
+                ("limiter", C.c_int), ("sub_mean", C.c_int), ("window", C.c_void_p),
+                ("inbuf_audio", C.c_void_p), ("inbuf_fft", C.c_void_p)]
+
+
+def hparma_frames(stream, n, overlap, t, p_e, sub_mean=0):
+    """Per frame: (psd[n/2+1], AR vector a[p_e+1], rank p) -- hparma_do with its intermediates."""
+    stream = np.ascontiguousarray(stream, np.float32)
+    h = hop(n, overlap)
+    frames = num_frames(stream.size, n, overlap)
+    st = _GoFftState()
+    _lib.go_fft_state_init(C.byref(st), n, C.c_float(overlap), WINDOWS["rectangular"], C.c_float(0.0), 0, sub_mean)
+    out = []
+    for f in range(frames):
+        hopbuf = stream[f * h:(f + 1) * h].copy()
+        psd = np.empty(n // 2 + 1, np.float32)
+        a = np.empty(p_e + 1, np.float32)
+        rank = C.c_int(0)
+        _lib.go_hparma_frame(C.byref(st), t, p_e, hopbuf, 1 if f == 0 else 0, psd, a, C.byref(rank))
+        out.append((psd, a, rank.value))
+    _lib.go_fft_state_free(C.byref(st))
     return out
 
 

@@ -24,5 +24,6 @@ CONFIGS = {
     "C2": dict(mode="fft", n=4096, overlap=0.75, window="hanning", fs=48000.0),
     "C3": dict(mode="mtm", n=4096, overlap=0.0, nw=2.5, kmax=4, fs=48000.0),
     "C3o": dict(mode="mtm", n=4096, overlap=0.75, nw=2.5, kmax=4, fs=48000.0),
+    "C5": dict(mode="hparma", n=4096, overlap=0.0, t=128, p_e=32, fs=48000.0),
     "C4": dict(mode="mtm", n=16384, overlap=0.0, nw=4.5, kmax=8, fs=48000.0),
 }

@@ -141,3 +141,27 @@ def test_compute_floor_and_update_avg(compat, oracle):
             assert abs(r / want_ret[0] - 1) < 1e-11 and peak.value == want_ret[1]
             assert a.effdepth == min(f + 1, depth)
         compat.delete_avg(C.byref(a))
+
+
+class HparmaParams(C.Structure):    # hparma.h:25-32
+    _fields_ = [("fft", FftParams), ("t", C.c_int), ("p_e", C.c_int), ("q_e", C.c_int)]
+
+
+def test_hparma_do_hop_by_hop(compat, oracle):
+    n, ovl, t, p_e = 4096, 0.5, 128, 32
+    h = oracle.hop(n, ovl)
+    x = synth(5 * h, seed=14)
+    _set(compat, "glfer_compat_autoscale", 0)
+    _set(compat, "glfer_compat_first_buffer", 1)
+    p = HparmaParams()
+    p.fft.n, p.fft.window_type, p.fft.overlap, p.fft.a, p.fft.limiter = n, 5, ovl, 0.0, 0   # source.c:368-372
+    p.t, p.p_e, p.q_e = t, p_e, -1                                                          # source.c:373-375
+    compat.hparma_init(C.byref(p))
+    psd = np.empty(n // 2 + 1, np.float32)
+    want = oracle.spectrogram_hparma(x, n, ovl, t, p_e)
+    for f in range(5):
+        hop = x[f * h:(f + 1) * h].copy()
+        compat.hparma_do(_fp(hop), _fp(psd), None, C.byref(p))
+        _set(compat, "glfer_compat_first_buffer", 0)
+        assert max(rel_err(1.0 / psd[:n // 2].astype(np.float64), 1.0 / want[f, :n // 2].astype(np.float64))) < 1e-4
+    compat.hparma_close(C.byref(p))

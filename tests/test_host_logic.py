@@ -27,7 +27,7 @@ def test_compat_library_exports_reference_entry_points():
     import torch  # noqa: F401  (one HIP runtime per process: torch's, loaded first)
     L = ctypes.CDLL(path)
     for sym in ("fft_init", "fft_do", "fft_psd", "fft_close", "mtm_init", "mtm_do", "mtm_close",
-                "compute_floor", "init_avg", "alloc_avg", "delete_avg", "update_avg_plain",
+                "hparma_init", "hparma_do", "hparma_close", "compute_floor", "init_avg", "alloc_avg", "delete_avg", "update_avg_plain",
                 "update_avg_sumextreme", "update_avg_sumavg"):
         assert hasattr(L, sym), sym
 

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from _signals import synth
+from _signals import rel_err, synth
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -172,6 +172,11 @@ def test_oracle_reproduces_golden(oracle, path):
                     r, avg, peak, var = a.update(mode, psd[f], int(g["minbin"]), int(g["maxbin"]), max0=max0, n=513)
                     assert np.array_equal(avg, g["%s_max%d_avg" % (mode, max0)][f])
                     assert np.array_equal(np.array([r, peak, var]), g["%s_max%d_ret" % (mode, max0)][f], equal_nan=True)
+    elif str(g["mode"]) == "hparma":
+        got = oracle.spectrogram_hparma(g["x"], int(g["n"]), float(g["overlap"]), int(g["t"]), int(g["p_e"]))
+        assert np.array_equal(got, g["psd"])
+        fr = oracle.hparma_frames(g["x"], int(g["n"]), float(g["overlap"]), int(g["t"]), int(g["p_e"]))
+        assert all(np.array_equal(f[1], a) and f[2] == r for f, a, r in zip(fr, g["ar"], g["rank"]))
     elif str(g["mode"]) == "fft":
         got = oracle.spectrogram_fft(g["x"], int(g["n"]), float(g["overlap"]), int(g["window"]), float(g["a"]),
                                      int(g["limiter"]), int(g["sub_mean"]), int(g["history_mode"]))
@@ -181,3 +186,46 @@ def test_oracle_reproduces_golden(oracle, path):
         got = oracle.spectrogram_mtm(g["x"], int(g["n"]), float(g["overlap"]), float(g["nw"]), int(g["kmax"]),
                                      int(g["sub_mean"]), int(g["history_mode"]))
         assert np.array_equal(got, g["psd"])
+
+
+def test_hparma_row0_overflow_and_ar_spectrum(oracle):
+    """hparma.c:89-102: lags 0..t-1 go into row 0 of a (t+1) x (p_e+1) contiguous matrix, so rows
+    i > p_e are built from already rewritten cells ("row 33 col 0 holds r(1) not r(33)").
+    The restatement is checked against an independent numpy construction of that aliasing and of
+    the rest of hparma_do (numpy SVD for the subspace instead of the Jacobi sweeps)."""
+    n, t, p_e = 4096, 128, 32
+    ncol = p_e + 1
+    x = synth(n, seed=12)
+    (psd, a, rank), = oracle.hparma_frames(x, n, 0.0, t, p_e)
+    xd = x.astype(np.float64)
+    r = np.array([np.dot(xd[i:], xd[:n - i]) / (n - i) for i in range(t)]).astype(np.float32)
+    flat = np.zeros((t + 1) * ncol, np.float32)
+    flat[:t] = r
+    for i in range(1, t):
+        for j in range(ncol):
+            flat[i * ncol + j] = flat[abs(j - i)]
+    M = flat[:t * ncol].reshape(t, ncol).astype(np.float64)
+    assert M[33, 0] == r[1] and M[33, 0] != r[33]                     # the aliasing itself
+    U, S, Vt = np.linalg.svd(M, full_matrices=False)
+    nu = np.sqrt(np.cumsum(S ** 2) / np.sum(S ** 2))
+    assert rank == int(np.argmax(nu > 0.995))
+    V = Vt.T
+    noise = V[:, rank + 1:]
+    a_np = noise @ noise[0] / (noise[0] @ noise[0])                   # hparma.c:125-138: projector row 0, normalised
+    assert np.abs(a.astype(np.float64) - a_np).max() < 5e-4 * np.abs(a_np).max()
+    A = np.polyval(a[::-1].astype(np.float64), np.exp(-2j * np.pi * np.arange(n // 2 + 1) / n))
+    inv = np.abs(A) ** 2 / n
+    got_inv = np.concatenate([1.0 / psd[:n // 2].astype(np.float64), psd[n // 2:].astype(np.float64)])
+    assert np.abs(got_inv - inv).max() / inv.max() < 1e-5            # the float32 FFT of the padded AR vector
+
+
+def test_hparma_is_conditioned_at_1e5(oracle):
+    """Why HP-ARMA parity is stated at 1e-4: perturbing every input sample by at most one float
+    ulp moves the REFERENCE algorithm's own |A(f)|^2 by up to ~1e-5 (peak-normalised)."""
+    n, ovl, t, p_e = 1024, 0.5, 96, 16
+    x = synth(10 * 512, seed=n + t)
+    rng = np.random.default_rng(0)
+    x2 = (x.view(np.int32) + rng.integers(-1, 2, x.size).astype(np.int32)).view(np.float32)
+    a, b = oracle.hparma_frames(x, n, ovl, t, p_e), oracle.hparma_frames(x2, n, ovl, t, p_e)
+    errs = [max(rel_err(1.0 / q[0][:n // 2].astype(np.float64), 1.0 / p[0][:n // 2].astype(np.float64))) for p, q in zip(a, b)]
+    assert 1e-6 < max(errs) < 1e-4, errs

@@ -55,6 +55,11 @@ def main():
     fft_case("c2_fft4096_hann_ovl75_s0", 4096, 0.75, "hanning", 12, 48000.0, 0)
     mtm_case("c3_mtm4096_nw25_k4_ovl0_s0", 4096, 0.0, 2.5, 4, 6, 48000.0, 0)
     mtm_case("c3_mtm4096_nw25_k4_ovl75_s1", 4096, 0.75, 2.5, 4, 10, 48000.0, 1)
+    # BASELINE config 5: HP-ARMA t=128, p_e=32, N=4096 (psd + AR vector + rank per frame)
+    x = synth(4 * 4096, seed=5)
+    fr = O.hparma_frames(x, 4096, 0.0, 128, 32)
+    save("c5_hparma4096_t128_p32_s5", mode="hparma", n=4096, overlap=np.float32(0.0), t=128, p_e=32, seed=5, x=x,
+         psd=np.array([f[0] for f in fr]), ar=np.array([f[1] for f in fr]), rank=np.array([f[2] for f in fr]))
     # edge fixtures
     fft_case("e_fft1024_kaiser_submean", 1024, 0.5, "kaiser", 10, 8000.0, 2, sub_mean=1)
     fft_case("e_fft1024_hann_zero_always", 1024, 0.5, "hanning", 6, 8000.0, 2, history_mode=1)
