@@ -50,6 +50,8 @@ def cpu_baseline(workload, n, overlap, nw, kmax, frames):
     t0 = time.perf_counter()
     if workload == "mtm":
         O.spectrogram_mtm(x, n, overlap, nw, kmax)
+    elif workload == "hparma":
+        O.spectrogram_hparma(x, n, overlap, 128, 32)
     else:
         O.spectrogram_fft(x, n, overlap, O.WINDOWS["hanning"])
     dt = time.perf_counter() - t0
@@ -65,7 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=262144, help="frames per GPU per step")
-    ap.add_argument("--workload", default="mtm", choices=["mtm", "fft"])
+    ap.add_argument("--workload", default="mtm", choices=["mtm", "fft", "hparma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -88,6 +90,12 @@ def main():
         n, overlap, nw, kmax = 4096, 0.0, 2.5, 4
         params = G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax)
         name = "C3: multitaper N=4096 NW=2.5 mtm_k=4 (5 tapers), overlap 0, 48 kHz mono f32"
+    elif args.workload == "hparma":
+        n, overlap, nw, kmax = 4096, 0.0, 0.0, 0
+        params = G.HparmaParams(n=n, overlap=overlap, t=128, p_e=32)
+        name = "C5: HP-ARMA t=128 p_e=32 N=4096, overlap 0, 48 kHz mono f32 (compute/latency bound, not HBM)"
+        if args.frames == 262144:
+            args.frames = 16384
     else:
         n, overlap, nw, kmax = 4096, 0.75, 0.0, 0
         params = G.FftParams(n=n, window_type=G.WINDOWS["hanning"], overlap=overlap)
@@ -146,8 +154,9 @@ def main():
         except Exception:
             pass
         line = {
-            "metric": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4" if args.workload == "mtm"
-                      else "spectrogram frames/sec + achieved HBM GB/s, N=4096 periodogram",
+            "metric": {"mtm": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4",
+                       "fft": "spectrogram frames/sec + achieved HBM GB/s, N=4096 periodogram",
+                       "hparma": "spectrogram frames/sec, HP-ARMA t=128 p_e=32 N=4096"}[args.workload],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -157,7 +166,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch, rocprofv3 PMC (profiles/r01_hbm_traffic.json)",
                          "algorithmic_bytes_per_launch": frames * b_alg,
-                         "kernel": "spectro16_kernel<12>", "kernel_ms": kernel_ms,
+                         "kernel": "hparma_kernel" if args.workload == "hparma" else "spectro16_kernel<12>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_frame": b_alg,
                          "note": "MTM is FP32-VALU-bound on this chip (SURVEY 7): see valu_frac"},
             "hbm_gbs_aggregate": fps * b_alg / 1e9,
@@ -171,7 +180,7 @@ def main():
                         "peak_Tops": VALU_PEAK_TOPS,
                         "frac": frames * lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}
         if world == 1 and not args.no_cpu_baseline:
-            cpu_frames = 16384 if args.workload == "mtm" else 131072
+            cpu_frames = {"mtm": 16384, "fft": 131072, "hparma": 4096}[args.workload]
             line["cpu_baseline"] = cpu_baseline(args.workload, n, overlap, nw, kmax, cpu_frames)
         print(json.dumps(line))
     if world > 1:

@@ -32,7 +32,7 @@ EXPORTS = [
     "glfer_hip_spectrum_device", "glfer_hip_spectrogram_host", "glfer_hip_wav_probe",
     "glfer_hip_spectrogram_wav", "glfer_hip_submean_device",
     "glfer_hip_floor_device",
-    "glfer_hip_avg_device", "glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version",
+    "glfer_hip_avg_device", "glfer_hip_palette", "glfer_hip_display_device", "glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version",
 ]
 
 
@@ -47,6 +47,24 @@ class Config(C.Structure):
                 ("sub_mean", C.c_int), ("history_mode", C.c_int), ("mtm_w", C.c_float),
                 ("mtm_k", C.c_int), ("sample_format", C.c_int), ("device", C.c_int),
                 ("hparma_t", C.c_int), ("hparma_p_e", C.c_int)]
+
+
+class Display(C.Structure):
+    """glfer_hip_display (include/glfer_hip.h): the options and the carried state of
+    main_window_draw's level tracking and pixel mapping (g_main.c:1099-1236)."""
+    _fields_ = [("scale_type", C.c_int), ("autoscale", C.c_int), ("overlap", C.c_float),
+                ("max_level_db", C.c_float), ("min_level_db", C.c_float), ("thr_level", C.c_float),
+                ("palette", C.c_int), ("first_buffer", C.c_int), ("display_max_lvl", C.c_float),
+                ("display_min_lvl", C.c_float)]
+
+    def __init__(self, scale_type=2, autoscale=1, overlap=0.0, max_level_db=-10.0, min_level_db=-60.0,
+                 thr_level=0.0, palette=0, first_buffer=1):
+        super().__init__(scale_type, autoscale, overlap, max_level_db, min_level_db, thr_level,
+                         palette, first_buffer, 0.0, 0.0)
+
+
+SCALE_LIN, SCALE_LIN_MAX0, SCALE_LOG, SCALE_LOG_MAX0 = range(4)          # glfer.h:43
+PALETTES = {"hsv": 0, "thresh": 1, "cool": 2, "hot": 3, "bw": 4, "bone": 5, "copper": 6, "otd": 7}
 
 
 class WavInfo(C.Structure):
@@ -93,6 +111,8 @@ def lib():
     L.glfer_hip_spectrogram_wav.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz), sz]
     L.glfer_hip_submean_device.argtypes = [vp, vp, C.c_int, sz, C.c_int, vp]
     L.glfer_hip_floor_device.argtypes = [vp, sz, C.c_int, vp, vp]
+    L.glfer_hip_palette.argtypes = [C.c_int, vp]
+    L.glfer_hip_display_device.argtypes = [C.POINTER(Display), vp, vp, vp, sz, C.c_int, vp, vp, vp, vp]
     L.glfer_hip_avg_device.argtypes = [C.c_int, vp, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, vp, vp, vp]
     for f in ("glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version"):
@@ -283,6 +303,39 @@ def compute_floor(psd):
     _check(lib().glfer_hip_floor_device(psd.data_ptr(), psd.shape[0], psd.shape[1], out.data_ptr(), st),
            "glfer_hip_floor_device")
     return out
+
+
+def palette(p_n):
+    """set_palette (g_main.c:651-762) as a uint8 [256][3] numpy array (host table)."""
+    import numpy as np
+    tab = (C.c_ubyte * 768)()
+    _check(lib().glfer_hip_palette(int(p_n), tab), "glfer_hip_palette")
+    return np.frombuffer(bytes(tab), np.uint8).reshape(256, 3).copy()
+
+
+def display(disp, src, stats, want_lev=True, want_levels=True):
+    """The column mapping of main_window_draw (g_main.c:1099-1236) for every row of `src`
+    (float32 PSD, or float64 averaged spectrum from update_avg) with compute_floor's `stats`.
+    `disp` (a Display) carries first_buffer / display_*_lvl across calls and is updated.
+    Returns (rgb uint8 [frames][bins][3], lev int16 [frames][bins] | None,
+    levels float32 [frames][4] | None)."""
+    torch = _torch()
+    assert src.is_cuda and src.is_contiguous() and src.dim() == 2
+    assert src.dtype in (torch.float32, torch.float64)
+    assert stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous()
+    assert stats.shape == (src.shape[0], 4)
+    frames, bins = src.shape
+    rgb = torch.empty((frames, bins, 3), dtype=torch.uint8, device=src.device)
+    lev = torch.empty((frames, bins), dtype=torch.int16, device=src.device) if want_lev else None
+    levels = torch.empty((frames, 4), dtype=torch.float32, device=src.device) if want_levels else None
+    st = C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
+    is_d = src.dtype == torch.float64
+    _check(lib().glfer_hip_display_device(
+        C.byref(disp), None if is_d else C.c_void_p(src.data_ptr()),
+        C.c_void_p(src.data_ptr()) if is_d else None, C.c_void_p(stats.data_ptr()), frames, bins,
+        C.c_void_p(rgb.data_ptr()), C.c_void_p(lev.data_ptr()) if want_lev else None,
+        C.c_void_p(levels.data_ptr()) if want_levels else None, st), "glfer_hip_display_device")
+    return rgb, lev, levels
 
 
 def update_avg(mode, psd, depth, minbin, maxbin, max0=0, n_out=None):

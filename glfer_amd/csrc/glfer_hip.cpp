@@ -76,6 +76,77 @@ extern "C" {
 
 const char *glfer_hip_version(void) { return "glfer_hip 0.2 (gfx950, 16 points/lane Stockham radix-16, LDS exchange)"; }
 
+int glfer_hip_palette(int palette, unsigned char colortab[768]) {
+  if (!colortab) return GLFER_E_ARG;
+  glfer::make_palette(palette, colortab);
+  return GLFER_OK;
+}
+
+int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const double *d_avg, const float *d_stats,
+                             size_t nframes, int bins, unsigned char *d_rgb, short *d_lev, float *d_levels,
+                             void *hip_stream) {
+  if (!d || !d_stats || !d_rgb || bins < 1) return GLFER_E_ARG;
+  if ((d_psd == nullptr) == (d_avg == nullptr)) return GLFER_E_ARG;
+  if (d->scale_type < GLFER_SCALE_LIN || d->scale_type > GLFER_SCALE_LOG_MAX0) return GLFER_E_ARG;
+  if (nframes == 0) return GLFER_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int scale_log = d->scale_type == GLFER_SCALE_LOG || d->scale_type == GLFER_SCALE_LOG_MAX0;
+
+  float *levels = d_levels;
+  float *scratch = nullptr;
+  unsigned char *d_tab = nullptr;
+  if (!levels) {
+    HIP_TRY(hipMalloc(&scratch, nframes * 4 * sizeof(float)));
+    levels = scratch;
+  }
+  int rc = GLFER_OK;
+  auto fail = [&](hipError_t err) { rc = hip_fail(err, "glfer_hip_display_device"); };
+  hipError_t e = hipMalloc(&d_tab, 768);
+  if (e != hipSuccess) { fail(e); (void)hipFree(scratch); return rc; }
+  unsigned char tab[768];
+  glfer::make_palette(d->palette, tab);
+  // pageable source: hipMemcpyAsync stages it before returning, so `tab` may go out of scope
+  e = hipMemcpyAsync(d_tab, tab, 768, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) fail(e);
+
+  if (rc == GLFER_OK) {
+    if (d->autoscale) {
+      e = glfer_launch_levels(d_stats, nframes, scale_log, 1, d->first_buffer, d->overlap, d->display_max_lvl,
+                              d->display_min_lvl, levels, st);
+    } else {                                                                   // g_main.c:1125-1139
+      float mx = pow(10.0, d->max_level_db / 10.0);
+      float mn = pow(10.0, d->min_level_db / 10.0);
+      mn = (mx > mn ? mn : mx / 10.0);
+      const float dmax = scale_log ? (float)(10.0 * log10(mx)) : mx;
+      const float dmin = scale_log ? (float)(10.0 * log10(mn)) : mn;
+      e = glfer_launch_levels_fixed(nframes, dmax, dmin, mx, mn, levels, st);
+    }
+    if (e != hipSuccess) fail(e);
+  }
+  if (rc == GLFER_OK) {
+    const float thr_level = d->thr_level / 100.0;                              // g_main.c:1099
+    e = glfer_launch_map(d_psd, d_avg, nframes, bins, scale_log, 255.0 * thr_level, 1.0 - thr_level, levels,
+                         d_tab, d_rgb, d_lev, st);
+    if (e != hipSuccess) fail(e);
+  }
+  float last[4] = {0, 0, 0, 0};
+  if (rc == GLFER_OK) {
+    e = hipMemcpyAsync(last, levels + (nframes - 1) * 4, sizeof last, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) fail(e);
+  } else {
+    (void)hipStreamSynchronize(st);
+  }
+  (void)hipFree(d_tab);
+  (void)hipFree(scratch);
+  if (rc == GLFER_OK) {
+    d->display_max_lvl = last[2];
+    d->display_min_lvl = last[3];
+    if (d->autoscale) d->first_buffer = 0;                                     // g_main.c:1120
+  }
+  return rc;
+}
+
 const char *glfer_hip_strerror(int code) {
   switch (code) {
     case GLFER_OK: return "ok";

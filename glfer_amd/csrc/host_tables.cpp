@@ -231,4 +231,46 @@ int make_twiddles16(int logn, float *tw_re_im) {
   return slot;
 }
 
+// ---------------------------------------------------------------------------
+// set_palette (g_main.c:651-762).  Every palette of the reference is piecewise linear in the
+// colour index c: channel = (unsigned char)(a*c + b) on [from, upto).  The reference converts
+// the double straight to unsigned char although some segments run below 0 or past 255 (OTD at
+// c = 0, BONE's red above c = 262/1.2, COPPER's red near c = 207); on x86-64 that conversion
+// is "truncate to int32, keep the low byte", which byte_of() spells out.
+namespace {
+struct Lin { double a, b; };
+struct Seg { int upto; Lin r, g, b; };
+constexpr Lin K0{0.0, 0.0}, K255{0.0, 255.0};
+
+const Seg kHsv[] = {{64, K0, {4.0, 0.0}, K255}, {128, K0, K255, {-4.0, 510.0}},
+                    {192, {4.0, -510.0}, K255, K0}, {256, K255, {-4.0, 1020.0}, K0}};
+const Seg kThresh[] = {{16, K0, K0, K0}, {64, K0, {4.0, 0.0}, K255}, {128, K0, K255, {-4.0, 510.0}},
+                       {192, {4.0, -510.0}, K255, K0}, {256, K255, {-4.0, 1020.0}, K0}};
+const Seg kCool[] = {{256, {1.0, 0.0}, {-1.0, 255.0}, K255}};
+const Seg kHot[] = {{96, {2.66667, 0.5}, K0, K0}, {192, K255, {2.66667, -254.0}, K0},
+                    {256, K255, K255, {4.0, -766.0}}};
+const Seg kBw[] = {{256, {1.0, 0.0}, {1.0, 0.0}, {1.0, 0.0}}};
+const Seg kBone[] = {{96, {0.88889, 0.0}, {0.88889, 0.0}, {1.2, 0.0}},
+                     {192, {0.88889, 0.0}, {1.2, -29.0}, {0.88889, 29.0}},
+                     {256, {1.2, -60.0}, {0.88889, 29.0}, {0.88889, 29.0}}};
+const Seg kCopper[] = {{208, {1.23, 0.0}, {0.78, 0.0}, {0.5, 0.0}}, {256, K255, {0.78, 0.0}, {0.5, 0.0}}};
+const Seg kOtd[] = {{128, K0, {2.0, -1.0}, {-2.0, 255.0}}, {256, {2.0, -255.0}, {-2.0, 511.0}, K0}};
+const Seg *const kPalettes[] = {kHsv, kThresh, kCool, kHot, kBw, kBone, kCopper, kOtd};
+
+inline unsigned char byte_of(Lin l, int c) {
+  const double v = l.a * (double)c + l.b;
+  return (unsigned char)(int)v;
+}
+}  // namespace
+
+void make_palette(int palette, unsigned char tab[768]) {
+  const Seg *seg = (palette >= 0 && palette < 8) ? kPalettes[palette] : kBw;   // else branch: black and white
+  for (int c = 0; c < 256; c++) {
+    while (c >= seg->upto) ++seg;
+    tab[3 * c] = byte_of(seg->r, c);
+    tab[3 * c + 1] = byte_of(seg->g, c);
+    tab[3 * c + 2] = byte_of(seg->b, c);
+  }
+}
+
 }  // namespace glfer

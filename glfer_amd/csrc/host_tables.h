@@ -4,6 +4,7 @@ namespace glfer {
 void make_window(int type, int n, float *w);                               // fft.c:309-360
 bool make_dpss(int n, int kmax, double nw, double *tapers, double *sig);   // g-l_dpss.c:288-347
 void make_twiddles(int n, int lanes, float *tw_re_im);                     // [64][lanes] (cos,sin)
+void make_palette(int palette, unsigned char colortab[768]);               // g_main.c:651-762
 int plan16_passes(int logn, int radix[4]);                                  // spectro16.hip schedule
 int make_twiddles16(int logn, float *tw_re_im);                            // returns slots per lane; [slot][N/16] (cos,sin)
 }  // namespace glfer

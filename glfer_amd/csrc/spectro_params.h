@@ -36,6 +36,14 @@ hipError_t glfer_launch_spectro16_n11(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16_n13(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16_n14(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_levels(const float *stats, size_t nframes, int scale_log, int autoscale,
+                               int first_buffer, float overlap, float max_lvl0, float min_lvl0,
+                               float *levels, hipStream_t st);
+hipError_t glfer_launch_levels_fixed(size_t nframes, float dmax, float dmin, float max_lvl, float min_lvl,
+                                     float *levels, hipStream_t st);
+hipError_t glfer_launch_map(const float *psd, const double *avg, size_t nframes, int n, int scale_log,
+                            double thr255, double one_m_thr, const float *levels,
+                            const unsigned char *colortab, unsigned char *rgb, short *lev, hipStream_t st);
 hipError_t glfer_launch_submean(const void *in, float *out, int H, long long nhops, int fmt,
                                 hipStream_t st);
 #ifdef __cplusplus

@@ -184,6 +184,43 @@ int glfer_hip_avg_device(int avg_mode, const float *d_psd, size_t nframes, int b
                          int depth, int minbin, int maxbin, int max0, double *d_avg,
                          double *d_ret, void *hip_stream);
 
+/* ---- display mapping: main_window_draw's column loop (g_main.c:1099-1236) over a batch ---- */
+enum { GLFER_SCALE_LIN = 0, GLFER_SCALE_LIN_MAX0, GLFER_SCALE_LOG, GLFER_SCALE_LOG_MAX0 };   /* glfer.h:43 */
+enum { GLFER_PAL_HSV = 0, GLFER_PAL_THRESH, GLFER_PAL_COOL, GLFER_PAL_HOT, GLFER_PAL_BW,
+       GLFER_PAL_BONE, GLFER_PAL_COPPER, GLFER_PAL_OTD };                                      /* glfer.h:47 */
+
+typedef struct {
+  int scale_type;          /* opt.scale_type                                                   */
+  int autoscale;           /* opt.autoscale                                                    */
+  float overlap;           /* opt.data_blocks_overlap (first-buffer correction, g_main.c:1114) */
+  float max_level_db;      /* opt.max_level_db / opt.min_level_db: used when autoscale is off  */
+  float min_level_db;
+  float thr_level;         /* opt.thr_level, percent                                           */
+  int palette;             /* opt.palette                                                      */
+  /* the state main_window_draw keeps between columns; updated by every call */
+  int first_buffer;        /* glfer.first_buffer                                               */
+  float display_max_lvl;   /* the two function statics of g_main.c:1081                        */
+  float display_min_lvl;
+} glfer_hip_display;
+
+/* set_palette (g_main.c:651-762): 256 RGB triplets into host memory. */
+int glfer_hip_palette(int palette, unsigned char colortab[768]);
+
+/* One call = `nframes` consecutive calls of the mapping part of main_window_draw.
+ *   d_psd    : [nframes][bins] float PSD rows (opt.averaging == NO_AVG), or NULL
+ *   d_avg    : [nframes][bins] double rows of avgdata.avg (any averaging mode), or NULL
+ *              -- exactly one of the two is given
+ *   d_stats  : [nframes][4] as written by glfer_hip_floor_device (sig, floor are used)
+ *   d_rgb    : [nframes][bins][3] bytes, pixel i of a column = bin bins-1-i (rgbbuf, n_zoom 1)
+ *   d_lev    : [nframes][bins] shorts = levbuf column, or NULL
+ *   d_levels : [nframes][4] floats = {display_max, display_min, display_max_lvl,
+ *              display_min_lvl} used for each column, or NULL
+ * disp->first_buffer / display_*_lvl are read as the incoming state and updated to the state
+ * after the last column (the call synchronises the stream to read them back). */
+int glfer_hip_display_device(glfer_hip_display *disp, const float *d_psd, const double *d_avg,
+                             const float *d_stats, size_t nframes, int bins, unsigned char *d_rgb,
+                             short *d_lev, float *d_levels, void *hip_stream);
+
 const char *glfer_hip_strerror(int code);
 /* text of the last HIP error seen by this thread ("" if none) */
 const char *glfer_hip_last_hip_error(void);

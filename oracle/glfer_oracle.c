@@ -809,6 +809,120 @@ void go_spectrogram_hparma(const float *stream, size_t nsamples, int n, float ov
 }
 
 /* ------------------------------------------------------------------ */
+/* g_main.c:651-762 set_palette.  The reference casts doubles (some negative or > 255) straight
+ * to unsigned char; on x86-64 that is a truncating double->int32 conversion whose low byte is
+ * kept, which is what (unsigned char)(int) spells out. */
+#define PAL(v) ((unsigned char)(int)(v))
+void go_palette(int p_n, unsigned char tab[768])
+{
+  unsigned char *p = tab;
+  for (long c = 0; c < 256; c++) {
+    long color = c * 256 / 256;
+    switch (p_n) {
+    case 0: case 1:                                   /* HSV, thresholded HSV */
+      if (p_n == 1 && color < 16) { *p++ = 0; *p++ = 0; *p++ = 0; }
+      else if (color < 64) { *p++ = 0; *p++ = PAL(color * 4.0); *p++ = 255; }
+      else if (color < 128) { *p++ = 0; *p++ = 255; *p++ = PAL(510.0 - color * 4.0); }
+      else if (color < 192) { *p++ = PAL(color * 4.0 - 510.0); *p++ = 255; *p++ = 0; }
+      else { *p++ = 255; *p++ = PAL(1020.0 - color * 4.0); *p++ = 0; }
+      break;
+    case 2:                                           /* cool */
+      *p++ = (unsigned char)color; *p++ = (unsigned char)(255 - color); *p++ = 255;
+      break;
+    case 3:                                           /* hot */
+      if (color < 96) { *p++ = PAL(color * 2.66667 + 0.5); *p++ = 0; *p++ = 0; }
+      else if (color < 192) { *p++ = 255; *p++ = PAL(color * 2.66667 - 254); *p++ = 0; }
+      else { *p++ = 255; *p++ = 255; *p++ = PAL(color * 4.0 - 766.0); }
+      break;
+    case 5:                                           /* bone */
+      if (color < 96) { *p++ = PAL(color * 0.88889); *p++ = PAL(color * 0.88889); *p++ = PAL(color * 1.20000); }
+      else if (color < 192) { *p++ = PAL(color * 0.88889); *p++ = PAL(color * 1.20000 - 29); *p++ = PAL(color * 0.88889 + 29); }
+      else { *p++ = PAL(color * 1.20000 - 60); *p++ = PAL(color * 0.88889 + 29); *p++ = PAL(color * 0.88889 + 29); }
+      break;
+    case 6:                                           /* copper */
+      if (color < 208) { *p++ = PAL(color * 1.23); *p++ = PAL(color * 0.78); *p++ = PAL(color * 0.5); }
+      else { *p++ = 255; *p++ = PAL(color * 0.78); *p++ = PAL(color * 0.5); }
+      break;
+    case 7:                                           /* OTD */
+      if (color < 128) { *p++ = 0; *p++ = PAL(2.0 * color - 1.0); *p++ = PAL(2.0 * (127.0 - color) + 1.0); }
+      else { *p++ = PAL(2.0 * (color - 127.0) - 1.0); *p++ = PAL(2.0 * (255.0 - color) + 1.0); *p++ = 0; }
+      break;
+    default:                                          /* BW (4) and anything else */
+      *p++ = (unsigned char)color; *p++ = (unsigned char)color; *p++ = (unsigned char)color;
+    }
+  }
+}
+
+/* double -> short / unsigned char the way the reference's implicit conversions behave on x86-64:
+ * truncating conversion to int32 (out of range or NaN gives INT_MIN), low bits kept */
+static int x86_d2i(double d)
+{
+  if (!(d > -2147483649.0 && d < 2147483648.0))
+    return (int)0x80000000u;
+  return (int)d;
+}
+
+/* g_main.c:1109-1139 + 1186-1236 */
+void go_display_column(go_display_state *st, const float *src_f, const double *src_d, int n,
+                       float sig_pwr, float floor_pwr, const unsigned char colortab[768],
+                       unsigned char *rgb, short *lev, float levels_out[2])
+{
+  const float thr_level = st->thr_level / 100.0;                       /* g_main.c:1099 */
+  float display_max, display_min;
+  if (st->autoscale) {                                                 /* g_main.c:1111-1124 */
+    if (st->first_buffer) {
+      if (st->overlap > 0.0) {
+        sig_pwr /= st->overlap;
+        floor_pwr /= st->overlap;
+      }
+      st->display_max_lvl = sig_pwr;
+      st->display_min_lvl = floor_pwr;
+      st->first_buffer = 0;
+    } else {
+      st->display_max_lvl = (1.0 - 0.99) * sig_pwr + 0.99 * st->display_max_lvl;
+      st->display_min_lvl = (1.0 - 0.99) * floor_pwr + 0.99 * st->display_min_lvl;
+    }
+  } else {                                                             /* g_main.c:1125-1130 */
+    st->display_max_lvl = pow(10.0, st->max_level_db / 10.0);
+    st->display_min_lvl = pow(10.0, st->min_level_db / 10.0);
+    st->display_min_lvl = (st->display_max_lvl > st->display_min_lvl ? st->display_min_lvl : st->display_max_lvl / 10.0);
+  }
+  if (st->scale_log) {                                                 /* g_main.c:1132-1139 */
+    display_max = 10.0 * log10(st->display_max_lvl);
+    display_min = 10.0 * log10(st->display_min_lvl);
+  } else {
+    display_max = st->display_max_lvl;
+    display_min = st->display_min_lvl;
+  }
+  levels_out[0] = display_max;
+  levels_out[1] = display_min;
+
+  for (int i = 0; i < n; i++) {                                        /* g_main.c:1186-1236 */
+    float sig_level;
+    if (st->scale_log) {
+      /* sig_level = levbuf[..] = 10.0*log10(x): the value of the assignment is the SHORT */
+      const double db = src_d ? 10.0 * log10(src_d[n - i - 1]) : 10.0 * log10(src_f[n - i - 1]);
+      lev[i] = (short)x86_d2i(db);
+      sig_level = lev[i];
+    } else {
+      sig_level = src_d ? src_d[n - i - 1] : src_f[n - i - 1];
+      lev[i] = (short)x86_d2i(10.0 * log10(sig_level));
+    }
+    const float f = 255 * ((sig_level - display_min) / (display_max - display_min));
+    unsigned char v;
+    if (f < 255.0 * thr_level)
+      v = 0;
+    else if (f > 255)
+      v = 255;
+    else
+      v = (unsigned char)x86_d2i((f - 255.0 * thr_level) / (1.0 - thr_level));
+    rgb[3 * i] = colortab[3 * v];
+    rgb[3 * i + 1] = colortab[3 * v + 1];
+    rgb[3 * i + 2] = colortab[3 * v + 2];
+  }
+}
+
+/* ------------------------------------------------------------------ */
 /* wav_fmt.c:104-117 */
 void go_pcm_u8_to_float(const unsigned char *in, size_t n, float *out)
 {

@@ -125,6 +125,28 @@ void go_hparma_frame(go_fft_state *st, int t, int p_e, float *hop, int first_buf
 void go_spectrogram_hparma(const float *stream, size_t nsamples, int n, float overlap, int t,
                            int p_e, int sub_mean, int history_mode, float *psd_out);
 
+/* ---- display mapping (g_main.c:1099-1236, palettes g_main.c:651-762) ---- */
+/* set_palette(): 256 RGB triplets; p_n as glfer.h:49 {HSV,THRESH,COOL,HOT,BW,BONE,COPPER,OTD} */
+void go_palette(int p_n, unsigned char colortab[768]);
+
+typedef struct {
+  int scale_log;        /* opt.scale_type is SCALE_LOG or SCALE_LOG_MAX0 (g_main.c:1132) */
+  int autoscale;        /* opt.autoscale                                                    */
+  float overlap;        /* opt.data_blocks_overlap (first-buffer correction, g_main.c:1114) */
+  float max_level_db, min_level_db;   /* fixed levels when autoscale is off (g_main.c:1126) */
+  float thr_level;      /* opt.thr_level, percent                                           */
+  int first_buffer;     /* glfer.first_buffer: in/out                                       */
+  float display_max_lvl, display_min_lvl;   /* the two statics of main_window_draw: in/out  */
+} go_display_state;
+
+/* One waterfall column (g_main.c:1109-1139 level tracking, g_main.c:1186-1236 mapping).
+ * src_f (float PSD) or src_d (avgdata.avg, when averaging is on) holds n values; sig/floor are
+ * compute_floor's outputs for this column.  rgb: n*3 bytes, row i = bin n-1-i; lev: n shorts
+ * (levbuf); levels_out: the display_max/display_min actually used (after the log, if any). */
+void go_display_column(go_display_state *st, const float *src_f, const double *src_d, int n,
+                       float sig_pwr, float floor_pwr, const unsigned char colortab[768],
+                       unsigned char *rgb, short *lev, float levels_out[2]);
+
 /* wav_fmt.c:104-117 sample conversion rules. */
 void go_pcm_u8_to_float(const unsigned char *in, size_t n, float *out);
 void go_pcm_s16_to_float(const short *in, size_t n, float *out);

@@ -193,6 +193,52 @@ def svd(A):
     return rc, A, S, Q
 
 
+PALETTES = {"hsv": 0, "thresh": 1, "cool": 2, "hot": 3, "bw": 4, "bone": 5, "copper": 6, "otd": 7}
+
+
+class _GoDisplayState(C.Structure):
+    _fields_ = [("scale_log", C.c_int), ("autoscale", C.c_int), ("overlap", C.c_float),
+                ("max_level_db", C.c_float), ("min_level_db", C.c_float), ("thr_level", C.c_float),
+                ("first_buffer", C.c_int), ("display_max_lvl", C.c_float),
+                ("display_min_lvl", C.c_float)]
+
+
+def palette(p_n):
+    """g_main.c:651-762 set_palette -> uint8 [256][3]."""
+    tab = np.zeros(768, np.uint8)
+    _lib.go_palette.argtypes = [C.c_int, np.ctypeslib.ndpointer(np.uint8)]
+    _lib.go_palette(int(p_n), tab)
+    return tab.reshape(256, 3)
+
+
+def display(psd, stats, palette_id=0, scale_log=True, autoscale=True, overlap=0.0,
+            max_level_db=-10.0, min_level_db=-60.0, thr_level=0.0, first_buffer=True,
+            state=(0.0, 0.0)):
+    """The waterfall loop of g_main.c:1099-1236 over rows of `psd` (float32 PSD, or float64 for
+    the averaged spectrum) with compute_floor outputs `stats` [frames][>=2] = (sig, floor, ..).
+    Returns rgb uint8 [frames][bins][3], lev int16 [frames][bins], levels float32 [frames][2]
+    and the final (first_buffer, display_max_lvl, display_min_lvl)."""
+    psd = np.ascontiguousarray(psd)
+    frames, n = psd.shape
+    tab = np.ascontiguousarray(palette(palette_id).reshape(-1))
+    st = _GoDisplayState(int(scale_log), int(autoscale), overlap, max_level_db, min_level_db,
+                         thr_level, int(first_buffer), state[0], state[1])
+    rgb = np.zeros((frames, n, 3), np.uint8)
+    lev = np.zeros((frames, n), np.int16)
+    levels = np.zeros((frames, 2), np.float32)
+    _lib.go_display_column.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    is_d = psd.dtype == np.float64
+    if not is_d:
+        psd = psd.astype(np.float32, copy=False)
+    for f in range(frames):
+        row = psd[f].ctypes.data
+        _lib.go_display_column(C.byref(st), None if is_d else row, row if is_d else None, n,
+                               float(stats[f][0]), float(stats[f][1]), tab.ctypes.data,
+                               rgb[f].ctypes.data, lev[f].ctypes.data, levels[f].ctypes.data)
+    return rgb, lev, levels, (st.first_buffer, st.display_max_lvl, st.display_min_lvl)
+
+
 def pcm_u8_to_float(b):
     b = np.ascontiguousarray(b, np.uint8)
     out = np.empty(b.size, np.float32)

@@ -1,0 +1,139 @@
+"""GPU parity tests (-m gpu) of the display mapping (main_window_draw, g_main.c:1099-1236):
+glfer_hip_display_device against the oracle's restatement.
+
+Integer/byte outputs are compared exactly.  The only device arithmetic that is not the same
+IEEE operation as on the CPU is the double-precision log10 (device libm vs glibc, both within
+an ulp of the true value): 10*log10(x) is TRUNCATED to a whole dB (levbuf is short), so a last-
+bit difference can only show when 10*log10(x) lies within an ulp of an integer.  MISMATCH_MAX
+bounds the fraction of such pixels; every other pixel must be identical."""
+import os
+
+import numpy as np
+import pytest
+
+from _signals import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+MISMATCH_MAX = 1e-4
+
+CASES = {"log_auto_hsv": dict(palette=0, scale_type=2, autoscale=1, overlap=0.5),
+         "lin_fixed_thresh": dict(palette=1, scale_type=0, autoscale=0, max_level_db=-25.0, min_level_db=-70.0,
+                                  thr_level=20.0),
+         "log_fixed_bone": dict(palette=5, scale_type=3, autoscale=0, max_level_db=-20.0, min_level_db=-80.0,
+                                thr_level=5.0)}
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _same(got, want, what):
+    bad = np.count_nonzero(got != want)
+    assert bad <= MISMATCH_MAX * want.size, "%s: %d of %d differ" % (what, bad, want.size)
+    return bad
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_display_golden(lib, torch_cuda, case):
+    g = np.load(os.path.join(GOLD, "display_fft1024.npz"))
+    d = lib.Display(**CASES[case])
+    rgb, lev, levels = lib.display(d, torch_cuda.from_numpy(g["psd"]).cuda(),
+                                   torch_cuda.from_numpy(g["stats"]).cuda())
+    levels = levels.cpu().numpy()
+    want_levels = g[case + "_levels"]
+    if CASES[case]["autoscale"]:
+        # the recurrence itself is exact IEEE; the dB conversion of the levels is log10
+        assert np.abs(levels[:, :2] - want_levels).max() <= 4e-6 * np.abs(want_levels).max()
+    else:
+        assert np.array_equal(levels[:, :2], want_levels)
+    exact_levels = np.array_equal(levels[:, :2], want_levels)
+    bad = _same(lev.cpu().numpy(), g[case + "_lev"], "levbuf")
+    if exact_levels and bad == 0:
+        assert np.array_equal(rgb.cpu().numpy(), g[case + "_rgb"])
+    else:
+        _same(rgb.cpu().numpy().reshape(-1, 3).view(np.dtype("V3")), g[case + "_rgb"].reshape(-1, 3).view(np.dtype("V3")), "rgb")
+    assert d.first_buffer == (0 if CASES[case]["autoscale"] else 1)
+    assert (d.display_max_lvl, d.display_min_lvl) == (levels[-1, 2], levels[-1, 3])
+
+
+def test_display_averaged_source(lib, torch_cuda):
+    g = np.load(os.path.join(GOLD, "display_fft1024.npz"))
+    d = lib.Display(palette=7, scale_type=2, autoscale=1, overlap=0.5)
+    rgb, lev, levels = lib.display(d, torch_cuda.from_numpy(g["avg"]).cuda(), torch_cuda.from_numpy(g["stats"]).cuda())
+    _same(lev.cpu().numpy(), g["avg_log_auto_otd_lev"], "levbuf")
+    _same(rgb.cpu().numpy().reshape(-1, 3).view(np.dtype("V3")),
+          g["avg_log_auto_otd_rgb"].reshape(-1, 3).view(np.dtype("V3")), "rgb")
+
+
+def test_linear_scale_pixels_are_exact(lib, oracle, torch_cuda):
+    # linear scale: no log10 between the PSD and the pixel, so every byte must agree
+    rng = np.random.default_rng(11)
+    psd = (rng.random((300, 2049)) ** 8).astype(np.float32)
+    psd[5, :40] = 0.0
+    stats = np.array([oracle.floor_stats(r) for r in psd], np.float32)
+    for autoscale, thr, pal in ((1, 0.0, 3), (0, 35.0, 6), (1, 10.0, 2)):
+        d = lib.Display(palette=pal, scale_type=1, autoscale=autoscale, overlap=0.75, max_level_db=-3.0,
+                        min_level_db=-40.0, thr_level=thr)
+        rgb, lev, levels = lib.display(d, torch_cuda.from_numpy(psd).cuda(), torch_cuda.from_numpy(stats).cuda())
+        w_rgb, w_lev, w_levels, st = oracle.display(psd, stats, palette_id=pal, scale_log=False,
+                                                    autoscale=bool(autoscale), overlap=0.75, max_level_db=-3.0,
+                                                    min_level_db=-40.0, thr_level=thr)
+        assert np.array_equal(levels.cpu().numpy()[:, :2], w_levels)
+        assert np.array_equal(rgb.cpu().numpy(), w_rgb)
+        _same(lev.cpu().numpy(), w_lev, "levbuf")
+        assert (d.first_buffer, d.display_max_lvl, d.display_min_lvl) == st
+
+
+def test_state_carries_across_calls(lib, oracle, torch_cuda):
+    rng = np.random.default_rng(12)
+    psd = (rng.random((257, 513)) ** 4).astype(np.float32)
+    stats = np.array([oracle.floor_stats(r) for r in psd], np.float32)
+    P, S = torch_cuda.from_numpy(psd).cuda(), torch_cuda.from_numpy(stats).cuda()
+    one = lib.Display(scale_type=0, autoscale=1, overlap=0.5)
+    rgb, _, levels = lib.display(one, P, S)
+    two = lib.Display(scale_type=0, autoscale=1, overlap=0.5)
+    parts = [lib.display(two, P[a:b].contiguous(), S[a:b].contiguous()) for a, b in ((0, 1), (1, 130), (130, 257))]
+    assert torch_cuda.equal(torch_cuda.cat([p[0] for p in parts]), rgb)
+    assert torch_cuda.equal(torch_cuda.cat([p[2] for p in parts]), levels)
+    assert (one.first_buffer, one.display_max_lvl, one.display_min_lvl) == \
+           (two.first_buffer, two.display_max_lvl, two.display_min_lvl)
+
+
+def test_special_values(lib, oracle, torch_cuda):
+    # zero, denormal, huge, inf and NaN bins; equal max/min levels (division by zero -> NaN/inf)
+    psd = np.array([[0.0, 1e-45, 1e-20, 1.0, 3e38, np.inf, np.nan, 0.5]], np.float32)
+    stats = np.array([[1.0, 1.0, 1.0, 3.0]], np.float32)          # sig == floor -> display span 0
+    for scale_type, autoscale in ((2, 0), (0, 0), (2, 1), (0, 1)):
+        d = lib.Display(palette=4, scale_type=scale_type, autoscale=autoscale, max_level_db=0.0, min_level_db=-100.0)
+        rgb, lev, _ = lib.display(d, torch_cuda.from_numpy(psd).cuda(), torch_cuda.from_numpy(stats).cuda())
+        w_rgb, w_lev, _, _ = oracle.display(psd, stats, palette_id=4, scale_log=scale_type >= 2,
+                                            autoscale=bool(autoscale), max_level_db=0.0, min_level_db=-100.0)
+        assert np.array_equal(lev.cpu().numpy(), w_lev), (scale_type, autoscale)
+        assert np.array_equal(rgb.cpu().numpy(), w_rgb), (scale_type, autoscale)
+
+
+def test_waterfall_end_to_end(lib, oracle, torch_cuda):
+    # samples -> PSD -> floor -> display, all on the device, against the same chain in the oracle
+    n, ovl = 1024, 0.5
+    x = synth(200 * 512, fs=8000.0, seed=21)
+    sp = lib.Spectrogram(lib.FftParams(n=n, overlap=ovl))
+    psd = sp.run(torch_cuda.from_numpy(x).cuda())
+    stats = lib.compute_floor(psd)
+    d = lib.Display(palette=0, scale_type=2, autoscale=1, overlap=ovl)
+    rgb, lev, _ = lib.display(d, psd, stats)
+    w_psd = oracle.spectrogram_fft(x, n, ovl, 0)
+    w_stats = np.array([oracle.floor_stats(r) for r in w_psd], np.float32)
+    w_rgb, w_lev, _, _ = oracle.display(w_psd, w_stats, palette_id=0, scale_log=True, autoscale=True, overlap=ovl)
+    # the PSDs agree to 1e-5 relative to the PEAK, far-down bins less tightly; a whole-dB cell
+    # changes when such a difference straddles an integer dB.  Bins within 30 dB of the frame's
+    # peak (relative PSD difference < 1e-2 there) must agree in all but ~1e-2/4.3 of the cells.
+    lev, w_lev = lev.cpu().numpy(), w_lev
+    assert np.abs(lev.astype(int) - w_lev).max() <= 1
+    strong = w_psd[:, ::-1] > w_psd.max(axis=1, keepdims=True) * 1e-3
+    assert np.count_nonzero((lev != w_lev) & strong) <= 2.5e-3 * np.count_nonzero(strong)
+    # colour index moves by at most one whole dB's worth: 255/(display span in dB) + rounding
+    assert np.count_nonzero((rgb.cpu().numpy() != w_rgb).any(axis=2) & (lev == w_lev)) <= 1e-3 * lev.size

@@ -105,3 +105,12 @@ def test_wav_header_parse_fixed_width(lib, tmp_path):
     q.write_bytes(bytes(bad) + b"\0" * 64)
     with pytest.raises(lib.GlferHipError, match="bad argument"):
         lib.wav_probe(str(q))
+
+
+def test_palettes_match_reference_tables(lib, oracle):
+    # glfer_hip_palette is a host table builder (set_palette, g_main.c:651-762): no GPU needed
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "display_fft1024.npz"))
+    for name, p_n in lib.PALETTES.items():
+        assert np.array_equal(lib.palette(p_n), g["palettes"][p_n]), name
+        assert np.array_equal(lib.palette(p_n), oracle.palette(p_n)), name
+    assert np.array_equal(lib.palette(-3), lib.palette(lib.PALETTES["bw"]))

@@ -172,6 +172,18 @@ def test_oracle_reproduces_golden(oracle, path):
                     r, avg, peak, var = a.update(mode, psd[f], int(g["minbin"]), int(g["maxbin"]), max0=max0, n=513)
                     assert np.array_equal(avg, g["%s_max%d_avg" % (mode, max0)][f])
                     assert np.array_equal(np.array([r, peak, var]), g["%s_max%d_ret" % (mode, max0)][f], equal_nan=True)
+    elif name.startswith("display_"):
+        cases = {"lin_fixed_thresh": dict(palette_id=1, scale_log=False, autoscale=False, max_level_db=-25.0,
+                                          min_level_db=-70.0, thr_level=20.0),
+                 "log_fixed_bone": dict(palette_id=5, scale_log=True, autoscale=False, max_level_db=-20.0,
+                                        min_level_db=-80.0, thr_level=5.0)}
+        for cname, kw in cases.items():
+            rgb, lev, levels, _ = oracle.display(g["psd"], g["stats"], **kw)
+            assert np.array_equal(rgb, g[cname + "_rgb"]) and np.array_equal(lev, g[cname + "_lev"])
+            assert np.array_equal(levels, g[cname + "_levels"])
+        rgb, lev, levels, _ = oracle.display(g["avg"], g["stats"], palette_id=7, scale_log=True, autoscale=True,
+                                             overlap=0.5)
+        assert np.array_equal(rgb, g["avg_log_auto_otd_rgb"]) and np.array_equal(lev, g["avg_log_auto_otd_lev"])
     elif str(g["mode"]) == "hparma":
         got = oracle.spectrogram_hparma(g["x"], int(g["n"]), float(g["overlap"]), int(g["t"]), int(g["p_e"]))
         assert np.array_equal(got, g["psd"])
@@ -229,3 +241,93 @@ def test_hparma_is_conditioned_at_1e5(oracle):
     a, b = oracle.hparma_frames(x, n, ovl, t, p_e), oracle.hparma_frames(x2, n, ovl, t, p_e)
     errs = [max(rel_err(1.0 / q[0][:n // 2].astype(np.float64), 1.0 / p[0][:n // 2].astype(np.float64))) for p, q in zip(a, b)]
     assert 1e-6 < max(errs) < 1e-4, errs
+
+
+# ---- display mapping (g_main.c:651-762, 1099-1236): g_main.c needs GTK and cannot be built
+# here, so the restatement is pinned by known answers worked out from the reference's formulas.
+
+def test_palette_known_answers(oracle):
+    P = oracle.PALETTES
+    hsv = oracle.palette(P["hsv"])
+    assert hsv[0].tolist() == [0, 0, 255] and hsv[63].tolist() == [0, 252, 255]
+    assert hsv[64].tolist() == [0, 255, 254] and hsv[128].tolist() == [2, 255, 0]
+    assert hsv[192].tolist() == [255, 252, 0] and hsv[255].tolist() == [255, 0, 0]
+    th = oracle.palette(P["thresh"])
+    assert not th[:16].any() and np.array_equal(th[16:], hsv[16:])
+    c = np.arange(256)
+    assert np.array_equal(oracle.palette(P["bw"]), np.stack([c, c, c], 1))
+    assert np.array_equal(oracle.palette(P["cool"]), np.stack([c, 255 - c, np.full(256, 255)], 1))
+    hot = oracle.palette(P["hot"])
+    assert hot[95].tolist() == [253, 0, 0] and hot[96].tolist() == [255, 2, 0] and hot[255].tolist() == [255, 255, 254]
+    # OTD runs below zero at both ends of its ramps: 2*0-1 = -1 -> 255, 2*(128-127)-1 = 1
+    otd = oracle.palette(P["otd"])
+    assert otd[0].tolist() == [0, 255, 255] and otd[1].tolist() == [0, 1, 253]
+    assert otd[128].tolist() == [1, 255, 0] and otd[255].tolist() == [255, 1, 0]
+    # BONE's red passes 255 at c = 263 -> never; copper's red 1.23*207 = 254.61 -> 254, then 255
+    cop = oracle.palette(P["copper"])
+    assert cop[207].tolist() == [254, 161, 103] and cop[208].tolist() == [255, 162, 104]
+    bone = oracle.palette(P["bone"])
+    assert bone[255].tolist() == [246, 255, 255] and bone[96].tolist() == [85, 86, 114]
+    # an unknown id is the reference's final else branch: black and white
+    assert np.array_equal(oracle.palette(42), oracle.palette(P["bw"]))
+
+
+def test_display_linear_fixed_levels_known_answer(oracle):
+    # linear scale, fixed levels 0 dB / -10 dB -> display range [0.1, 1.0]; BW palette = v itself
+    n = 64
+    psd = np.linspace(0.0, 1.2, n, dtype=np.float32)[None, :]
+    stats = np.zeros((1, 4), np.float32)
+    rgb, lev, levels, _ = oracle.display(psd, stats, palette_id=4, scale_log=False, autoscale=False,
+                                         max_level_db=0.0, min_level_db=-10.0)
+    assert levels[0].tolist() == [1.0, np.float32(0.1)]
+    x = psd[0, ::-1].astype(np.float32)                       # pixel i shows bin n-1-i
+    f = np.float32(255) * ((x - np.float32(0.1)) / (np.float32(1.0) - np.float32(0.1)))
+    want = np.where(f < 0, 0, np.where(f > 255, 255, np.trunc(f))).astype(np.uint8)
+    assert np.array_equal(rgb[0, :, 0], want) and np.array_equal(rgb[0, :, 1], want)
+    assert rgb[0, 0, 0] == 255 and rgb[0, -1, 0] == 0
+
+
+def test_display_log_truncates_to_whole_db(oracle):
+    # sig_level takes the value of the SHORT levbuf cell (g_main.c:1195): -37.6 dB shows as -37
+    db = np.array([[-37.6, -0.4, -99.9, -12.5, 3.7]])
+    psd = (10.0 ** (db / 10.0)).astype(np.float32)
+    rgb, lev, levels, _ = oracle.display(psd, np.zeros((1, 4), np.float32), palette_id=4, scale_log=True,
+                                         autoscale=False, max_level_db=0.0, min_level_db=-100.0)
+    assert lev[0].tolist() == [3, -12, -99, 0, -37]            # pixel i shows bin n-1-i, truncated toward 0
+    assert levels[0].tolist() == [0.0, -100.0]
+    want = [255, int(np.float32(255) * np.float32(88 / 100)), int(255 * np.float32(1 / 100)), 255, int(255 * np.float32(63 / 100))]
+    assert rgb[0, :, 0].tolist() == want
+    # a zero bin: log10(0) = -inf -> the x86 conversion gives INT_MIN, whose low 16 bits are 0
+    rgb, lev, _, _ = oracle.display(np.zeros((1, 3), np.float32), np.zeros((1, 4), np.float32), palette_id=4,
+                                    scale_log=True, autoscale=False, max_level_db=0.0, min_level_db=-100.0)
+    assert lev[0].tolist() == [0, 0, 0] and rgb[0, :, 0].tolist() == [255, 255, 255]
+
+
+def test_display_autoscale_recurrence(oracle):
+    rng = np.random.default_rng(3)
+    stats = np.abs(rng.standard_normal((50, 4))).astype(np.float32) + 0.1
+    stats[:, 1] *= 0.01
+    psd = np.abs(rng.standard_normal((50, 17))).astype(np.float32)
+    _, _, levels, st = oracle.display(psd, stats, scale_log=False, autoscale=True, overlap=0.5)
+    mx = np.float32(stats[0, 0] / np.float32(0.5))             # first buffer: /= overlap
+    mn = np.float32(stats[0, 1] / np.float32(0.5))
+    assert levels[0].tolist() == [mx, mn]
+    for f in range(1, 50):
+        mx = np.float32((1.0 - 0.99) * float(stats[f, 0]) + 0.99 * float(mx))
+        mn = np.float32((1.0 - 0.99) * float(stats[f, 1]) + 0.99 * float(mn))
+        assert levels[f].tolist() == [mx, mn]
+    assert st == (0, mx, mn)
+    # state carried across calls == one long call
+    _, _, l1, s1 = oracle.display(psd[:20], stats[:20], scale_log=False, autoscale=True, overlap=0.5)
+    _, _, l2, s2 = oracle.display(psd[20:], stats[20:], scale_log=False, autoscale=True, overlap=0.5,
+                                  first_buffer=bool(s1[0]), state=s1[1:])
+    assert np.array_equal(np.vstack([l1, l2]), levels) and s2 == st
+
+
+def test_display_golden(oracle):
+    g = np.load(os.path.join(GOLD, "display_fft1024.npz"))
+    assert np.array_equal(np.array([oracle.palette(i) for i in range(8)]), g["palettes"])
+    rgb, lev, levels, _ = oracle.display(g["psd"], g["stats"], palette_id=0, scale_log=True, autoscale=True,
+                                         overlap=0.5)
+    assert np.array_equal(rgb, g["log_auto_hsv_rgb"]) and np.array_equal(lev, g["log_auto_hsv_lev"])
+    assert np.array_equal(levels, g["log_auto_hsv_levels"])

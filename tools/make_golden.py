@@ -90,6 +90,23 @@ def main():
             avg_out["%s_max%d_ret" % (mode, max0)] = np.array(rets)
     fl = np.array([O.floor_stats(p) for p in psd], np.float64)
     save("avg_floor_fft1024", psd=psd, depth=4, minbin=25, maxbin=450, floor=fl, **avg_out)
+    # display mapping (g_main.c:1099-1236) of that PSD sequence: the default look (log scale,
+    # autoscale, HSV) and a fixed-level linear THRESH-palette one with a 20 % threshold; plus
+    # the averaged (double) source in log scale and all eight palettes
+    disp = {}
+    cases = {"log_auto_hsv": dict(palette_id=0, scale_log=True, autoscale=True, overlap=0.5),
+             "lin_fixed_thresh": dict(palette_id=1, scale_log=False, autoscale=False, max_level_db=-25.0,
+                                      min_level_db=-70.0, thr_level=20.0),
+             "log_fixed_bone": dict(palette_id=5, scale_log=True, autoscale=False, max_level_db=-20.0,
+                                    min_level_db=-80.0, thr_level=5.0)}
+    for name, kw in cases.items():
+        rgb, lev, levels, _ = O.display(psd[:, :513], fl, **kw)
+        disp[name + "_rgb"], disp[name + "_lev"], disp[name + "_levels"] = rgb, lev, levels
+    rgb, lev, levels, _ = O.display(avg_out["plain_max0_avg"], fl, palette_id=7, scale_log=True, autoscale=True,
+                                    overlap=0.5)
+    disp["avg_log_auto_otd_rgb"], disp["avg_log_auto_otd_lev"], disp["avg_log_auto_otd_levels"] = rgb, lev, levels
+    save("display_fft1024", psd=psd[:, :513], stats=fl.astype(np.float32), avg=avg_out["plain_max0_avg"],
+         palettes=np.array([O.palette(i) for i in range(8)]), **disp)
 
 
 if __name__ == "__main__":
