@@ -166,7 +166,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch, rocprofv3 PMC (profiles/r01_hbm_traffic.json)",
                          "algorithmic_bytes_per_launch": frames * b_alg,
-                         "kernel": "hparma_kernel" if args.workload == "hparma" else "spectro16_kernel<12>", "kernel_ms": kernel_ms,
+                         "kernel": {"hparma": "hparma_kernel", "fft": "spectro16h_kernel<12>"}.get(args.workload, "spectro16_kernel<12>"), "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_frame": b_alg,
                          "note": "MTM is FP32-VALU-bound on this chip (SURVEY 7): see valu_frac"},
             "hbm_gbs_aggregate": fps * b_alg / 1e9,

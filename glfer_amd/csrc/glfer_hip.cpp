@@ -53,6 +53,9 @@ struct glfer_hip_plan {
   std::vector<double> sig;          // [ntapers]
   float *d_taps = nullptr;          // [npairs][8][n/16][4] scaled tables (tap_slot)
   float2 *d_tw = nullptr;           // [64][lanes]
+  float *d_htaps = nullptr;         // real-input form (spectro16h.hip): window pairs, [8][n/32][4]
+  float2 *d_htw = nullptr;          //   twiddles of the n/2-point transform
+  float2 *d_hrot = nullptr;         //   (cos,sin)(2 pi t/n), t < n/32
   uint16_t *d_lagmap = nullptr;     // HP-ARMA: [t][p_e+1] lag held by each matrix cell
   float2 *d_unit = nullptr;         // HP-ARMA: [n/2+1] exp(-2 pi i k/n)
   float *d_scratch = nullptr;       // sub_mean copy of the hops of one call
@@ -234,6 +237,31 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   std::vector<float> tw((size_t)2 * glfer::make_twiddles16(logn, nullptr) * p->lanes);
   glfer::make_twiddles16(logn, tw.data());
 
+  // --- real-input form of the linear periodogram (spectro16h.hip): z[i] = y[2i] + i*y[2i+1],
+  // lane t of n/32 holds points i = t + (n/32)*m; |X|^2/N needs the inputs scaled by sqrt(1/(4N))
+  std::vector<float> htaps, htw, hrot;
+  if (cfg->mode == GLFER_MODE_FFT && !p->nonlin && n >= 512) {
+    const int th = n / 32;
+    const double scale = std::sqrt(1.0 / (4.0 * n));
+    const bool rect = (cfg->window_type == GLFER_WIN_RECTANGULAR);
+    htaps.resize((size_t)n);
+    for (int m = 0; m < 16; m++)
+      for (int t = 0; t < th; t++)
+        for (int e = 0; e < 2; e++) {
+          const int i = 2 * (t + th * m) + e;
+          const double w = rect ? 1.0 : (double)p->window[i];
+          htaps[((size_t)(m / 2) * th + t) * 4 + (size_t)(m & 1) * 2 + e] = (float)(w * scale);
+        }
+    htw.resize((size_t)2 * glfer::make_twiddles16(logn - 1, nullptr) * th);
+    glfer::make_twiddles16(logn - 1, htw.data());
+    hrot.resize((size_t)2 * th);
+    for (int t = 0; t < th; t++) {
+      const double ang = 2.0 * 3.14159265358979323846 * t / n;
+      hrot[2 * t] = (float)std::cos(ang);
+      hrot[2 * t + 1] = (float)std::sin(ang);
+    }
+  }
+
   // --- HP-ARMA tables: which lag each cell of the t x (p_e+1) matrix holds after the
   // reference's fill (hparma.c:89-102).  r_xx is matrix(0,t,0,p_e) (hparma.c:64): its rows
   // are contiguous (util.c:153-160), lags 0..t-1 are written into row 0 past its p_e+1
@@ -263,6 +291,14 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_tw, tw.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(p->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !htaps.empty()) {
+    e = hipMalloc((void **)&p->d_htaps, htaps.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_htw, htw.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_hrot, hrot.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->d_htaps, htaps.data(), htaps.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_htw, htw.data(), htw.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_hrot, hrot.data(), hrot.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess && !lagmap.empty()) {
     e = hipMalloc((void **)&p->d_lagmap, lagmap.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_unit, unit.size() * sizeof(float));
@@ -282,6 +318,9 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (!p) return;
   if (p->d_taps) (void)hipFree(p->d_taps);
   if (p->d_tw) (void)hipFree(p->d_tw);
+  if (p->d_htaps) (void)hipFree(p->d_htaps);
+  if (p->d_htw) (void)hipFree(p->d_htw);
+  if (p->d_hrot) (void)hipFree(p->d_hrot);
   if (p->d_scratch) (void)hipFree(p->d_scratch);
   if (p->d_lagmap) (void)hipFree(p->d_lagmap);
   if (p->d_unit) (void)hipFree(p->d_unit);
@@ -320,6 +359,16 @@ int glfer_hip_make_dpss(int n, int kmax, double nw, double *tapers, double *sig)
 }
 
 static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
+  if (sp.htaps && !sp.spec && !sp.nonlin) {        // single taper, PSD only: the real-input form
+    switch (n) {
+      case 512: return glfer_launch_spectro16h_n9(&sp, st);
+      case 1024: return glfer_launch_spectro16h_n10(&sp, st);
+      case 2048: return glfer_launch_spectro16h_n11(&sp, st);
+      case 4096: return glfer_launch_spectro16h_n12(&sp, st);
+      case 8192: return glfer_launch_spectro16h_n13(&sp, st);
+      case 16384: return glfer_launch_spectro16h_n14(&sp, st);
+    }
+  }
   switch (n) {
     case 256: return glfer_launch_spectro16_n8(&sp, st);
     case 512: return glfer_launch_spectro16_n9(&sp, st);
@@ -359,6 +408,9 @@ static int run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, 
   sp.spec_unscale = p->spec_unscale;
   sp.taps = p->d_taps;
   sp.tw = p->d_tw;
+  sp.htaps = p->d_htaps;
+  sp.htw = p->d_htw;
+  sp.hrot = p->d_hrot;
   sp.psd = d_psd;
   sp.spec = d_spec;
 

@@ -21,8 +21,7 @@
 // No MFMA: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "fft_inreg.hpp"
-#include "spectro_params.h"
+#include "stockham16.hpp"
 
 #ifndef GLFER16_LAYOUT
 #define GLFER16_LAYOUT 0      /* 0: +1-per-16 padded exchange; 1: row/natural layouts */
@@ -35,77 +34,6 @@
 #endif
 
 namespace glfer {
-
-typedef float v2f32 __attribute__((ext_vector_type(2)));
-
-// Radix schedule for N = 2^LOGN with 16 points per lane.
-template <int LOGN>
-struct Plan16 {
-  static constexpr int N = 1 << LOGN;
-  static constexpr int T = N / 16;                                   // lanes per frame
-  static constexpr int NPASS = LOGN <= 8 ? 2 : (LOGN <= 12 ? 3 : 4);
-  static constexpr int radix(int i) {
-    if (i < 2) return 16;
-    if (NPASS == 3) return N / 256;
-    return i == 2 ? 16 : N / 4096;
-  }
-  static constexpr int ls(int i) {                                    // product of earlier radices
-    int l = 1;
-    for (int j = 0; j < i; j++) l *= radix(j);
-    return l;
-  }
-  static constexpr int tw_offset(int i) {                             // first twiddle slot of pass i
-    int o = 0;
-    for (int j = 1; j < i; j++) o += (16 / radix(j)) * (radix(j) - 1);
-    return o;
-  }
-  static constexpr int NTW = tw_offset(NPASS);                        // twiddles per lane
-};
-
-
-// sample formats: wav_fmt.c:104-117
-template <int FMT>
-__device__ __forceinline__ float cvt_sample(const void *ubase, unsigned elem_off) {
-  if constexpr (FMT == GLFER_FMT_F32) {
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + (size_t)(elem_off * 4u));
-  } else if constexpr (FMT == GLFER_FMT_S16) {
-    return (float)*reinterpret_cast<const short *>(reinterpret_cast<const char *>(ubase) + (size_t)(elem_off * 2u)) / 32768.0f;
-  } else {
-    return ((float)*(reinterpret_cast<const unsigned char *>(ubase) + (size_t)elem_off) - 128.0f) / 128.0f;
-  }
-}
-
-// Range-checked buffer load of one sample (raw buffer: out-of-range offsets read 0): one shared
-// VGPR byte offset + an SGPR/immediate offset, so gathering a frame costs no address VALU.
-template <int FMT>
-__device__ __forceinline__ float buf_sample(__amdgpu_buffer_rsrc_t rsrc, unsigned voff_bytes, unsigned soff_bytes) {
-  if constexpr (FMT == GLFER_FMT_F32) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, soff_bytes, 0));
-  } else if constexpr (FMT == GLFER_FMT_S16) {
-    return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff_bytes, soff_bytes, 0) / 32768.0f;
-  } else {
-    return ((float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsrc, voff_bytes, soff_bytes, 0) - 128.0f) / 128.0f;
-  }
-}
-
-template <int T>
-__device__ __forceinline__ void frame_sync() {
-  if constexpr (T > 64) {
-    __syncthreads();
-  } else {                       // the frame lives in one wave: LDS ops of a wave are in order
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-template <int LOGN>
-struct Launch16 {
-  static constexpr int T = Plan16<LOGN>::T;
-  static constexpr int FPB = T >= 256 ? 1 : 256 / T;          // frames per block
-  static constexpr int BLOCK = T * FPB;
-  static constexpr int PADN = Plan16<LOGN>::N + Plan16<LOGN>::N / 16;   // covers both exchange layouts
-  static constexpr int LDS_WORDS = FPB * PADN + 16 * 17;       // + pass-1 twiddle table [16][17] (padded rows)
-};
 
 // One kernel, persistent blocks.  The work of a block is a flat sequence of ROUNDS
 // (frame group, taper pair); the 48 loads of round r+1 (16 samples, 2x16 taper values per

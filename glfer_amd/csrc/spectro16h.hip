@@ -1,0 +1,246 @@
+// spectro16h.hip -- single-taper frames (the periodogram of fft_do/fft_psd, fft.c:190-226) as a
+// REAL-input transform: the windowed frame y[0..N) is packed as z[n] = y[2n] + i*y[2n+1], one
+// complex M = N/2 point Stockham FFT is run (stockham16.hpp, 16 points per lane, N/32 lanes per
+// frame), and the N-point spectrum is recovered bin pair by bin pair,
+//     E = Z[k] + conj(Z[M-k]),  O = Z[k] - conj(Z[M-k]),  P = -i * W_N^k * O,
+//     X[k] = (E + P)/2,  X[M-k] = conj(E - P)/2,
+// so |X[k]|^2 and |X[M-k]|^2 come from one E/P pair.  Against spectro16.hip's packed form (which
+// spends a whole N-point complex transform on one real frame when there is no second taper to
+// put in the imaginary part) this is half the butterflies and half the LDS exchange traffic.
+// The 1/N of fft.c:212-216 and the two halvings above are folded into the window: w*sqrt(1/(4N)).
+//
+// Layout: frames per block = 256/(N/32) (N=4096: two frames, two wavefronts each).  The window
+// is the same for every frame and stays in 32 VGPRs for the whole launch; the next frame's samples
+// are fetched (8-byte loads: y[2n], y[2n+1] are adjacent) right after pass 0 has handed its data
+// to LDS.  Mirror step: only the upper half of Z (k >= M/2) goes through LDS, lane t keeps its
+// own Z[k], k < M/2, in registers; the post twiddle W_N^(t + T*m) is the lane's W_N^t (two VGPRs)
+// times the compile-time constant W_32^m.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "stockham16.hpp"
+
+// Build variant per block size, chosen so that nothing spills (tools/hbench, -Rpass-analysis):
+// window in LDS up to N = 4096 (165 VGPRs, 3 waves/SIMD, 53 KB LDS per block); re-read per frame
+// above that, where the LDS copy would cost a resident block (N = 16384: 2 waves/SIMD, 194 VGPRs).
+#ifndef GLFER16H_WAVES_PER_SIMD
+#define GLFER16H_WAVES_PER_SIMD (GLFER_LOGN_OR(12) == 14 ? 2 : 3)
+#endif
+#ifndef GLFER16H_VAR
+#define GLFER16H_VAR (GLFER_LOGN_OR(12) <= 12 ? 2 : 1)
+#endif
+#ifdef GLFER_LOGN
+#define GLFER_LOGN_OR(d) GLFER_LOGN
+#else
+#define GLFER_LOGN_OR(d) d
+#endif
+
+namespace glfer {
+
+template <int LOGN>
+struct LaunchH {
+  using C = Plan16<LOGN - 1>;
+  static constexpr int M = C::N, TH = C::T;
+  static constexpr int FPB = TH >= 256 ? 1 : 256 / TH;
+  static constexpr int BLOCK = TH * FPB;
+  static constexpr int PADM = M + M / 16;
+  static constexpr int LDS_WORDS = FPB * PADM + 16 * 17;
+};
+
+// VAR (where the window lives): 0 = 32 VGPRs for the whole launch, 1 = re-read from the table
+// at the top of every frame, 2 = in LDS ([16][T] pairs, shared by the block's frames)
+template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR>
+__global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(SpectroParams p) {
+  using L = LaunchH<LOGN>;
+  using C = typename L::C;
+  constexpr int N = 1 << LOGN, M = L::M, T = L::TH, FPB = L::FPB, PADM = L::PADM, NPASS = C::NPASS;
+  constexpr int TW1 = 15;
+  constexpr int NTWR = C::NTW - TW1;
+  constexpr int NT = NTWR > 0 ? NTWR : 1;
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  __shared__ v2f32 lds[L::LDS_WORDS + (VAR == 2 ? M : 0)];
+
+  const unsigned tid = threadIdx.x;
+  const unsigned t = tid % T;
+  const unsigned fl = tid / T;
+  v2f32 *xb = lds + fl * PADM;
+  v2f32 *tw1 = lds + FPB * PADM;
+
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.htw);
+    if (tid < 256) {
+      const unsigned k = tid >> 4, q = tid & 15;
+      tw1[k * 17 + q] = q ? tw[(q - 1) * T + k] : v2f32{1.0f, 0.0f};
+    }
+  }
+  float twr[NT], twi[NT];
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.htw) + t;
+#pragma unroll
+    for (int e = 0; e < NTWR; e++) {
+      const v2f32 w = tw[(TW1 + e) * T];
+      twr[e] = w.x;
+      twi[e] = w.y;
+    }
+    if constexpr (NTWR == 0) twr[0] = twi[0] = 0.0f;
+  }
+  const v2f32 rot = reinterpret_cast<const v2f32 *>(p.hrot)[t];        // (cos, sin)(2 pi t / N)
+  // the window, in the lane's point order: wn[m] = (w[2n], w[2n+1]), n = t + T*m
+  v2f32 wn[16];
+  typedef float v4f32 __attribute__((ext_vector_type(4)));
+  auto load_window = [&] {
+    const v4f32 *ht = reinterpret_cast<const v4f32 *>(p.htaps) + t;
+#pragma unroll
+    for (int mh = 0; mh < 8; mh++) {
+      const v4f32 q = ht[T * mh];
+      wn[2 * mh] = v2f32{q.x, q.y};
+      wn[2 * mh + 1] = v2f32{q.z, q.w};
+    }
+  };
+  v2f32 *wl = lds + L::LDS_WORDS;                 // VAR 2: wl[m*T + t]
+  if constexpr (VAR == 0) load_window();
+  if constexpr (VAR == 2) {
+    if (fl == 0) {
+      load_window();
+#pragma unroll
+      for (int m = 0; m < 16; m++) wl[m * T + t] = wn[m];
+    }
+  }
+  __syncthreads();
+  const v2f32 *tw1row = tw1 + (t & 15) * 17;
+  const long long stride = (long long)gridDim.x * FPB;
+
+  v2f32 px[16];
+  auto prefetch_x = [&](long long fblk) {
+    // as spectro16.hip: descriptor based at the first sample of the block's first frame (or
+    // at the stream start), samples before the stream read 0 through the range check
+    const long long f = fblk + fl;
+    const unsigned flc = f < p.nframes ? fl : (unsigned)(p.nframes - 1 - fblk);
+    const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
+    const long long sbase = sblk > 0 ? sblk : 0;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sbase * (long long)esz, 0, 0x7fffffff, 0x00020000);
+    const int lrel = (int)(sblk - sbase) + (int)(flc * (unsigned)p.H + 2u * t);
+    if (sblk >= 0 && p.history_mode == 0) {
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (FMT == GLFER_FMT_F32) {
+          px[m] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (unsigned)lrel * 4u, (unsigned)(2 * T * m) * 4u, 0));
+        } else {
+          px[m].x = buf_sample<FMT>(xrsrc, (unsigned)lrel * esz, (unsigned)(2 * T * m) * esz);
+          px[m].y = buf_sample<FMT>(xrsrc, (unsigned)lrel * esz, (unsigned)(2 * T * m + 1) * esz);
+        }
+      });
+    } else {
+      static_for<0, 32>([&](auto ec) {
+        constexpr int m = decltype(ec)::value / 2, e = decltype(ec)::value % 2;
+        const int j = 2 * (T * m + (int)t) + e;
+        const int rel = lrel + 2 * T * m + e;
+        const bool ok = p.history_mode ? (j >= p.R) : (rel >= 0);
+        const float x = buf_sample<FMT>(xrsrc, ok ? (unsigned)rel * esz : 0x80000000u, 0u);
+        if constexpr (e == 0) px[m].x = ok ? x : 0.0f;
+        else px[m].y = ok ? x : 0.0f;
+      });
+    }
+  };
+
+  long long fblk = (long long)blockIdx.x * FPB;
+  if (fblk >= p.nframes) return;
+  prefetch_x(fblk);
+
+  constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
+  // register holding bin t + T*m after the last pass
+  auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };
+
+  while (true) {
+    float zr[16], zi[16];
+    if constexpr (VAR == 1) load_window();
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      const v2f32 w = VAR == 2 ? wl[m * T + t] : wn[m];
+      zr[m] = px[m].x * w.x;
+      zi[m] = px[m].y * w.y;
+    }
+    const long long nfblk = fblk + stride;
+    const bool has_next = nfblk < p.nframes;
+
+    stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
+      if (has_next) prefetch_x(nfblk);
+    });
+
+    // ---- mirror step: Z[k], k >= M/2, through LDS (entry u = k - M/2)
+    frame_sync<T>();
+    static_for<8, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int r = rho_of(m);
+      xb[t + T * (m - 8)] = v2f32{zr[r], zi[r]};
+    });
+    frame_sync<T>();
+    const long long f = fblk + fl;
+    if (f < p.nframes) {
+      float *o = p.psd + (size_t)f * (N / 2 + 1);
+      static_for<0, 8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int r = rho_of(m);
+        const int k = (int)t + T * m;
+        v2f32 b = xb[M / 2 - k];                       // Z[M-k]; entry M/2 (t = 0, m = 0) is never written
+        const float ar = zr[r], ai = zi[r];
+        if constexpr (m == 0) {
+          if (t == 0) b = v2f32{ar, ai};               // k = 0 pairs with itself: bins 0 and N/2
+        }
+        const float er = ar + b.x, ei = ai - b.y, orr = ar - b.x, oi = ai + b.y;
+        constexpr cplx64 u = unit_root(m, 32);         // W_N^(T*m) = exp(-i 2 pi m/32) = (u.c, -u.s)
+        constexpr float cm = (float)u.c, sm = (float)u.s;
+        const float c = m == 0 ? rot.x : __builtin_fmaf(rot.x, cm, -rot.y * sm);
+        const float s = m == 0 ? rot.y : __builtin_fmaf(rot.y, cm, rot.x * sm);
+        // P = -i * (c - i s) * O = (-s*Or + c*Oi) + i(-s*Oi - c*Or)
+        const float pr = __builtin_fmaf(c, oi, -s * orr);
+        const float pi = -__builtin_fmaf(c, orr, s * oi);
+        const float x1r = er + pr, x1i = ei + pi, x2r = er - pr, x2i = ei - pi;
+        o[k] = __builtin_fmaf(x1r, x1r, x1i * x1i);
+        o[M - k] = __builtin_fmaf(x2r, x2r, x2i * x2i);
+      });
+      if (t == 0) {                                    // k = M/2 pairs with itself: X = conj(Z)
+        constexpr int r = rho_of(8);
+        o[M / 2] = 4.0f * __builtin_fmaf(zr[r], zr[r], zi[r] * zi[r]);
+      }
+    }
+    if (!has_next) break;
+    fblk = nfblk;
+  }
+}
+
+}  // namespace glfer
+
+#ifndef GLFER_NO_LAUNCHERS
+using namespace glfer;
+
+#ifndef GLFER_LOGN
+#error "compile with -DGLFER_LOGN=<log2 of the block size>"
+#endif
+#define GLFER_CAT2(a, b) a##b
+#define GLFER_CAT(a, b) GLFER_CAT2(a, b)
+
+template <int FMT>
+static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
+  constexpr int L = GLFER_LOGN;
+  using LC = LaunchH<L>;
+  const long long work = ((long long)p.nframes + LC::FPB - 1) / LC::FPB;
+  if (work == 0) return hipSuccess;
+  const long long per_cu = (GLFER16H_WAVES_PER_SIMD * 256) / LC::BLOCK > 0 ? (GLFER16H_WAVES_PER_SIMD * 256) / LC::BLOCK : 1;
+  const long long resident = 256LL * per_cu;
+  const unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
+  hipLaunchKernelGGL((spectro16h_kernel<L, FMT>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+  return hipGetLastError();
+}
+
+// the real-input form of the single-taper path; needs p->htaps/htw/hrot (glfer_hip.cpp builds them)
+extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16h_n, GLFER_LOGN)(const SpectroParams *p, hipStream_t st) {
+  if (!p->htaps || !p->htw || !p->hrot || p->nonlin || p->spec) return hipErrorInvalidValue;
+  switch (p->fmt) {
+    case GLFER_FMT_F32: return launch16h_fmt<GLFER_FMT_F32>(*p, st);
+    case GLFER_FMT_S16: return launch16h_fmt<GLFER_FMT_S16>(*p, st);
+    case GLFER_FMT_U8: return launch16h_fmt<GLFER_FMT_U8>(*p, st);
+  }
+  return hipErrorInvalidValue;
+}
+#endif  // GLFER_NO_LAUNCHERS

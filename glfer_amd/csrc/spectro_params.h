@@ -22,6 +22,10 @@ struct SpectroParams {
   float spec_unscale;      /* factor folded into taper 0 (undone for the spectrum output)    */
   const float *taps;       /* device: [npairs][N][2] taper pairs interleaved, weights and 1/(2N) folded */
   const float2 *tw;        /* device: [slots][N/16] per-lane inter-pass twiddles (cos,sin)    */
+  /* real-input (N/2-point) form of a single taper, spectro16h.hip; NULL when not built for this plan */
+  const float *htaps;      /* device: [8][N/32][4] window as (w[2n],w[2n+1]) pairs, sqrt(1/(4N)) folded */
+  const float2 *htw;       /* device: [slots][N/32] inter-pass twiddles of the N/2-point transform      */
+  const float2 *hrot;      /* device: [N/32] (cos,sin)(2 pi t/N), the lane part of the post twiddle     */
   float *psd;              /* device: [nframes][N/2+1]                                       */
   float *spec;             /* device, optional: [nframes][N] halfcomplex spectrum            */
 };
@@ -36,6 +40,12 @@ hipError_t glfer_launch_spectro16_n11(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16_n13(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16_n14(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16h_n9(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16h_n10(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16h_n11(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16h_n12(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16h_n13(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16h_n14(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_levels(const float *stats, size_t nframes, int scale_log, int autoscale,
                                int first_buffer, float overlap, float max_lvl0, float min_lvl0,
                                float *levels, hipStream_t st);

@@ -1,0 +1,154 @@
+// stockham16.hpp -- pieces shared by the 16-points-per-lane Stockham kernels (spectro16.hip: the
+// packed-pair N-point form; spectro16h.hip: the real-input N/2-point form): the radix schedule,
+// the range-checked sample gather, the frame barrier and the pass loop with its LDS exchange.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fft_inreg.hpp"
+#include "spectro_params.h"
+
+namespace glfer {
+
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+
+// Radix schedule for N = 2^LOGN with 16 points per lane.
+template <int LOGN>
+struct Plan16 {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int T = N / 16;                                   // lanes per frame
+  static constexpr int NPASS = LOGN <= 8 ? 2 : (LOGN <= 12 ? 3 : 4);
+  static constexpr int radix(int i) {
+    if (i < 2) return 16;
+    if (NPASS == 3) return N / 256;
+    return i == 2 ? 16 : N / 4096;
+  }
+  static constexpr int ls(int i) {                                    // product of earlier radices
+    int l = 1;
+    for (int j = 0; j < i; j++) l *= radix(j);
+    return l;
+  }
+  static constexpr int tw_offset(int i) {                             // first twiddle slot of pass i
+    int o = 0;
+    for (int j = 1; j < i; j++) o += (16 / radix(j)) * (radix(j) - 1);
+    return o;
+  }
+  static constexpr int NTW = tw_offset(NPASS);                        // twiddles per lane
+};
+
+
+// sample formats: wav_fmt.c:104-117
+template <int FMT>
+__device__ __forceinline__ float cvt_sample(const void *ubase, unsigned elem_off) {
+  if constexpr (FMT == GLFER_FMT_F32) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + (size_t)(elem_off * 4u));
+  } else if constexpr (FMT == GLFER_FMT_S16) {
+    return (float)*reinterpret_cast<const short *>(reinterpret_cast<const char *>(ubase) + (size_t)(elem_off * 2u)) / 32768.0f;
+  } else {
+    return ((float)*(reinterpret_cast<const unsigned char *>(ubase) + (size_t)elem_off) - 128.0f) / 128.0f;
+  }
+}
+
+// Range-checked buffer load of one sample (raw buffer: out-of-range offsets read 0): one shared
+// VGPR byte offset + an SGPR/immediate offset, so gathering a frame costs no address VALU.
+template <int FMT>
+__device__ __forceinline__ float buf_sample(__amdgpu_buffer_rsrc_t rsrc, unsigned voff_bytes, unsigned soff_bytes) {
+  if constexpr (FMT == GLFER_FMT_F32) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, soff_bytes, 0));
+  } else if constexpr (FMT == GLFER_FMT_S16) {
+    return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff_bytes, soff_bytes, 0) / 32768.0f;
+  } else {
+    return ((float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsrc, voff_bytes, soff_bytes, 0) - 128.0f) / 128.0f;
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void frame_sync() {
+  if constexpr (T > 64) {
+    __syncthreads();
+  } else {                       // the frame lives in one wave: LDS ops of a wave are in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int LOGN>
+struct Launch16 {
+  static constexpr int T = Plan16<LOGN>::T;
+  static constexpr int FPB = T >= 256 ? 1 : 256 / T;          // frames per block
+  static constexpr int BLOCK = T * FPB;
+  static constexpr int PADN = Plan16<LOGN>::N + Plan16<LOGN>::N / 16;   // covers both exchange layouts
+  static constexpr int LDS_WORDS = FPB * PADN + 16 * 17;       // + pass-1 twiddle table [16][17] (padded rows)
+};
+
+// The Stockham passes of one complex 2^LOGM-point transform held 16 points per lane
+// (lane t of T = 2^LOGM/16: points t + T*m on entry; on exit register b + B*brev(q',R) holds
+// bin t + T*(b + B*q'), R = last radix, B = 16/R).  xb: this frame's exchange buffer
+// (M + M/16 entries), tw1row: the lane's row of the shared pass-1 table, twr/twi: the
+// lane's later-pass twiddles.  after_first_write() runs between the first exchange's writes
+// and its barrier: the place where the next round's global loads are issued.
+template <int LOGM, int NT, class Hook>
+__device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[16], v2f32 *xb, unsigned t,
+                                                  const v2f32 *tw1row, const float (&twr)[NT],
+                                                  const float (&twi)[NT], Hook &&after_first_write) {
+  using C = Plan16<LOGM>;
+  constexpr int T = C::T, NPASS = C::NPASS, TW1 = 15;
+  static_for<0, NPASS>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int R = C::radix(i), Ls = C::ls(i), B = 16 / R;
+    if constexpr (i == 1) {
+      static_for<1, 16>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const v2f32 w = tw1row[q];
+        const float a = zr[q], c = zi[q];
+        zr[q] = __builtin_fmaf(a, w.x, -c * w.y);
+        zi[q] = __builtin_fmaf(a, w.y, c * w.x);
+      });
+    } else if constexpr (i > 1) {
+      static_for<0, B>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        static_for<1, R>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          constexpr int e = C::tw_offset(i) - TW1 + b * (R - 1) + (q - 1);
+          constexpr int m = b + B * q;
+          const float a = zr[m], c = zi[m];
+          zr[m] = __builtin_fmaf(a, twr[e], -c * twi[e]);
+          zi[m] = __builtin_fmaf(a, twi[e], c * twr[e]);
+        });
+      });
+    }
+    static_for<0, B>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      dit<R, B, b, 16>(zr, zi);
+    });
+    if constexpr (i < NPASS - 1) {
+      frame_sync<T>();                     // everyone has finished reading the previous exchange
+      static_for<0, B>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        const int j = (int)t + T * b;
+        const int k = j & (Ls - 1);
+        const int a0 = (j - k) * R + k;
+        v2f32 *wbase = xb + a0 + (a0 >> 4);
+        constexpr int WS = Ls >= 16 ? Ls + Ls / 16 : 1;
+        static_for<0, R>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          constexpr int src = b + B * brev(q, R);
+          wbase[q * WS] = v2f32{zr[src], zi[src]};
+        });
+      });
+      if constexpr (i == 0) {
+        after_first_write();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      frame_sync<T>();
+      const v2f32 *rbase = xb + t + (t >> 4);
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const v2f32 v = rbase[m * (T + T / 16)];
+        zr[m] = v.x;
+        zi[m] = v.y;
+      });
+    }
+  });
+}
+
+}  // namespace glfer

@@ -121,6 +121,40 @@ def test_halfcomplex_spectrum(lib, torch_cuda):
     assert np.abs(spec - exact).max() / np.abs(exact).max() < 1e-6   # table twiddles: closer to exact
 
 
+@pytest.mark.parametrize("n,overlap,fmt", [(512, 0.5, "f32"), (1024, 0.33, "s16"), (4096, 0.75, "f32"),
+                                           (4096, 0.9, "u8"), (8192, 0.5, "f32"), (16384, 0.25, "s16")])
+def test_real_input_kernel_agrees_with_packed_kernel(lib, oracle, torch_cuda, n, overlap, fmt):
+    # The PSD-only periodogram runs the real-input N/2-point kernel (spectro16h.hip); asking for
+    # the spectrum as well runs the packed N-point kernel (spectro16.hip).  Two independent
+    # kernels, same rows -- and both against the oracle.  Odd hops (overlap 0.33) make the
+    # 8-byte sample-pair loads start on odd sample indices.
+    rng = np.random.default_rng(n)
+    frames = 37
+    h = oracle.hop(n, overlap)
+    x = synth(frames * h + 5, seed=n)
+    if fmt == "s16":
+        raw = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16)
+        xf, sf = oracle.pcm_s16_to_float(raw), lib.SAMPLES_S16
+    elif fmt == "u8":
+        raw = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8)
+        xf, sf = oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
+    else:
+        raw, xf, sf = x, x, lib.SAMPLES_F32
+    del rng
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=1, overlap=overlap, sample_format=sf))
+    d = torch_cuda.from_numpy(raw).cuda()
+    half = sp.run(d).cpu().numpy()
+    packed, _ = sp.run(d, spectrum=True)
+    packed = packed.cpu().numpy()
+    want = oracle.spectrogram_fft(xf, n, overlap, 1)
+    assert half.shape == want.shape
+    assert rel_err(half, packed)[0] < 2e-6
+    assert max(rel_err(half, want)) < TOL and max(rel_err(packed, want)) < TOL
+    # per frame too (a quiet frame must not hide behind a loud one)
+    for f in range(frames):
+        assert np.abs(half[f] - want[f]).max() <= TOL * want[f].max()
+
+
 def test_edge_inputs(lib, oracle, torch_cuda):
     torch = torch_cuda
     sp = lib.Spectrogram(lib.FftParams(n=1024, window_type=0, overlap=0.5))
