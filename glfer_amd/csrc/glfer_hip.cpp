@@ -56,6 +56,7 @@ struct glfer_hip_plan {
   float *d_htaps = nullptr;         // real-input form (spectro16h.hip): window pairs, [8][n/32][4]
   float2 *d_htw = nullptr;          //   twiddles of the n/2-point transform
   float2 *d_hrot = nullptr;         //   (cos,sin)(2 pi t/n), t < n/32
+  float *d_xtaps = nullptr;         // odd taper counts (spectro16x.hip): the last taper alone, [4][n/16][4]
   uint16_t *d_lagmap = nullptr;     // HP-ARMA: [t][p_e+1] lag held by each matrix cell
   float2 *d_unit = nullptr;         // HP-ARMA: [n/2+1] exp(-2 pi i k/n)
   float *d_scratch = nullptr;       // sub_mean copy of the hops of one call
@@ -262,6 +263,19 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     }
   }
 
+  // --- odd taper count (spectro16x.hip): the last taper shares a transform with the next frame's;
+  // |Y|^2 = |E|^2/4 there (no mirror-sum doubling), so its scale carries 1/4 instead of 1/2
+  std::vector<float> xtaps;
+  if (cfg->mode == GLFER_MODE_MTM && (p->ntapers & 1) && p->ntapers >= 3) {
+    const int T = n / 16, j = p->ntapers - 1;
+    const double scale = std::sqrt(1.0 / (4.0 * n * (1.0 + p->sig[j])));
+    xtaps.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+      const int t = i % T, m = i / T;
+      xtaps[((size_t)(m / 4) * T + t) * 4 + (size_t)(m & 3)] = (float)(p->tapers[(size_t)j * n + i] * scale);
+    }
+  }
+
   // --- HP-ARMA tables: which lag each cell of the t x (p_e+1) matrix holds after the
   // reference's fill (hparma.c:89-102).  r_xx is matrix(0,t,0,p_e) (hparma.c:64): its rows
   // are contiguous (util.c:153-160), lags 0..t-1 are written into row 0 past its p_e+1
@@ -299,6 +313,10 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     if (e == hipSuccess) e = hipMemcpy(p->d_htw, htw.data(), htw.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_hrot, hrot.data(), hrot.size() * sizeof(float), hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && !xtaps.empty()) {
+    e = hipMalloc((void **)&p->d_xtaps, xtaps.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->d_xtaps, xtaps.data(), xtaps.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess && !lagmap.empty()) {
     e = hipMalloc((void **)&p->d_lagmap, lagmap.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_unit, unit.size() * sizeof(float));
@@ -321,6 +339,7 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (p->d_htaps) (void)hipFree(p->d_htaps);
   if (p->d_htw) (void)hipFree(p->d_htw);
   if (p->d_hrot) (void)hipFree(p->d_hrot);
+  if (p->d_xtaps) (void)hipFree(p->d_xtaps);
   if (p->d_scratch) (void)hipFree(p->d_scratch);
   if (p->d_lagmap) (void)hipFree(p->d_lagmap);
   if (p->d_unit) (void)hipFree(p->d_unit);
@@ -358,17 +377,7 @@ int glfer_hip_make_dpss(int n, int kmax, double nw, double *tapers, double *sig)
   return glfer::make_dpss(n, kmax, nw, tapers, sig) ? GLFER_OK : GLFER_E_NUMERIC;
 }
 
-static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
-  if (sp.htaps && !sp.spec && !sp.nonlin) {        // single taper, PSD only: the real-input form
-    switch (n) {
-      case 512: return glfer_launch_spectro16h_n9(&sp, st);
-      case 1024: return glfer_launch_spectro16h_n10(&sp, st);
-      case 2048: return glfer_launch_spectro16h_n11(&sp, st);
-      case 4096: return glfer_launch_spectro16h_n12(&sp, st);
-      case 8192: return glfer_launch_spectro16h_n13(&sp, st);
-      case 16384: return glfer_launch_spectro16h_n14(&sp, st);
-    }
-  }
+static hipError_t launch_packed(const SpectroParams &sp, int n, hipStream_t st) {
   switch (n) {
     case 256: return glfer_launch_spectro16_n8(&sp, st);
     case 512: return glfer_launch_spectro16_n9(&sp, st);
@@ -379,6 +388,72 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
     case 16384: return glfer_launch_spectro16_n14(&sp, st);
   }
   return hipErrorInvalidValue;
+}
+
+static hipError_t launch_real_input(const SpectroParams &sp, int n, hipStream_t st) {
+  switch (n) {
+    case 512: return glfer_launch_spectro16h_n9(&sp, st);
+    case 1024: return glfer_launch_spectro16h_n10(&sp, st);
+    case 2048: return glfer_launch_spectro16h_n11(&sp, st);
+    case 4096: return glfer_launch_spectro16h_n12(&sp, st);
+    case 8192: return glfer_launch_spectro16h_n13(&sp, st);
+    case 16384: return glfer_launch_spectro16h_n14(&sp, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+static hipError_t launch_shared_odd(const SpectroParams &sp, int n, hipStream_t st) {
+  switch (n) {
+    case 256: return glfer_launch_spectro16x_n8(&sp, st);
+    case 512: return glfer_launch_spectro16x_n9(&sp, st);
+    case 1024: return glfer_launch_spectro16x_n10(&sp, st);
+    case 4096: return glfer_launch_spectro16x_n12(&sp, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// Kernel choice.  spectro16.hip (two tapers packed per N-point transform) does everything; two
+// specialisations take the frames that lie wholly inside the stream when they apply:
+//   * one taper, PSD only      -> spectro16h.hip, real-input N/2-point transform
+//   * odd taper count >= 3     -> spectro16x.hip, last taper shared by two frames
+// The first ceil(R/H) frames of a stream reach back before sample 0 (zero history, fft.c:103-108);
+// they stay with spectro16.hip, which has the range-checked gather for that.
+static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
+  const bool real_input = sp.htaps && sp.npairs == 1 && n >= 512;
+  // built where it fits 3 waves/SIMD without spilling (N = 2048 and N >= 8192 do not: they stay packed)
+  const bool shared_odd = sp.xtaps && sp.npairs >= 2 && (n <= 1024 || n == 4096);
+  if (sp.spec || sp.nonlin || !(real_input || shared_odd)) return launch_packed(sp, n, st);
+  const long long first_inside = ((long long)sp.R + sp.H - 1) / sp.H;          // first frame f with f*H >= R
+  // spectro16x.hip works on groups of G consecutive frames (frame f shares its last transform with
+  // frame f + G/2).  Groups are aligned to GLOBAL frame indices and only whole groups go to it, so a
+  // frame's result does not depend on how the stream was cut into launches, chunks or shards, as
+  // long as the cuts fall on multiples of GLFER_FRAME_ALIGN (shard.py and the WAV reader see to it).
+  const int lanes = n / 16;
+  const long long G = real_input ? 1 : 2 * (lanes >= 256 ? 1 : 256 / lanes);
+  const long long lo = sp.frame0, hi = sp.frame0 + sp.nframes;
+  long long b0 = lo > first_inside ? lo : first_inside;
+  b0 = (b0 + G - 1) / G * G;
+  long long b1 = hi / G * G;
+  if (b0 >= b1) return launch_packed(sp, n, st);
+  auto sub = [&](long long from, long long to) {
+    SpectroParams q = sp;
+    q.frame0 = from;
+    q.nframes = (int)(to - from);
+    q.psd = sp.psd + (size_t)(from - lo) * (size_t)(n / 2 + 1);
+    return q;
+  };
+  if (b0 > lo) {
+    const SpectroParams head = sub(lo, b0);
+    hipError_t e = launch_packed(head, n, st);
+    if (e != hipSuccess) return e;
+  }
+  if (hi > b1) {
+    const SpectroParams tail = sub(b1, hi);
+    hipError_t e = launch_packed(tail, n, st);
+    if (e != hipSuccess) return e;
+  }
+  const SpectroParams body = sub(b0, b1);
+  return real_input ? launch_real_input(body, n, st) : launch_shared_odd(body, n, st);
 }
 
 static int run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first,
@@ -411,6 +486,7 @@ static int run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, 
   sp.htaps = p->d_htaps;
   sp.htw = p->d_htw;
   sp.hrot = p->d_hrot;
+  sp.xtaps = p->d_xtaps;
   sp.psd = d_psd;
   sp.spec = d_spec;
 
@@ -532,6 +608,7 @@ int glfer_hip_spectrogram_wav(glfer_hip_plan *p, const char *path, float *h_psd,
   if (chunk_frames == 0) chunk_frames = 16384;
   if (chunk_frames < 2 * (halo / hop)) chunk_frames = 2 * (halo / hop);     // halo copy must not overlap itself
   if (chunk_frames < 1) chunk_frames = 1;
+  chunk_frames = (chunk_frames + GLFER_FRAME_ALIGN - 1) / GLFER_FRAME_ALIGN * GLFER_FRAME_ALIGN;   // see launch_by_n
   if (chunk_frames > frames) chunk_frames = frames;
   FILE *f = fopen(path, "rb");
   if (!f) return GLFER_E_ARG;

@@ -110,35 +110,32 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   const long long stride = (long long)gridDim.x * FPB;
 
   v2f32 px[16];
+  // The launcher hands this kernel only frames that lie wholly inside the stream
+  // ((frame0+f)*H >= R; the first ceil(R/H) frames of a stream go to spectro16.hip, which has the
+  // zero-history gather), so every load is in range: one shared VGPR offset + immediates.
+  // history_mode 1 zeroes the first R samples of every frame afterwards (fft.c:103-108).
   auto prefetch_x = [&](long long fblk) {
-    // as spectro16.hip: descriptor based at the first sample of the block's first frame (or
-    // at the stream start), samples before the stream read 0 through the range check
     const long long f = fblk + fl;
     const unsigned flc = f < p.nframes ? fl : (unsigned)(p.nframes - 1 - fblk);
     const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
-    const long long sbase = sblk > 0 ? sblk : 0;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sbase * (long long)esz, 0, 0x7fffffff, 0x00020000);
-    const int lrel = (int)(sblk - sbase) + (int)(flc * (unsigned)p.H + 2u * t);
-    if (sblk >= 0 && p.history_mode == 0) {
+        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
+    const unsigned lrel = flc * (unsigned)p.H + 2u * t;
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      if constexpr (FMT == GLFER_FMT_F32) {
+        px[m] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, lrel * 4u, (unsigned)(2 * T * m) * 4u, 0));
+      } else {
+        px[m].x = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(2 * T * m) * esz);
+        px[m].y = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(2 * T * m + 1) * esz);
+      }
+    });
+    if (p.history_mode) {
+      const int d = 2 * (int)t - p.R;                  // sample j = 2*(t + T*m) + e is kept iff j >= R
       static_for<0, 16>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        if constexpr (FMT == GLFER_FMT_F32) {
-          px[m] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (unsigned)lrel * 4u, (unsigned)(2 * T * m) * 4u, 0));
-        } else {
-          px[m].x = buf_sample<FMT>(xrsrc, (unsigned)lrel * esz, (unsigned)(2 * T * m) * esz);
-          px[m].y = buf_sample<FMT>(xrsrc, (unsigned)lrel * esz, (unsigned)(2 * T * m + 1) * esz);
-        }
-      });
-    } else {
-      static_for<0, 32>([&](auto ec) {
-        constexpr int m = decltype(ec)::value / 2, e = decltype(ec)::value % 2;
-        const int j = 2 * (T * m + (int)t) + e;
-        const int rel = lrel + 2 * T * m + e;
-        const bool ok = p.history_mode ? (j >= p.R) : (rel >= 0);
-        const float x = buf_sample<FMT>(xrsrc, ok ? (unsigned)rel * esz : 0x80000000u, 0u);
-        if constexpr (e == 0) px[m].x = ok ? x : 0.0f;
-        else px[m].y = ok ? x : 0.0f;
+        px[m].x = (d >= -2 * T * m) ? px[m].x : 0.0f;
+        px[m].y = (d + 1 >= -2 * T * m) ? px[m].y : 0.0f;
       });
     }
   };

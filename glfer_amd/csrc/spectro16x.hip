@@ -1,0 +1,324 @@
+// spectro16x.hip -- multitaper frames with an ODD number of tapers (mtm_do with kmax even,
+// mtm.c:189-220: kmax+1 tapers; BASELINE configs 3 and 4 have 5 and 9).
+//
+// spectro16.hip packs tapers 2p, 2p+1 of ONE frame as re/im of a complex N-point transform, so an
+// odd taper count leaves the imaginary half of the last transform empty.  Here the last taper of
+// TWO frames shares one transform: z = sA*(xA*v) + i*sB*(xB*v).  The two real spectra are separated
+// bin pair by bin pair, E = Z[k] + conj(Z[N-k]) = 2*sA*Y_A[k], O = Z[k] - conj(Z[N-k]) = 2i*sB*Y_B[k],
+// through one mirror exchange in LDS, and |E|^2/sA^2, |O|^2/sB^2 are added to the two frames' sums.
+// T tapers cost T/2 transforms per frame instead of ceil(T/2): 2.5 instead of 3 for T = 5.
+//
+// sA, sB are powers of two chosen per frame so that both halves enter the shared transform at the
+// same magnitude (the frame's power summed over the even number of tapers already done, halved
+// exponent).  Without them the rounding error of the louder frame (~1e-7 of ITS peak) would leak
+// into the quieter one; with them each frame sees the error level of a transform of its own data
+// (x2 at most), and a power-of-two factor changes no mantissa bit.
+//
+// Per block iteration: frame group A (NP full rounds, fold -> partial PSD parked in LDS), frame
+// group B (NP full rounds, fold -> partial PSD in 9 VGPRs), one shared round.  The loop nest is
+// explicit (not a round-kind state machine) so that register liveness is what it looks like:
+// acc is dead outside a group's full rounds, psdB outside group B's fold .. the shared round.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "stockham16.hpp"
+
+#ifndef GLFER16X_WAVES_PER_SIMD
+#define GLFER16X_WAVES_PER_SIMD 3
+#endif
+
+namespace glfer {
+
+template <int LOGN>
+struct LaunchX {
+  using C = Plan16<LOGN>;
+  static constexpr int N = C::N, T = C::T;
+  static constexpr int FPB = T >= 256 ? 1 : 256 / T;
+  static constexpr int BLOCK = T * FPB;
+  static constexpr int PADN = N + N / 16;
+  static constexpr int WPF = T >= 64 ? T / 64 : 1;                    // wavefronts per frame
+  static constexpr int PART = N / 2 + 2;                              // floats per parked partial PSD (even)
+  static constexpr int LDS_WORDS = FPB * PADN + 16 * 17 + 2 * FPB * PART / 2 + (FPB * WPF + 1) / 2;
+};
+
+template <int LOGN, int FMT, int WPS = GLFER16X_WAVES_PER_SIMD>
+__global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(SpectroParams p) {
+  using C = Plan16<LOGN>;
+  using L = LaunchX<LOGN>;
+  constexpr int N = C::N, T = C::T, NPASS = C::NPASS, FPB = L::FPB, PADN = L::PADN, WPF = L::WPF;
+  constexpr int TW1 = 15;
+  constexpr int NTWR = C::NTW - TW1;
+  constexpr int NT = NTWR > 0 ? NTWR : 1;
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  typedef float v4f32 __attribute__((ext_vector_type(4)));
+  __shared__ v2f32 lds[L::LDS_WORDS];
+
+  const unsigned tid = threadIdx.x;
+  const unsigned t = tid % T;
+  const unsigned fl = tid / T;
+  v2f32 *xb = lds + fl * PADN;
+  v2f32 *tw1 = lds + FPB * PADN;
+  float *part = reinterpret_cast<float *>(lds + FPB * PADN + 16 * 17) + fl * L::PART;   // folded sums: group A, then (+FPB*PART) group B
+  float *red = reinterpret_cast<float *>(lds + FPB * PADN + 16 * 17 + 2 * FPB * L::PART / 2);
+
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.tw);
+    if (tid < 256) {
+      const unsigned k = tid >> 4, q = tid & 15;
+      tw1[k * 17 + q] = q ? tw[(q - 1) * T + k] : v2f32{1.0f, 0.0f};
+    }
+  }
+  float twr[NT], twi[NT];
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.tw) + t;
+#pragma unroll
+    for (int e = 0; e < NTWR; e++) {
+      const v2f32 w = tw[(TW1 + e) * T];
+      twr[e] = w.x;
+      twi[e] = w.y;
+    }
+    if constexpr (NTWR == 0) twr[0] = twi[0] = 0.0f;
+  }
+  __syncthreads();
+  const v2f32 *tw1row = tw1 + (t & 15) * 17;
+
+  const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.taps), 0, p.npairs * 2 * N * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.xtaps), 0, N * 4, 0x00020000);
+  const unsigned toff = t * 16u;
+  const int NP = p.npairs - 1;                       // full (two-taper) rounds per frame; the last pair is the shared one
+  const long long stride = (long long)gridDim.x * (2 * FPB);
+
+  float px[16];          // samples of the frame group in work (A, then B)
+  v2f32 pt[16];          // next full round: taper pair; shared round: pt[0..7] = the odd taper, pt[8..15] = group A's samples
+  // Loads the 16 samples of frame (fblk + fl) into dst[0..15].  The launcher hands this kernel
+  // only frames that lie wholly inside the stream ((frame0+f)*H >= R; the first ceil(R/H) frames
+  // of a stream go to spectro16.hip, which has the zero-history gather), so every load is in
+  // range: one shared VGPR offset + immediates.  history_mode 1 (fft.c:103-108 with
+  // glfer.first_buffer stuck at TRUE) zeroes the first R samples of every frame afterwards.
+  auto load_x = [&](float (&dst)[16], long long fblk) {
+    const long long f = fblk + fl;
+    const unsigned flc = f < p.nframes ? fl : (unsigned)(p.nframes - 1 - fblk);   // clamp: loads stay in range
+    const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
+    const unsigned lrel = flc * (unsigned)p.H + t;
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      dst[m] = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(T * m) * esz);
+    });
+    if (p.history_mode) {
+      const int d = (int)t - p.R;
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        dst[m] = (d >= -T * m) ? dst[m] : 0.0f;
+      });
+    }
+  };
+  auto prefetch_taps = [&](int pair) {
+    const unsigned tap_p = (unsigned)pair * (N * 8u);
+    static_for<0, 8>([&](auto mc) {
+      constexpr int mh = decltype(mc)::value;
+      const v4f32 q = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(trsrc, toff, tap_p + (unsigned)(T * mh) * 16u, 0));
+      pt[2 * mh] = v2f32{q.x, q.y};
+      pt[2 * mh + 1] = v2f32{q.z, q.w};
+    });
+  };
+  // shared round: the odd taper ([m/4][T][4] floats: values at samples t + T*(4*(m/4) + j)) and a
+  // second copy of group A's samples (px holds group B by then)
+  auto prefetch_shared = [&](long long fblk) {
+    static_for<0, 4>([&](auto mc) {
+      constexpr int mq = decltype(mc)::value;
+      const v4f32 q = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, toff, (unsigned)(T * mq) * 16u, 0));
+      pt[2 * mq] = v2f32{q.x, q.y};
+      pt[2 * mq + 1] = v2f32{q.z, q.w};
+    });
+    float xa[16];
+    load_x(xa, fblk);
+#pragma unroll
+    for (int m = 0; m < 8; m++) pt[8 + m] = v2f32{xa[2 * m], xa[2 * m + 1]};
+  };
+
+  long long fblk = (long long)blockIdx.x * (2 * FPB);
+  if (fblk >= p.nframes) return;
+  load_x(px, fblk);
+  prefetch_taps(0);
+
+  constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
+  auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };   // register of bin t + T*m
+
+  while (true) {                                              // one iteration: frame groups A and B
+    const bool hasB = fblk + FPB < p.nframes;                 // block-uniform
+    const int ngroups = hasB ? 2 : 1;
+    const long long nfblk = fblk + stride;
+    const bool has_next = nfblk < p.nframes;
+    constexpr int kSilent = 0x7fff;
+    int hxA = 0, hxB = 0;          // scale into the shared round = 2^-hx, chosen from the frame's power
+
+    for (int which = 0; which < ngroups; which++) {
+      float acc[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+      for (int pair = 0; pair < NP; pair++) {
+        // ---- full round: re = x*taper(2*pair), im = x*taper(2*pair+1)
+        float zr[16], zi[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          zr[m] = px[m] * pt[m].x;
+          zi[m] = px[m] * pt[m].y;
+        }
+        // the next round's loads go out after the first exchange's writes
+        stockham16_passes<LOGN, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
+          if (pair + 1 < NP) {
+            prefetch_taps(pair + 1);
+          } else if (which + 1 < ngroups) {
+            prefetch_taps(0);
+            load_x(px, fblk + FPB);
+          } else {
+            prefetch_shared(fblk);
+          }
+        });
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          acc[r] = __builtin_fmaf(zr[r], zr[r], __builtin_fmaf(zi[r], zi[r], acc[r]));
+      }
+      // ---- the group's full rounds are done: mirror fold psd[k] = acc[k] + acc[N-k] through
+      // LDS, and the frame's power (sum of acc over the frame) for the shared round's scale
+      float e = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) e += acc[r];
+      constexpr int RW = T < 64 ? T : 64;
+#pragma unroll
+      for (int w = 1; w < RW; w <<= 1) e += __shfl_xor(e, w);
+      float *fold = reinterpret_cast<float *>(xb);
+      frame_sync<T>();
+      static_for<0, 16>([&](auto rc) {
+        constexpr int rho = decltype(rc)::value;
+        constexpr int b = rho % BL, qp = brev(rho / BL, RL);
+        fold[(int)t + T * (b + BL * qp)] = acc[rho];
+      });
+      if constexpr (T >= 64) {
+        if ((t & 63) == 0) red[fl * WPF + (t >> 6)] = e;
+      }
+      frame_sync<T>();
+      if constexpr (T >= 64) {
+        e = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WPF; w++) e += red[fl * WPF + w];
+      }
+      int ex = __builtin_amdgcn_frexp_expf(e);                 // 0 for e = 0, inf, nan
+      ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
+      // a frame whose power is exactly 0 (digital silence) must stay exactly 0, as in the
+      // reference, whatever its partner's rounding leaves in the shared transform: scale 0
+      const int hx = e == 0.0f ? kSilent : ex >> 1;
+      if (which == 0) hxA = hx;
+      else hxB = hx;
+      float *dstp = part + which * (FPB * L::PART);
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int k = T * m + (int)t;
+        dstp[k] = fold[k] + fold[(N - k) & (N - 1)];
+      }
+      if (t == 0) dstp[N / 2] = 2.0f * fold[N / 2];
+    }
+
+    // ---- shared round: re = sA*(xA*v), im = sB*(xB*v), v the odd taper
+    {
+      float zr[16], zi[16];
+      const float sA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxA);
+      const float sB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxB);
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        const float v = (m & 1) ? pt[m / 2].y : pt[m / 2].x;
+        const float xa = (m & 1) ? pt[8 + m / 2].y : pt[8 + m / 2].x;
+        zr[m] = (xa * v) * sA;
+        zi[m] = hasB ? (px[m] * v) * sB : 0.0f;
+      }
+      stockham16_passes<LOGN, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
+        if (has_next) {
+          prefetch_taps(0);
+          load_x(px, nfblk);
+        }
+      });
+      // separate the two spectra through the mirror pairs (k, N-k).  Z[k] for k >= N/2 goes
+      // through LDS (entry k - N/2); the lane keeps its own Z[k], k < N/2.
+      frame_sync<T>();
+      static_for<8, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int r = rho_of(m);
+        xb[t + T * (m - 8)] = v2f32{zr[r], zi[r]};
+      });
+      frame_sync<T>();
+      // rows of the two frame groups through buffer descriptors: one shared VGPR offset plus
+      // SGPR/immediate offsets (no per-store address VGPRs), and rows past the last frame fall
+      // outside num_records, so their stores are dropped by the range check
+      constexpr unsigned ROWB = (N / 2 + 1) * 4u;
+      const long long leftA = p.nframes - fblk, leftB = p.nframes - (fblk + FPB);
+      const unsigned recA = (unsigned)((leftA > FPB ? FPB : leftA) * (long long)ROWB);
+      const unsigned recB = leftB > 0 ? (unsigned)((leftB > FPB ? FPB : leftB) * (long long)ROWB) : 0u;
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)fblk * (N / 2 + 1), 0, recA, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)(fblk + (leftB > 0 ? FPB : 0)) * (N / 2 + 1), 0, recB, 0x00020000);
+      const unsigned voff = fl * ROWB + t * 4u;
+      const float uA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxA);
+      const float uB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxB);
+      const float *partB = part + FPB * L::PART;
+      static_for<0, 8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int r = rho_of(m);
+        const int k = (int)t + T * m;
+        v2f32 b = xb[N / 2 - k];                        // Z[N-k]; entry N/2 (k = 0) is never written
+        const float ar = zr[r], ai = zi[r];
+        if constexpr (m == 0) {
+          if (t == 0) b = v2f32{ar, ai};                // k = 0 pairs with itself
+        }
+        const float er = ar + b.x, ei = ai - b.y, orr = ar - b.x, oi = ai + b.y;
+        const float pa = __builtin_fmaf(er, er, ei * ei), pb = __builtin_fmaf(orr, orr, oi * oi);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pa, uA, part[k])), ra, voff, (unsigned)(T * m) * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pb, uB, partB[k])), rb, voff, (unsigned)(T * m) * 4u, 0);
+      });
+      if (t == 0) {                                     // k = N/2 pairs with itself: E = 2 Re Z, O = 2i Im Z
+        constexpr int r = rho_of(8);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, part[N / 2])), ra, voff, (unsigned)(N / 2) * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, partB[N / 2])), rb, voff, (unsigned)(N / 2) * 4u, 0);
+      }
+    }
+    if (!has_next) break;
+    fblk = nfblk;
+  }
+}
+
+}  // namespace glfer
+
+#ifndef GLFER_NO_LAUNCHERS
+using namespace glfer;
+
+#ifndef GLFER_LOGN
+#error "compile with -DGLFER_LOGN=<log2 of the block size>"
+#endif
+#define GLFER_CAT2(a, b) a##b
+#define GLFER_CAT(a, b) GLFER_CAT2(a, b)
+
+template <int FMT>
+static hipError_t launch16x_fmt(const SpectroParams &p, hipStream_t st) {
+  constexpr int L = GLFER_LOGN;
+  using LC = LaunchX<L>;
+  const long long work = ((long long)p.nframes + 2 * LC::FPB - 1) / (2 * LC::FPB);
+  if (work == 0) return hipSuccess;
+  const long long per_cu = (GLFER16X_WAVES_PER_SIMD * 256) / LC::BLOCK > 0 ? (GLFER16X_WAVES_PER_SIMD * 256) / LC::BLOCK : 1;
+  const long long resident = 256LL * per_cu;
+  const unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
+  hipLaunchKernelGGL((spectro16x_kernel<L, FMT>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+  return hipGetLastError();
+}
+
+// odd taper counts >= 3; needs p->xtaps (the last taper alone, glfer_hip.cpp builds it)
+extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16x_n, GLFER_LOGN)(const SpectroParams *p, hipStream_t st) {
+  if (!p->xtaps || p->npairs < 2 || p->nonlin || p->spec) return hipErrorInvalidValue;
+  switch (p->fmt) {
+    case GLFER_FMT_F32: return launch16x_fmt<GLFER_FMT_F32>(*p, st);
+    case GLFER_FMT_S16: return launch16x_fmt<GLFER_FMT_S16>(*p, st);
+    case GLFER_FMT_U8: return launch16x_fmt<GLFER_FMT_U8>(*p, st);
+  }
+  return hipErrorInvalidValue;
+}
+#endif  // GLFER_NO_LAUNCHERS

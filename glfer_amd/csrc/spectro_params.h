@@ -26,6 +26,8 @@ struct SpectroParams {
   const float *htaps;      /* device: [8][N/32][4] window as (w[2n],w[2n+1]) pairs, sqrt(1/(4N)) folded */
   const float2 *htw;       /* device: [slots][N/32] inter-pass twiddles of the N/2-point transform      */
   const float2 *hrot;      /* device: [N/32] (cos,sin)(2 pi t/N), the lane part of the post twiddle     */
+  /* odd taper counts, spectro16x.hip: the last taper alone; NULL when not built for this plan */
+  const float *xtaps;      /* device: [4][N/16][4] last taper, sqrt(1/(4N(1+sig))) folded               */
   float *psd;              /* device: [nframes][N/2+1]                                       */
   float *spec;             /* device, optional: [nframes][N] halfcomplex spectrum            */
 };
@@ -40,6 +42,10 @@ hipError_t glfer_launch_spectro16_n11(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16_n13(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16_n14(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16x_n8(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16x_n9(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16x_n10(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16x_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n9(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n10(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n11(const SpectroParams *p, hipStream_t st);

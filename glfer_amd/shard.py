@@ -7,12 +7,21 @@ on the data path, only the outputs' row ranges are disjoint.
 """
 
 
-def frame_range(total_frames, rank, world):
-    """(first, count) of this rank's contiguous block; the remainder goes to the low ranks."""
-    base, rem = divmod(total_frames, world)
-    count = base + (1 if rank < rem else 0)
-    first = rank * base + min(rank, rem)
-    return first, count
+FRAME_ALIGN = 32      # GLFER_FRAME_ALIGN (include/glfer_hip.h): cuts on multiples of it keep every
+                      # frame bit-identical to the single-launch run
+
+
+def frame_range(total_frames, rank, world, align=FRAME_ALIGN):
+    """(first, count) of this rank's contiguous block.  The stream is dealt out in units of
+    `align` frames (the remainder units go to the low ranks, the last partial unit to whoever
+    holds the end), so every boundary is a multiple of `align`."""
+    units = -(-total_frames // align)
+    base, rem = divmod(units, world)
+    u_first = rank * base + min(rank, rem)
+    u_count = base + (1 if rank < rem else 0)
+    first = min(total_frames, u_first * align)
+    last = min(total_frames, (u_first + u_count) * align)
+    return first, last - first
 
 
 def sample_window(first, count, hop, n, history_mode=0):

@@ -84,6 +84,11 @@ typedef struct glfer_hip_config {
   int hparma_p_e;      /* opt.hparma_p_e: number of poles (source.c:374); q_e is fixed to -1 (source.c:375) */
 } glfer_hip_config;
 
+/* Cut a stream into launches, chunks or shards at frame indices that are multiples of this and
+ * every frame's PSD is bit-identical to the one-shot run (the multitaper kernel for odd taper
+ * counts works on aligned groups of up to 32 frames). Other cuts are still correct, to rounding. */
+#define GLFER_FRAME_ALIGN 32
+
 typedef struct glfer_hip_plan glfer_hip_plan;
 
 /* fft_init (fft.c:168-187) / mtm_init (mtm.c:88-151) / hparma_init (hparma.c:45-71): builds the
