@@ -148,7 +148,7 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
     const unsigned ph = (blockIdx.x >> 8) & 3;
     for (unsigned i = 0; i < ph; i++) __builtin_amdgcn_s_sleep(STG);
   }
-  long long fblk = (long long)blockIdx.x * FPB;
+  long long fblk = (long long)xcd_block_index() * FPB;
   if (fblk >= p.nframes) return;
   int pair = 0;
   prefetch_x(fblk);
@@ -416,7 +416,8 @@ static hipError_t launch16_fmt(const SpectroParams &p, hipStream_t st) {
   const long long work = ((long long)p.nframes + LC::FPB - 1) / LC::FPB;
   if (work == 0) return hipSuccess;
   const long long resident = 256LL * ((GLFER16_WAVES_PER_SIMD * 256) / LC::BLOCK > 0 ? (GLFER16_WAVES_PER_SIMD * 256) / LC::BLOCK : 1);
-  const unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
+  unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
+  if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
   if (p.nonlin || p.spec)
     hipLaunchKernelGGL((spectro16_kernel<L, FMT, true>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   else

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     }
   };
 
-  long long fblk = (long long)blockIdx.x * FPB;
+  long long fblk = (long long)xcd_block_index() * FPB;
   if (fblk >= p.nframes) return;
   prefetch_x(fblk);
 
@@ -225,7 +225,8 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
   if (work == 0) return hipSuccess;
   const long long per_cu = (GLFER16H_WAVES_PER_SIMD * 256) / LC::BLOCK > 0 ? (GLFER16H_WAVES_PER_SIMD * 256) / LC::BLOCK : 1;
   const long long resident = 256LL * per_cu;
-  const unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
+  unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
+  if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
   hipLaunchKernelGGL((spectro16h_kernel<L, FMT>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   return hipGetLastError();
 }
@@ -233,6 +234,8 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
 // the real-input form of the single-taper path; needs p->htaps/htw/hrot (glfer_hip.cpp builds them)
 extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16h_n, GLFER_LOGN)(const SpectroParams *p, hipStream_t st) {
   if (!p->htaps || !p->htw || !p->hrot || p->nonlin || p->spec) return hipErrorInvalidValue;
+  // the gather has no zero-history path: every frame must lie wholly inside the stream
+  if (p->frame0 * (long long)p->H < (long long)p->R) return hipErrorInvalidValue;
   switch (p->fmt) {
     case GLFER_FMT_F32: return launch16h_fmt<GLFER_FMT_F32>(*p, st);
     case GLFER_FMT_S16: return launch16h_fmt<GLFER_FMT_S16>(*p, st);

@@ -22,6 +22,11 @@
 #include <stdint.h>
 #include "stockham16.hpp"
 
+// PSD rows are written once and never read by this kernel: non-temporal stores (aux bit 1 = nt) keep
+// them from displacing the sample stream in L2, which the shared round re-reads
+#ifndef GLFER_PSD_STORE_AUX
+#define GLFER_PSD_STORE_AUX 2
+#endif
 #ifndef GLFER16X_WAVES_PER_SIMD
 #define GLFER16X_WAVES_PER_SIMD 3
 #endif
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
     for (int m = 0; m < 8; m++) pt[8 + m] = v2f32{xa[2 * m], xa[2 * m + 1]};
   };
 
-  long long fblk = (long long)blockIdx.x * (2 * FPB);
+  long long fblk = (long long)xcd_block_index() * (2 * FPB);
   if (fblk >= p.nframes) return;
   load_x(px, fblk);
   prefetch_taps(0);
@@ -192,10 +197,11 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
       for (int w = 1; w < RW; w <<= 1) e += __shfl_xor(e, w);
       float *fold = reinterpret_cast<float *>(xb);
       frame_sync<T>();
-      static_for<0, 16>([&](auto rc) {
-        constexpr int rho = decltype(rc)::value;
-        constexpr int b = rho % BL, qp = brev(rho / BL, RL);
-        fold[(int)t + T * (b + BL * qp)] = acc[rho];
+      // only the upper half (bins >= N/2, entry k - N/2) goes through LDS; the lane adds the
+      // partner of each of its own lower bins
+      static_for<8, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        fold[t + T * (m - 8)] = acc[rho_of(m)];
       });
       if constexpr (T >= 64) {
         if ((t & 63) == 0) red[fl * WPF + (t >> 6)] = e;
@@ -214,12 +220,16 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
       if (which == 0) hxA = hx;
       else hxB = hx;
       float *dstp = part + which * (FPB * L::PART);
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
+      static_for<0, 8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
         const int k = T * m + (int)t;
-        dstp[k] = fold[k] + fold[(N - k) & (N - 1)];
-      }
-      if (t == 0) dstp[N / 2] = 2.0f * fold[N / 2];
+        float other = fold[N / 2 - k];                 // acc[N-k]; entry N/2 (k = 0) is never written
+        if constexpr (m == 0) {
+          if (t == 0) other = acc[rho_of(0)];          // bin 0 pairs with itself
+        }
+        dstp[k] = acc[rho_of(m)] + other;
+      });
+      if (t == 0) dstp[N / 2] = 2.0f * acc[rho_of(8)];
     }
 
     // ---- shared round: re = sA*(xA*v), im = sB*(xB*v), v the odd taper
@@ -273,13 +283,13 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
         }
         const float er = ar + b.x, ei = ai - b.y, orr = ar - b.x, oi = ai + b.y;
         const float pa = __builtin_fmaf(er, er, ei * ei), pb = __builtin_fmaf(orr, orr, oi * oi);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pa, uA, part[k])), ra, voff, (unsigned)(T * m) * 4u, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pb, uB, partB[k])), rb, voff, (unsigned)(T * m) * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pa, uA, part[k])), ra, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pb, uB, partB[k])), rb, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
       });
       if (t == 0) {                                     // k = N/2 pairs with itself: E = 2 Re Z, O = 2i Im Z
         constexpr int r = rho_of(8);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, part[N / 2])), ra, voff, (unsigned)(N / 2) * 4u, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, partB[N / 2])), rb, voff, (unsigned)(N / 2) * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, part[N / 2])), ra, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, partB[N / 2])), rb, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
       }
     }
     if (!has_next) break;
@@ -306,7 +316,8 @@ static hipError_t launch16x_fmt(const SpectroParams &p, hipStream_t st) {
   if (work == 0) return hipSuccess;
   const long long per_cu = (GLFER16X_WAVES_PER_SIMD * 256) / LC::BLOCK > 0 ? (GLFER16X_WAVES_PER_SIMD * 256) / LC::BLOCK : 1;
   const long long resident = 256LL * per_cu;
-  const unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
+  unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
+  if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
   hipLaunchKernelGGL((spectro16x_kernel<L, FMT>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   return hipGetLastError();
 }
@@ -314,6 +325,8 @@ static hipError_t launch16x_fmt(const SpectroParams &p, hipStream_t st) {
 // odd taper counts >= 3; needs p->xtaps (the last taper alone, glfer_hip.cpp builds it)
 extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16x_n, GLFER_LOGN)(const SpectroParams *p, hipStream_t st) {
   if (!p->xtaps || p->npairs < 2 || p->nonlin || p->spec) return hipErrorInvalidValue;
+  // the gather has no zero-history path: every frame must lie wholly inside the stream
+  if (p->frame0 * (long long)p->H < (long long)p->R) return hipErrorInvalidValue;
   switch (p->fmt) {
     case GLFER_FMT_F32: return launch16x_fmt<GLFER_FMT_F32>(*p, st);
     case GLFER_FMT_S16: return launch16x_fmt<GLFER_FMT_S16>(*p, st);

@@ -61,6 +61,14 @@ __device__ __forceinline__ float buf_sample(__amdgpu_buffer_rsrc_t rsrc, unsigne
   }
 }
 
+// Workgroup w of a launch runs on XCD (w mod 8), each XCD with its own L2.  Overlapped frames share
+// samples with their neighbours, so neighbouring frame blocks should share an L2: logical block
+// index = the XCD's contiguous slice of the grid (gridDim.x a multiple of 8; identity otherwise).
+__device__ __forceinline__ unsigned xcd_block_index() {
+  const unsigned w = blockIdx.x, g = gridDim.x;
+  return (g & 7u) ? w : (w & 7u) * (g >> 3) + (w >> 3);
+}
+
 template <int T>
 __device__ __forceinline__ void frame_sync() {
   if constexpr (T > 64) {

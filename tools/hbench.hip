@@ -35,7 +35,10 @@ int main(int argc, char **argv) {
   std::vector<float> tw((size_t)2 * glfer::make_twiddles16(LOGN, nullptr) * (N / 16)), htw((size_t)2 * glfer::make_twiddles16(LOGN - 1, nullptr) * TH);
   glfer::make_twiddles16(LOGN, tw.data());
   glfer::make_twiddles16(LOGN - 1, htw.data());
-  const size_t ns = (size_t)nframes * H;
+  // the real-input kernel takes only frames that lie wholly inside the stream (the library's
+  // launcher sends the first R/H frames to the packed kernel): start at frame R/H = 3
+  constexpr int F0 = (N - H) / H;
+  const size_t ns = (size_t)(nframes + F0) * H;
   std::vector<float> x(ns);
   unsigned s = 12345;
   for (size_t i = 0; i < ns; i++) { s = s * 1664525u + 1013904223u; x[i] = (float)((s >> 8) * (1.0 / 16777216.0) - 0.5) + 0.3f * sinf(0.01f * (float)i); }
@@ -56,7 +59,7 @@ int main(int argc, char **argv) {
   CK(hipMemcpy(d_htw, htw.data(), htw.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(d_hrot, hrot.data(), hrot.size() * 4, hipMemcpyHostToDevice));
   SpectroParams sp = {};
-  sp.stream = d_x; sp.nframes = nframes; sp.H = H; sp.R = N - H; sp.npairs = 1; sp.fmt = GLFER_FMT_F32;
+  sp.stream = d_x; sp.frame0 = F0; sp.nframes = nframes; sp.H = H; sp.R = N - H; sp.npairs = 1; sp.fmt = GLFER_FMT_F32;
   sp.taps = d_taps; sp.tw = d_tw; sp.htaps = d_htaps; sp.htw = d_htw; sp.hrot = d_hrot; sp.spec_unscale = 1.0f;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Condense a gpurun_out/prof/ tree (rocprofv3 --kernel-trace --stats and --pmc passes over
-bench.py) into the small summaries kept under profiles/.   usage: summarize_prof.py <round-tag>"""
+"""Condense a gpurun_out/prof[_<workload>]/ tree (rocprofv3 --kernel-trace --stats and --pmc
+passes over bench.py) into the small summaries kept under profiles/.
+usage: summarize_prof.py <round-tag> [mtm|fft]"""
 import collections
 import csv
 import glob
@@ -9,8 +10,10 @@ import os
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+workload = sys.argv[2] if len(sys.argv) > 2 else "mtm"
+suffix = "" if workload == "mtm" else "_" + workload
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prof = os.path.join(root, "gpurun_out", "prof")
+prof = os.path.join(root, "gpurun_out", "prof" + suffix)
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
@@ -20,18 +23,19 @@ def one(pattern):
 
 
 rows = list(csv.DictReader(open(one("stats/*/*_kernel_stats.csv"))))
-with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as f:
+with open(os.path.join(out, tag + "_kernel_stats" + suffix + ".csv"), "w") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
     for r in rows:
         w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
                     r["MaxNs"], r["StdDev"]])
-k = [r for r in rows if "spectro16" in r["Name"]][0]
+k = max((r for r in rows if "spectro16" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+KNAME = k["Name"]
 
 
 def pmc(path, name):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-         if "spectro16" in r["Kernel_Name"] and r["Counter_Name"] == name]
+         if r["Kernel_Name"] == KNAME and r["Counter_Name"] == name]
     return sum(v) / len(v)
 
 
@@ -39,18 +43,20 @@ fetch = pmc(one("fetch/*/*_counter_collection.csv"), "FETCH_SIZE")
 write = pmc(one("write/*/*_counter_collection.csv"), "WRITE_SIZE")
 sq = collections.defaultdict(list)
 for r in csv.DictReader(open(one("sq/*/*_counter_collection.csv"))):
-    if "spectro16" in r["Kernel_Name"]:
+    if r["Kernel_Name"] == KNAME:
         sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
 sq = {n: sum(v) / len(v) for n, v in sq.items()}
-frames, hop, bins = 262144, 4096, 2049
+frames, hop, bins = (262144, 4096, 2049) if workload == "mtm" else (262144, 1024, 2049)
 alg = frames * (4 * hop + 4 * bins)
 # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports exactly half
 # the bytes of a coalesced streaming read -> doubled here; WRITE_SIZE reads the bytes exactly.
 traffic = (2 * fetch + write) * 1024
 summary = {
     "command": "rocprofv3 --kernel-trace {--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*} "
-               "-- python3 bench.py --steps K --warmup 1 --no-cpu-baseline   (separate passes)",
-    "workload": "C3 MTM N=4096 NW=2.5 mtm_k=4 overlap 0, %d frames per launch" % frames,
+               "-- python3 bench.py --steps K --warmup 1 --no-cpu-baseline%s   (separate passes)"
+               % ("" if workload == "mtm" else " --workload " + workload),
+    "workload": ("C3 MTM N=4096 NW=2.5 mtm_k=4 overlap 0, %d frames per launch" if workload == "mtm" else
+                 "C2 periodogram Hanning N=4096 overlap 75 %%, %d frames per launch") % frames,
     "kernel": k["Name"], "kernel_avg_ns_profiled": float(k["AverageNs"]), "kernel_calls": int(k["Calls"]),
     "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
     "hbm_traffic_bytes_per_launch_corrected": traffic,
@@ -59,5 +65,5 @@ summary = {
     "traffic_over_algorithmic": traffic / alg,
     "sq_counters_per_launch": sq, "frames_per_launch": frames,
 }
-json.dump(summary, open(os.path.join(out, tag + "_hbm_traffic.json"), "w"), indent=1)
+json.dump(summary, open(os.path.join(out, tag + "_hbm_traffic" + suffix + ".json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
