@@ -57,6 +57,7 @@ struct glfer_hip_plan {
   float2 *d_htw = nullptr;          //   twiddles of the n/2-point transform
   float2 *d_hrot = nullptr;         //   (cos,sin)(2 pi t/n), t < n/32
   float *d_xtaps = nullptr;         // odd taper counts (spectro16x.hip): the last taper alone, [4][n/16][4]
+  float *d_ltaps = nullptr;         // odd taper counts, LDS-resident half tables (spectro16xl.hip)
   uint16_t *d_lagmap = nullptr;     // HP-ARMA: [t][p_e+1] lag held by each matrix cell
   float2 *d_unit = nullptr;         // HP-ARMA: [n/2+1] exp(-2 pi i k/n)
   float *d_scratch = nullptr;       // sub_mean copy of the hops of one call
@@ -276,6 +277,39 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     }
   }
 
+  // --- the same, with half tables that stay in LDS (spectro16xl.hip): DPSS tapers are symmetric
+  // (even order) or antisymmetric (odd order) about the frame centre, so samples n < N/2 suffice.
+  // Built only if the tapers computed above have that symmetry to 1e-7 of their peak and the
+  // tables leave room for two blocks per CU.
+  std::vector<float> ltaps;
+  if (!xtaps.empty() && n <= 4096) {
+    const int T = n / 16, nfull = p->npairs - 1;
+    bool sym = true;
+    for (int j = 0; j < p->ntapers && sym; j++) {
+      const double *v = &p->tapers[(size_t)j * n];
+      double peak = 0.0, dev = 0.0;
+      for (int i = 0; i < n / 2; i++) {
+        peak = std::max(peak, std::fabs(v[i]));
+        dev = std::max(dev, std::fabs(v[n - 1 - i] - ((j & 1) ? -v[i] : v[i])));
+      }
+      sym = dev <= 1e-7 * peak;
+    }
+    const size_t lds = ((size_t)(n + n / 16) * (T >= 256 ? 1 : 256 / T) + 16 * 17 + 8 + (size_t)nfull * 8 * T + 4 * T) * 8;
+    if (sym && lds <= 80 * 1024) {
+      ltaps.resize((size_t)nfull * 8 * T * 2 + (size_t)8 * T);
+      for (int j = 0; j < p->ntapers; j++) {
+        const bool last = j == p->ntapers - 1;
+        const double scale = std::sqrt(1.0 / ((last ? 4.0 : 2.0) * n * (1.0 + p->sig[j])));
+        for (int m = 0; m < 8; m++)
+          for (int t = 0; t < T; t++) {
+            const float val = (float)(p->tapers[(size_t)j * n + t + T * m] * scale);
+            if (last) ltaps[(size_t)nfull * 8 * T * 2 + (size_t)m * T + t] = val;
+            else ltaps[(((size_t)(j / 2) * 8 + m) * T + t) * 2 + (j & 1)] = val;
+          }
+      }
+    }
+  }
+
   // --- HP-ARMA tables: which lag each cell of the t x (p_e+1) matrix holds after the
   // reference's fill (hparma.c:89-102).  r_xx is matrix(0,t,0,p_e) (hparma.c:64): its rows
   // are contiguous (util.c:153-160), lags 0..t-1 are written into row 0 past its p_e+1
@@ -317,6 +351,10 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     e = hipMalloc((void **)&p->d_xtaps, xtaps.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->d_xtaps, xtaps.data(), xtaps.size() * sizeof(float), hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && !ltaps.empty()) {
+    e = hipMalloc((void **)&p->d_ltaps, ltaps.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->d_ltaps, ltaps.data(), ltaps.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess && !lagmap.empty()) {
     e = hipMalloc((void **)&p->d_lagmap, lagmap.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_unit, unit.size() * sizeof(float));
@@ -340,6 +378,7 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (p->d_htw) (void)hipFree(p->d_htw);
   if (p->d_hrot) (void)hipFree(p->d_hrot);
   if (p->d_xtaps) (void)hipFree(p->d_xtaps);
+  if (p->d_ltaps) (void)hipFree(p->d_ltaps);
   if (p->d_scratch) (void)hipFree(p->d_scratch);
   if (p->d_lagmap) (void)hipFree(p->d_lagmap);
   if (p->d_unit) (void)hipFree(p->d_unit);
@@ -403,6 +442,15 @@ static hipError_t launch_real_input(const SpectroParams &sp, int n, hipStream_t 
 }
 
 static hipError_t launch_shared_odd(const SpectroParams &sp, int n, hipStream_t st) {
+  if (sp.ltaps) {                      // taper half tables resident in LDS
+    switch (n) {
+      case 256: return glfer_launch_spectro16xl_n8(&sp, st);
+      case 512: return glfer_launch_spectro16xl_n9(&sp, st);
+      case 1024: return glfer_launch_spectro16xl_n10(&sp, st);
+      case 2048: return glfer_launch_spectro16xl_n11(&sp, st);
+      case 4096: return glfer_launch_spectro16xl_n12(&sp, st);
+    }
+  }
   switch (n) {
     case 256: return glfer_launch_spectro16x_n8(&sp, st);
     case 512: return glfer_launch_spectro16x_n9(&sp, st);
@@ -421,7 +469,7 @@ static hipError_t launch_shared_odd(const SpectroParams &sp, int n, hipStream_t 
 static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   const bool real_input = sp.htaps && sp.npairs == 1 && n >= 512;
   // built where it fits 3 waves/SIMD without spilling (N = 2048 and N >= 8192 do not: they stay packed)
-  const bool shared_odd = sp.xtaps && sp.npairs >= 2 && (n <= 1024 || n == 4096);
+  const bool shared_odd = sp.xtaps && sp.npairs >= 2 && (sp.ltaps || n <= 1024 || n == 4096);
   if (sp.spec || sp.nonlin || !(real_input || shared_odd)) return launch_packed(sp, n, st);
   const long long first_inside = ((long long)sp.R + sp.H - 1) / sp.H;          // first frame f with f*H >= R
   // spectro16x.hip works on groups of G consecutive frames (frame f shares its last transform with
@@ -487,6 +535,7 @@ static int run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, 
   sp.htw = p->d_htw;
   sp.hrot = p->d_hrot;
   sp.xtaps = p->d_xtaps;
+  sp.ltaps = p->d_ltaps;
   sp.psd = d_psd;
   sp.spec = d_spec;
 

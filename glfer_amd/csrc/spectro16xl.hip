@@ -1,0 +1,324 @@
+// spectro16xl.hip -- spectro16x.hip's scheme (odd taper count: the last taper of two frames shares
+// one transform) with the taper tables RESIDENT IN LDS.
+//
+// In spectro16x.hip every round fetches its taper pair from the L2-resident table: 32 KB per round
+// through the CU's 64 B/clk vector-memory path, 80 KB per frame at T = 5, five times the frame's
+// own samples, plus 32 prefetch VGPRs.  DPSS tapers are symmetric (even order) or antisymmetric
+// (odd order) about the frame centre, v_k[N-1-n] = (-1)^k v_k[n], so HALF of each table is enough:
+// lane t's samples t + T*m, m >= 8, are lane T-1-t's samples at 15-m.  (2*NP+1) half tables are
+// (2*NP+1)*N*2 bytes: 40 KB for N = 4096, T = 5, next to the 35 KB exchange buffer -- two blocks
+// per CU, 8 wavefronts, which measures the same as three (tools/xbench: the kernel is bound by
+// VALU issue, not by latency hiding).  Reading them is 16 ds_read_b64 per round (LDS reads run at
+// 256 B/clk).  With 256 VGPRs per lane both frame groups' samples and both partial PSDs stay in
+// registers: nothing is re-read from memory and nothing but the exchange goes through LDS.
+//
+// The host builds the half tables only when the tapers it computed are (anti)symmetric to 1e-7 of
+// their peak (they are, to rounding; the check guards the identity, not the algorithm).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "stockham16.hpp"
+
+#ifndef GLFER_PSD_STORE_AUX
+#define GLFER_PSD_STORE_AUX 2      /* non-temporal: PSD rows are written once, never re-read here */
+#endif
+
+namespace glfer {
+
+template <int LOGN>
+struct LaunchXL {
+  using C = Plan16<LOGN>;
+  static constexpr int N = C::N, T = C::T;
+  static_assert(T <= 256, "one block of 256 lanes holds whole frames");
+  static constexpr int FPB = 256 / T;
+  static constexpr int BLOCK = 256;
+  static constexpr int PADN = N + N / 16;
+  static constexpr int WPF = T >= 64 ? T / 64 : 1;
+  // v2f32 words: exchange, pass-1 twiddles, power partials, then the taper half tables
+  static constexpr int FIXED_WORDS = FPB * PADN + 16 * 17 + (FPB * WPF + 1) / 2 + 1;
+  static constexpr size_t lds_bytes(int nfull) { return ((size_t)FIXED_WORDS + (size_t)nfull * 8 * T + 4 * T) * 8; }
+};
+
+template <int LOGN, int FMT>
+__global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
+  using C = Plan16<LOGN>;
+  using L = LaunchXL<LOGN>;
+  constexpr int N = C::N, T = C::T, NPASS = C::NPASS, FPB = L::FPB, PADN = L::PADN, WPF = L::WPF;
+  constexpr int TW1 = 15;
+  constexpr int NTWR = C::NTW - TW1;
+  constexpr int NT = NTWR > 0 ? NTWR : 1;
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  extern __shared__ v2f32 lds[];
+
+  const unsigned tid = threadIdx.x;
+  const unsigned t = tid % T;
+  const unsigned fl = tid / T;
+  const int NP = p.npairs - 1;                       // full (two-taper) rounds per frame
+  v2f32 *xb = lds + fl * PADN;
+  v2f32 *tw1 = lds + FPB * PADN;
+  float *red = reinterpret_cast<float *>(lds + FPB * PADN + 16 * 17);
+  v2f32 *tl2 = lds + L::FIXED_WORDS;                 // [NP][8][T] (taper 2p, taper 2p+1) at sample t + T*m, m < 8
+  float *tl1 = reinterpret_cast<float *>(tl2 + NP * 8 * T);   // [8][T] the last (even-order) taper
+
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.tw);
+    const unsigned k = tid >> 4, q = tid & 15;
+    tw1[k * 17 + q] = q ? tw[(q - 1) * T + k] : v2f32{1.0f, 0.0f};
+    const v2f32 *g2 = reinterpret_cast<const v2f32 *>(p.ltaps);
+    for (int i = tid; i < NP * 8 * T; i += 256) tl2[i] = g2[i];
+    const float *g1 = p.ltaps + (size_t)NP * 8 * T * 2;
+    for (int i = tid; i < 8 * T; i += 256) tl1[i] = g1[i];
+  }
+  float twr[NT], twi[NT];
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.tw) + t;
+#pragma unroll
+    for (int e = 0; e < NTWR; e++) {
+      const v2f32 w = tw[(TW1 + e) * T];
+      twr[e] = w.x;
+      twi[e] = w.y;
+    }
+    if constexpr (NTWR == 0) twr[0] = twi[0] = 0.0f;
+  }
+  __syncthreads();
+  const v2f32 *tw1row = tw1 + (t & 15) * 17;
+  const long long stride = (long long)gridDim.x * (2 * FPB);
+
+  // Samples of frame (fblk + fl).  Only frames wholly inside the stream reach this kernel (the
+  // launcher sends a stream's first ceil(R/H) frames to spectro16.hip), so every load is in range.
+  auto load_x = [&](float (&dst)[16], long long fblk) {
+    const long long f = fblk + fl;
+    const unsigned flc = f < p.nframes ? fl : (unsigned)(p.nframes - 1 - fblk);
+    const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
+    const unsigned lrel = flc * (unsigned)p.H + t;
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      dst[m] = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(T * m) * esz);
+    });
+    if (p.history_mode) {                            // fft.c:103-108 with glfer.first_buffer stuck at TRUE
+      const int d = (int)t - p.R;
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        dst[m] = (d >= -T * m) ? dst[m] : 0.0f;
+      });
+    }
+  };
+
+  long long fblk = (long long)xcd_block_index() * (2 * FPB);
+  if (fblk >= p.nframes) return;
+  float xA[16], xB[16];
+  load_x(xA, fblk);
+  if (fblk + FPB < p.nframes) load_x(xB, fblk + FPB);
+  else {
+#pragma unroll
+    for (int m = 0; m < 16; m++) xB[m] = 0.0f;
+  }
+
+  constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
+  auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };   // register of bin t + T*m
+  constexpr int kSilent = 0x7fff;
+
+  // One frame group's NP full rounds; leaves the mirror-folded sums psd[k] = acc[k] + acc[N-k]
+  // (k = t + T*m, m < 8, and k = N/2 on lane 0) and the exponent of the shared round's scale.
+  auto full_rounds = [&](const float (&x)[16], float (&psd)[8], float &nyq, int &hx) {
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    for (int pair = 0; pair < NP; pair++) {
+      const v2f32 *wlo = tl2 + pair * 8 * T + t, *whi = tl2 + pair * 8 * T + (T - 1 - t);
+      float zr[16], zi[16];
+      GLFER_STAMP(0);                                // round start
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (m < 8) {
+          const v2f32 w = wlo[m * T];
+          zr[m] = x[m] * w.x;
+          zi[m] = x[m] * w.y;
+        } else {                                     // sample N-1-n: even taper as is, odd taper negated
+          const v2f32 w = whi[(15 - m) * T];
+          zr[m] = x[m] * w.x;
+          zi[m] = -(x[m] * w.y);
+        }
+      });
+      stockham16_passes<LOGN, NT>(zr, zi, xb, t, tw1row, twr, twi, [] {});
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        acc[r] = __builtin_fmaf(zr[r], zr[r], __builtin_fmaf(zi[r], zi[r], acc[r]));
+      GLFER_STAMP(15);                               // round end (accumulated)
+    }
+    float e = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) e += acc[r];
+    constexpr int RW = T < 64 ? T : 64;
+#pragma unroll
+    for (int w = 1; w < RW; w <<= 1) e += __shfl_xor(e, w);
+    float *fold = reinterpret_cast<float *>(xb);
+    frame_sync<T>();
+    static_for<8, 16>([&](auto mc) {                 // upper half (entry k - N/2) through LDS
+      constexpr int m = decltype(mc)::value;
+      fold[t + T * (m - 8)] = acc[rho_of(m)];
+    });
+    if constexpr (T >= 64) {
+      if ((t & 63) == 0) red[fl * WPF + (t >> 6)] = e;
+    }
+    frame_sync<T>();
+    if constexpr (T >= 64) {
+      e = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WPF; w++) e += red[fl * WPF + w];
+    }
+    int ex = __builtin_amdgcn_frexp_expf(e);         // 0 for e = 0, inf, nan
+    ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
+    hx = e == 0.0f ? kSilent : ex >> 1;              // digital silence stays exactly 0 (scale 0)
+    static_for<0, 8>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const int k = T * m + (int)t;
+      float other = fold[N / 2 - k];                 // acc[N-k]; entry N/2 (k = 0) is never written
+      if constexpr (m == 0) {
+        if (t == 0) other = acc[rho_of(0)];
+      }
+      psd[m] = acc[rho_of(m)] + other;
+    });
+    nyq = 2.0f * acc[rho_of(8)];
+  };
+
+  while (true) {                                     // one iteration: frame groups A and B
+    const bool hasB = fblk + FPB < p.nframes;        // block-uniform
+    const long long nfblk = fblk + stride;
+    const bool has_next = nfblk < p.nframes;
+    float psdA[8], psdB[8], nyqA = 0.0f, nyqB = 0.0f;
+    int hxA = kSilent, hxB = kSilent;
+#pragma unroll
+    for (int m = 0; m < 8; m++) psdA[m] = psdB[m] = 0.0f;
+    // one copy of the rounds in the instruction stream: the group is chosen by register moves
+#pragma clang loop unroll(disable)
+    for (int which = 0; which < (hasB ? 2 : 1); which++) {
+      float xw[16], psd[8], nyq;
+      int hx;
+#pragma unroll
+      for (int m = 0; m < 16; m++) xw[m] = which ? xB[m] : xA[m];
+      full_rounds(xw, psd, nyq, hx);
+      if (which == 0) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) psdA[m] = psd[m];
+        nyqA = nyq;
+        hxA = hx;
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; m++) psdB[m] = psd[m];
+        nyqB = nyq;
+        hxB = hx;
+      }
+    }
+
+    // ---- shared round: re = sA*(xA*v), im = sB*(xB*v), v the last taper (even order: symmetric)
+    float zr[16], zi[16];
+    {
+      const float sA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxA);
+      const float sB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxB);
+      const float *vlo = tl1 + t, *vhi = tl1 + (T - 1 - t);
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const float v = m < 8 ? vlo[m * T] : vhi[(15 - m) * T];
+        zr[m] = (xA[m] * v) * sA;
+        zi[m] = (xB[m] * v) * sB;
+      });
+    }
+    // the next iteration's samples go out after the first exchange's writes
+    stockham16_passes<LOGN, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
+      if (has_next) {
+        load_x(xA, nfblk);
+        if (nfblk + FPB < p.nframes) load_x(xB, nfblk + FPB);
+      }
+    });
+    // separate the two spectra through the mirror pairs (k, N-k): E = Z[k] + conj Z[N-k] = 2 sA Y_A[k],
+    // O = Z[k] - conj Z[N-k] = 2i sB Y_B[k].  Z[k], k >= N/2, goes through LDS (entry k - N/2).
+    frame_sync<T>();
+    static_for<8, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int r = rho_of(m);
+      xb[t + T * (m - 8)] = v2f32{zr[r], zi[r]};
+    });
+    frame_sync<T>();
+    {
+      constexpr unsigned ROWB = (N / 2 + 1) * 4u;
+      const long long leftA = p.nframes - fblk, leftB = p.nframes - (fblk + FPB);
+      const unsigned recA = (unsigned)((leftA > FPB ? FPB : leftA) * (long long)ROWB);
+      const unsigned recB = leftB > 0 ? (unsigned)((leftB > FPB ? FPB : leftB) * (long long)ROWB) : 0u;
+      // rows past the last frame fall outside num_records: their stores are dropped
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)fblk * (N / 2 + 1), 0, recA, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)(fblk + (leftB > 0 ? FPB : 0)) * (N / 2 + 1), 0, recB, 0x00020000);
+      const unsigned voff = fl * ROWB + t * 4u;
+      const float uA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxA);
+      const float uB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxB);
+      static_for<0, 8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int r = rho_of(m);
+        const int k = (int)t + T * m;
+        v2f32 b = xb[N / 2 - k];                     // Z[N-k]; entry N/2 (k = 0) is never written
+        const float ar = zr[r], ai = zi[r];
+        if constexpr (m == 0) {
+          if (t == 0) b = v2f32{ar, ai};             // k = 0 pairs with itself
+        }
+        const float er = ar + b.x, ei = ai - b.y, orr = ar - b.x, oi = ai + b.y;
+        const float pa = __builtin_fmaf(er, er, ei * ei), pb = __builtin_fmaf(orr, orr, oi * oi);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pa, uA, psdA[m])), ra, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pb, uB, psdB[m])), rb, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
+      });
+      if (t == 0) {                                  // k = N/2 pairs with itself: E = 2 Re Z, O = 2i Im Z
+        constexpr int r = rho_of(8);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, nyqA)), ra, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, nyqB)), rb, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
+      }
+    }
+    if (!has_next) break;
+    fblk = nfblk;
+    if (fblk + FPB >= p.nframes) {
+#pragma unroll
+      for (int m = 0; m < 16; m++) xB[m] = 0.0f;
+    }
+  }
+}
+
+}  // namespace glfer
+
+#ifndef GLFER_NO_LAUNCHERS
+using namespace glfer;
+
+#ifndef GLFER_LOGN
+#error "compile with -DGLFER_LOGN=<log2 of the block size>"
+#endif
+#define GLFER_CAT2(a, b) a##b
+#define GLFER_CAT(a, b) GLFER_CAT2(a, b)
+
+template <int FMT>
+static hipError_t launch16xl_fmt(const SpectroParams &p, hipStream_t st) {
+  constexpr int L = GLFER_LOGN;
+  using LC = LaunchXL<L>;
+  const size_t shmem = LC::lds_bytes(p.npairs - 1);
+  if (shmem > 80 * 1024) return hipErrorInvalidValue;            // two blocks per CU or not at all
+  const long long work = ((long long)p.nframes + 2 * LC::FPB - 1) / (2 * LC::FPB);
+  if (work == 0) return hipSuccess;
+  const long long resident = 256LL * 2;
+  unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
+  if (grid >= 64) grid &= ~7u;                       // whole XCD slices: see xcd_block_index()
+  auto kern = spectro16xl_kernel<L, FMT>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, st, p);
+  return hipGetLastError();
+}
+
+// odd taper counts >= 3 whose half tables fit in LDS; needs p->ltaps (glfer_hip.cpp builds it)
+extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16xl_n, GLFER_LOGN)(const SpectroParams *p, hipStream_t st) {
+  if (!p->ltaps || p->npairs < 2 || p->nonlin || p->spec) return hipErrorInvalidValue;
+  if (p->frame0 * (long long)p->H < (long long)p->R) return hipErrorInvalidValue;   // no zero-history path here
+  switch (p->fmt) {
+    case GLFER_FMT_F32: return launch16xl_fmt<GLFER_FMT_F32>(*p, st);
+    case GLFER_FMT_S16: return launch16xl_fmt<GLFER_FMT_S16>(*p, st);
+    case GLFER_FMT_U8: return launch16xl_fmt<GLFER_FMT_U8>(*p, st);
+  }
+  return hipErrorInvalidValue;
+}
+#endif  // GLFER_NO_LAUNCHERS

@@ -28,6 +28,8 @@ struct SpectroParams {
   const float2 *hrot;      /* device: [N/32] (cos,sin)(2 pi t/N), the lane part of the post twiddle     */
   /* odd taper counts, spectro16x.hip: the last taper alone; NULL when not built for this plan */
   const float *xtaps;      /* device: [4][N/16][4] last taper, sqrt(1/(4N(1+sig))) folded               */
+  /* odd taper counts with LDS-resident half tables, spectro16xl.hip; NULL when not built */
+  const float *ltaps;      /* device: [npairs-1][8][N/16][2] pair halves, then [8][N/16] the last taper */
   float *psd;              /* device: [nframes][N/2+1]                                       */
   float *spec;             /* device, optional: [nframes][N] halfcomplex spectrum            */
 };
@@ -46,6 +48,11 @@ hipError_t glfer_launch_spectro16x_n8(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16x_n9(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16x_n10(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16x_n12(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16xl_n8(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16xl_n9(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16xl_n10(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16xl_n11(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16xl_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n9(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n10(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n11(const SpectroParams *p, hipStream_t st);

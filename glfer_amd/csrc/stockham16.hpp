@@ -7,6 +7,12 @@
 #include "fft_inreg.hpp"
 #include "spectro_params.h"
 
+// Timeline stamps for tools/stampbench only: GLFER_STAMP(id) records the shader clock of one chosen
+// wave at a phase boundary.  Expands to nothing in the product build.
+#ifndef GLFER_STAMP
+#define GLFER_STAMP(id)
+#endif
+
 namespace glfer {
 
 typedef float v2f32 __attribute__((ext_vector_type(2)));
@@ -128,8 +134,10 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
       constexpr int b = decltype(bc)::value;
       dit<R, B, b, 16>(zr, zi);
     });
+    GLFER_STAMP(4 * i + 1);                // pass i butterflies done
     if constexpr (i < NPASS - 1) {
       frame_sync<T>();                     // everyone has finished reading the previous exchange
+      GLFER_STAMP(4 * i + 2);              // through the pre-write barrier
       static_for<0, B>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
         const int j = (int)t + T * b;
@@ -147,7 +155,9 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
         after_first_write();
         __builtin_amdgcn_sched_barrier(0);
       }
+      GLFER_STAMP(4 * i + 3);              // writes (and the hook's loads) issued
       frame_sync<T>();
+      GLFER_STAMP(4 * i + 4);              // through the post-write barrier
       const v2f32 *rbase = xb + t + (t >> 4);
       static_for<0, 16>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
