@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
 
     // ---- shared round: re = sA*(xA*v), im = sB*(xB*v), v the last taper (even order: symmetric)
     float zr[16], zi[16];
+    GLFER_STAMP(0);                                  // shared round start
     {
       const float sA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxA);
       const float sB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxB);
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, nyqB)), rb, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
       }
     }
+    GLFER_STAMP(15);                                 // shared round end (separated, stored)
     if (!has_next) break;
     fblk = nfblk;
     if (fblk + FPB >= p.nframes) {

@@ -85,9 +85,9 @@ int main(int argc, char **argv) {
   }
   std::vector<unsigned long long> st(64 * 16);
   CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
-  const char *names[16] = {"round start", "pass0 butterflies", "pre-write barrier 0", "writes 0 issued", "post-write barrier 0",
+  const char *names[16] = {"round start", "form z + pass0 butterflies", "pre-write barrier 0", "writes 0 issued", "post-write barrier 0",
                            "pass1 (reads+twiddle+bfly)", "pre-write barrier 1", "writes 1 issued", "post-write barrier 1",
-                           "pass2 (reads+twiddle+bfly)", "", "", "", "", "", "accumulate |Z|^2"};
+                           "pass2 (reads+twiddle+bfly)", "", "", "", "", "", "accumulate / separate+store"};
   const int order[11] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15};
   double sum[16] = {0};
   int cnt = 0;
@@ -100,7 +100,8 @@ int main(int argc, char **argv) {
   }
   double tot = 0;
   for (int i = 1; i < 11; i++) tot += sum[order[i]] / cnt;
-  printf("wave 0 of block 8, %d rounds averaged; s_memtime ticks (100 MHz REFCLK on gfx9: x24 for ~2.4 GHz clocks if so)\n", cnt);
+  printf("wave 0 of block 8, %d rounds averaged (4 full + 1 shared per frame pair); s_memtime ticks.\n"
+         "NOTE: stamp 0 reads a counter from memory, so the first interval carries ~2 k ticks of load latency.\n", cnt);
   for (int i = 1; i < 11; i++) printf("  -> %-28s %9.1f  (%4.1f%%)\n", names[order[i]], sum[order[i]] / cnt, 100.0 * sum[order[i]] / cnt / tot);
   printf("  round total %.1f ticks; first/last stamp of rounds 8 and 55: %llu .. %llu\n", tot, st[8 * 16], st[55 * 16 + 15]);
   return 0;
