@@ -22,7 +22,11 @@ __device__ int g_round;
     }                                                                                                \
   } while (0)
 #define GLFER_NO_LAUNCHERS
+#ifdef STAMP_XD
+#include "spectro16xd.hip"
+#else
 #include "spectro16xl.hip"
+#endif
 #include "host_tables.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -49,6 +53,24 @@ int main(int argc, char **argv) {
   std::vector<float> x(ns);
   unsigned s = 12345;
   for (size_t i = 0; i < ns; i++) { s = s * 1664525u + 1013904223u; x[i] = (float)((s >> 8) * (1.0 / 16777216.0) - 0.5); }
+  std::vector<float> dlane((size_t)19 * 256 * 2);
+  for (int pl = 0; pl < 256; pl++) {
+    const int ka = pl >> 4, i = pl & 15, c = i ^ ((i & 4) ? 3 : 0);
+    for (int kb = 0; kb < 16; kb++) {
+      const double ang = -2.0 * M_PI * (double)((c * (ka + 16 * kb)) % 4096) / 4096.0;
+      dlane[((size_t)kb * 256 + pl) * 2] = (float)cos(ang);
+      dlane[((size_t)kb * 256 + pl) * 2 + 1] = (float)sin(ang);
+    }
+    const int hs[3] = {8, 4, 2};
+    for (int j = 0; j < 3; j++) {
+      const double ang = (c & hs[j]) ? -2.0 * M_PI * (double)(c % hs[j]) / (2.0 * hs[j]) : 0.0;
+      dlane[((size_t)(16 + j) * 256 + pl) * 2] = (float)cos(ang);
+      dlane[((size_t)(16 + j) * 256 + pl) * 2 + 1] = (float)sin(ang);
+    }
+  }
+  float *d_dl;
+  CK(hipMalloc((void **)&d_dl, dlane.size() * 4));
+  CK(hipMemcpy(d_dl, dlane.data(), dlane.size() * 4, hipMemcpyHostToDevice));
   float *d_x, *d_lt, *d_psd;
   float2 *d_tw;
   unsigned long long *d_st;
@@ -65,8 +87,22 @@ int main(int argc, char **argv) {
   SpectroParams sp = {};
   sp.stream = d_x; sp.nframes = nframes; sp.H = H; sp.R = 0; sp.npairs = NP + 1; sp.fmt = GLFER_FMT_F32;
   sp.tw = d_tw; sp.ltaps = d_lt; sp.psd = d_psd;
+#ifdef STAMP_XD
+  const size_t shmem = glfer::LaunchXD::lds_bytes(NP);
+  auto kern = glfer::spectro16xd_kernel<GLFER_FMT_F32>;
+  const char *names[16] = {"round start", "form z + pass0 butterflies", "pre-write barrier", "writes issued", "post-write barrier",
+                           "reads + tw1 + pass1 + tw2", "", "", "", "cross-lane pass 2 (DPP)", "", "", "", "", "", "accumulate / separate+store"};
+  const int NORD = 7;
+  const int order[11] = {0, 1, 2, 3, 4, 5, 9, 15, 0, 0, 0};
+#else
   const size_t shmem = glfer::LaunchXL<LOGN>::lds_bytes(NP);
   auto kern = glfer::spectro16xl_kernel<LOGN, GLFER_FMT_F32>;
+  const char *names[16] = {"round start", "form z + pass0 butterflies", "pre-write barrier 0", "writes 0 issued", "post-write barrier 0",
+                           "pass1 (reads+twiddle+bfly)", "pre-write barrier 1", "writes 1 issued", "post-write barrier 1",
+                           "pass2 (reads+twiddle+bfly)", "", "", "", "", "", "accumulate / separate+store"};
+  const int NORD = 10;
+  const int order[11] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15};
+#endif
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -85,24 +121,20 @@ int main(int argc, char **argv) {
   }
   std::vector<unsigned long long> st(64 * 16);
   CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
-  const char *names[16] = {"round start", "form z + pass0 butterflies", "pre-write barrier 0", "writes 0 issued", "post-write barrier 0",
-                           "pass1 (reads+twiddle+bfly)", "pre-write barrier 1", "writes 1 issued", "post-write barrier 1",
-                           "pass2 (reads+twiddle+bfly)", "", "", "", "", "", "accumulate / separate+store"};
-  const int order[11] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15};
   double sum[16] = {0};
   int cnt = 0;
   for (int r = 8; r < 56; r++) {                      // steady state
     bool ok = true;
-    for (int i = 0; i < 11; i++) ok = ok && st[r * 16 + order[i]] != 0;
+    for (int i = 0; i <= NORD; i++) ok = ok && st[r * 16 + order[i]] != 0;
     if (!ok) continue;
-    for (int i = 1; i < 11; i++) sum[order[i]] += (double)(st[r * 16 + order[i]] - st[r * 16 + order[i - 1]]);
+    for (int i = 1; i <= NORD; i++) sum[order[i]] += (double)(st[r * 16 + order[i]] - st[r * 16 + order[i - 1]]);
     cnt++;
   }
   double tot = 0;
-  for (int i = 1; i < 11; i++) tot += sum[order[i]] / cnt;
+  for (int i = 1; i <= NORD; i++) tot += sum[order[i]] / cnt;
   printf("wave 0 of block 8, %d rounds averaged (4 full + 1 shared per frame pair); s_memtime ticks.\n"
          "NOTE: stamp 0 reads a counter from memory, so the first interval carries ~2 k ticks of load latency.\n", cnt);
-  for (int i = 1; i < 11; i++) printf("  -> %-28s %9.1f  (%4.1f%%)\n", names[order[i]], sum[order[i]] / cnt, 100.0 * sum[order[i]] / cnt / tot);
+  for (int i = 1; i <= NORD; i++) printf("  -> %-28s %9.1f  (%4.1f%%)\n", names[order[i]], sum[order[i]] / cnt, 100.0 * sum[order[i]] / cnt / tot);
   printf("  round total %.1f ticks; first/last stamp of rounds 8 and 55: %llu .. %llu\n", tot, st[8 * 16], st[55 * 16 + 15]);
   return 0;
 }
