@@ -201,6 +201,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
         o[M / 2] = 4.0f * __builtin_fmaf(zr[r], zr[r], zi[r] * zi[r]);
       }
     }
+    if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();     // mirror entries read: buffer free
     if (!has_next) break;
     fblk = nfblk;
   }

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
         dstp[k] = acc[rho_of(m)] + other;
       });
       if (t == 0) dstp[N / 2] = 2.0f * acc[rho_of(8)];
+      if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();   // fold buffer read: free for the next writes
     }
 
     // ---- shared round: re = sA*(xA*v), im = sB*(xB*v), v the odd taper
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, part[N / 2])), ra, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, partB[N / 2])), rb, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
       }
+      if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();   // mirror entries read: buffer free
     }
     if (!has_next) break;
     fblk = nfblk;

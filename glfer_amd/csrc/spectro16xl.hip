@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
       psd[m] = acc[rho_of(m)] + other;
     });
     nyq = 2.0f * acc[rho_of(8)];
+    if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();     // fold buffer read: free for the next writes
   };
 
   while (true) {                                     // one iteration: frame groups A and B
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, nyqA)), ra, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, nyqB)), rb, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
       }
+      if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();   // mirror entries read: buffer free
     }
     GLFER_STAMP(15);                                 // shared round end (separated, stored)
     if (!has_next) break;

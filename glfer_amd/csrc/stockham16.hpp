@@ -12,6 +12,11 @@
 #ifndef GLFER_STAMP
 #define GLFER_STAMP(id)
 #endif
+// 1: the barrier that frees the exchange buffer sits right after an exchange's reads; 0: in front
+// of the next exchange's writes
+#ifndef GLFER16_BARRIER_AFTER_READS
+#define GLFER16_BARRIER_AFTER_READS 1
+#endif
 
 namespace glfer {
 
@@ -130,15 +135,29 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
         });
       });
     }
-    static_for<0, B>([&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      dit<R, B, b, 16>(zr, zi);
-    });
+    constexpr bool kEmit = GLFER16_BARRIER_AFTER_READS != 0 && i < NPASS - 1 && B == 1;
+    if constexpr (kEmit) {
+      // nothing fences the exchange's writes off from the butterflies that produce them (the
+      // barrier sits after the previous reads): each output goes to LDS as soon as it exists
+      const int k = (int)t & (Ls - 1);
+      const int a0 = ((int)t - k) * R + k;
+      v2f32 *wbase = xb + a0 + (a0 >> 4);
+      constexpr int WS = Ls >= 16 ? Ls + Ls / 16 : 1;
+      dit_emit<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
+        constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
+        wbase[q * WS] = v2f32{zr[reg], zi[reg]};
+      });
+    } else {
+      static_for<0, B>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        dit<R, B, b, 16>(zr, zi);
+      });
+    }
     GLFER_STAMP(4 * i + 1);                // pass i butterflies done
     if constexpr (i < NPASS - 1) {
-      frame_sync<T>();                     // everyone has finished reading the previous exchange
+      if constexpr (GLFER16_BARRIER_AFTER_READS == 0) frame_sync<T>();   // everyone has finished reading the previous exchange
       GLFER_STAMP(4 * i + 2);              // through the pre-write barrier
-      static_for<0, B>([&](auto bc) {
+      if constexpr (!kEmit) static_for<0, B>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
         const int j = (int)t + T * b;
         const int k = j & (Ls - 1);
@@ -165,6 +184,11 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
         zr[m] = v.x;
         zi[m] = v.y;
       });
+      // With the barrier here (the reads have landed: the barrier waits for lgkmcnt(0)) instead
+      // of in front of the next writes, those writes are not fenced off from the butterflies
+      // that produce them and can be issued as their data becomes ready.  The buffer is then
+      // free for ANY writer after this point, including the caller's fold / mirror steps.
+      if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();
     }
   });
 }
