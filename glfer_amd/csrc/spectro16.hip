@@ -23,9 +23,6 @@
 #include <stdint.h>
 #include "stockham16.hpp"
 
-#ifndef GLFER16_LAYOUT
-#define GLFER16_LAYOUT 0      /* 0: +1-per-16 padded exchange; 1: row/natural layouts */
-#endif
 #ifndef GLFER16_STAGGER
 #define GLFER16_STAGGER 8     /* start delay, in s_sleep units, per (blockIdx/256)%4 */
 #endif
@@ -39,9 +36,9 @@ namespace glfer {
 // (frame group, taper pair); the 48 loads of round r+1 (16 samples, 2x16 taper values per
 // lane) are issued right after round r has handed its data to LDS, so they fly under the
 // remaining two passes instead of stalling the next round.
-// ABL (timing ablations for tools/kbench only; results are wrong for ABL != 0):
-//   1 = skip the LDS exchanges and barriers, 2 = skip the butterflies and twiddles, 3 = skip the global gathers
-template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD, int ABL = 0, int LAY = GLFER16_LAYOUT, int STG = GLFER16_STAGGER>
+// (The timing ablations and the alternative exchange layout of the first round of work are kept
+// with tools/experiments/kbench.hip; their results are in profiles/r01_kbench_ablation.txt.)
+template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD, int STG = GLFER16_STAGGER>
 __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(SpectroParams p) {
   using C = Plan16<LOGN>;
   using L = Launch16<LOGN>;
@@ -67,7 +64,8 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
       tw1[k * 17 + q] = q ? tw[(q - 1) * T + k] : v2f32{1.0f, 0.0f};     // slot q-1, lane k (k < 16 <= T)
     }
   }
-  float twr[NTWR > 0 ? NTWR : 1], twi[NTWR > 0 ? NTWR : 1];
+  constexpr int NT = NTWR > 0 ? NTWR : 1;
+  float twr[NT], twi[NT];
   {
     const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.tw) + t;
 #pragma unroll
@@ -91,11 +89,6 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
   float px[16];
   v2f32 pt[16];
   auto prefetch_x = [&](long long fblk) {
-    if constexpr (ABL == 3) {
-#pragma unroll
-      for (int m = 0; m < 16; m++) px[m] = 0.5f + m;
-      return;
-    }
     // Stream index of frame-relative sample j is sblk + flc*H + j with sblk wave-uniform.  The
     // descriptor starts at sample max(sblk,0); samples before the stream (first frames only)
     // get a negative offset -- a huge unsigned one -- and read 0 by the range check: the
@@ -126,11 +119,6 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
     }
   };
   auto prefetch_taps = [&](int pair) {
-    if constexpr (ABL == 3) {
-#pragma unroll
-      for (int m = 0; m < 16; m++) pt[m] = v2f32{0.25f, 0.125f * (float)pair};
-      return;
-    }
     // table layout [pair][m/2][lane][4] = (taper 2p, taper 2p+1) at samples t+T*m and t+T*(m+1):
     // one 16-byte load per lane brings two complex points' worth of tapers (8 loads per round)
     const unsigned tap_p = (unsigned)pair * (N * 8u);              // byte offset of this pair's table (uniform)
@@ -190,131 +178,12 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
     }
     const bool has_next = nfblk < p.nframes;
 
-    // ---- Stockham passes
-    static_for<0, NPASS>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      constexpr int R = C::radix(i), Ls = C::ls(i), B = 16 / R;
-      if constexpr (ABL == 2) {
-      } else if constexpr (i == 1) {
-        // twiddle W_256^(k*q), k = t mod 16, from the shared LDS table
-        static_for<1, 16>([&](auto qc) {
-          constexpr int q = decltype(qc)::value;
-          const v2f32 w = tw1row[q];
-          const float a = zr[q], c = zi[q];
-          zr[q] = __builtin_fmaf(a, w.x, -c * w.y);
-          zi[q] = __builtin_fmaf(a, w.y, c * w.x);
-        });
-      } else if constexpr (i > 1) {
-        // twiddle W_(Ls*R)^(k*q), k = (t + T*b) mod Ls, on input q of butterfly b (register b + B*q)
-        static_for<0, B>([&](auto bc) {
-          constexpr int b = decltype(bc)::value;
-          static_for<1, R>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            constexpr int e = C::tw_offset(i) - TW1 + b * (R - 1) + (q - 1);
-            constexpr int m = b + B * q;
-            const float a = zr[m], c = zi[m];
-            zr[m] = __builtin_fmaf(a, twr[e], -c * twi[e]);
-            zi[m] = __builtin_fmaf(a, twi[e], c * twr[e]);
-          });
-        });
-      }
-      if constexpr (ABL != 2) {
-        static_for<0, B>([&](auto bc) {
-          constexpr int b = decltype(bc)::value;
-          dit<R, B, b, 16>(zr, zi);          // output q' at register b + B*brev(q', R)
-        });
-      }
-      if constexpr (i < NPASS - 1 && ABL == 1) {
-        if constexpr (i == 0) {
-          if (has_next) {
-              prefetch_taps(npair);
-              if (npair == 0) prefetch_x(nfblk);
-            }
-        }
-      } else if constexpr (i < NPASS - 1) {
-        frame_sync<T>();                   // everyone has finished reading the previous exchange
-        // Exchange layouts (8-byte (re,im) entries), both linear in the compile-time index so
-        // every access is base + immediate, and both free of bank conflicts for the 16-lane
-        // ds_write_b64 groups (32 banks) and the 32-lane ds_read_b64 groups (64 banks):
-        //  * after pass 0: row q' (stride T+2), column = producing lane.  The consumer
-        //    j = 16u+k reads row k at columns u + (T/16)*m; (T+2) mod 32 = 2 spreads the 16
-        //    rows a wave touches over distinct bank pairs.
-        //  * after later passes: natural Stockham order a = (j-k)*R + k + q*Ls (Ls >= 16:
-        //    16 consecutive lanes write 16 consecutive entries), read back at t + T*m.
-        if constexpr (LAY == 0) {
-          // +1-per-16 padded index a + a/16: linear in q and m here (q*Ls and T*m are multiples
-          // of 16, or q < 16 on top of a multiple of 16).  Write groups are conflict free; a
-          // 32-lane read group spans 66 dwords, i.e. one 2-way conflict, but consecutive reads
-          // are 2176 B apart, which keeps them single ds_read_b64 (not the slower ds_read2_b64).
-          static_for<0, B>([&](auto bc) {
-            constexpr int b = decltype(bc)::value;
-            const int j = (int)t + T * b;
-            const int k = j & (Ls - 1);
-            const int a0 = (j - k) * R + k;
-            v2f32 *wbase = xb + a0 + (a0 >> 4);
-            constexpr int WS = Ls >= 16 ? Ls + Ls / 16 : 1;
-            static_for<0, R>([&](auto qc) {
-              constexpr int q = decltype(qc)::value;
-              constexpr int src = b + B * brev(q, R);
-              wbase[q * WS] = v2f32{zr[src], zi[src]};
-            });
-          });
-          if constexpr (i == 0) {
-            if (has_next) {
-              prefetch_taps(npair);
-              if (npair == 0) prefetch_x(nfblk);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          frame_sync<T>();
-          const v2f32 *rbase = xb + t + (t >> 4);
-          static_for<0, 16>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            const v2f32 v = rbase[m * (T + T / 16)];
-            zr[m] = v.x;
-            zi[m] = v.y;
-          });
-        } else if constexpr (i == 0) {
-          v2f32 *wbase = xb + t;
-          static_for<0, 16>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            wbase[q * (T + 2)] = v2f32{zr[brev(q, 16)], zi[brev(q, 16)]};
-          });
-          // the prefetch registers are free now: start the next round's loads
-          if (has_next) {
-              prefetch_taps(npair);
-              if (npair == 0) prefetch_x(nfblk);
-            }
-          __builtin_amdgcn_sched_barrier(0);
-          frame_sync<T>();
-          const v2f32 *rbase = xb + (t & 15) * (T + 2) + (t >> 4);
-          static_for<0, 16>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            const v2f32 v = rbase[m * (T / 16)];
-            zr[m] = v.x;
-            zi[m] = v.y;
-          });
-        } else {
-          static_for<0, B>([&](auto bc) {
-            constexpr int b = decltype(bc)::value;
-            const int j = (int)t + T * b;
-            const int k = j & (Ls - 1);
-            v2f32 *wbase = xb + (j - k) * R + k;
-            static_for<0, R>([&](auto qc) {
-              constexpr int q = decltype(qc)::value;
-              constexpr int src = b + B * brev(q, R);
-              wbase[q * Ls] = v2f32{zr[src], zi[src]};
-            });
-          });
-          frame_sync<T>();
-          const v2f32 *rbase = xb + t;
-          static_for<0, 16>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            const v2f32 v = rbase[m * T];
-            zr[m] = v.x;
-            zi[m] = v.y;
-          });
-        }
+    // ---- Stockham passes (stockham16.hpp); the next round's loads go out after the first
+    // exchange's writes: the prefetch registers are free by then
+    stockham16_passes<LOGN, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
+      if (has_next) {
+        prefetch_taps(npair);
+        if (npair == 0) prefetch_x(nfblk);
       }
     });
 
@@ -364,6 +233,7 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
         }
         if (t == 0) o[N / 2] = 2.0f * fold[N / 2];
       }
+      if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();   // fold buffer read: free for the next writes
     }
     if (!has_next) break;
     fblk = nfblk;
