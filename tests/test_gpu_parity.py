@@ -85,6 +85,46 @@ def test_baseline_configs_vs_oracle(lib, oracle, torch_cuda, cfg, seed):
     assert worst < TOL, worst
 
 
+@pytest.mark.parametrize("n,overlap,kmax,nw,sub_mean,history_mode,fmt,frames", [
+    (4096, 0.75, 4, 2.5, 1, 0, "f32", 71),      # spectro16xl: odd tapers, LDS tables; mean removal + overlap
+    (4096, 0.5, 4, 2.5, 0, 1, "s16", 37),       # history zeroed in every frame, PCM input, odd frame count
+    (4096, 0.9, 2, 2.0, 0, 0, "u8", 65),        # 3 tapers, hop 409 (odd), many early frames
+    (4096, 0.0, 8, 4.5, 0, 0, "f32", 33),       # 9 tapers: tables too big for LDS -> spectro16x
+    (1024, 0.5, 4, 2.5, 1, 1, "f32", 203),      # several frames per block, both options at once
+    (512, 0.33, 6, 4.0, 0, 0, "s16", 150),      # 7 tapers, odd hop
+    (256, 0.0, 2, 1.5, 0, 0, "f32", 97),        # smallest block: 16 frames per block
+    (2048, 0.25, 4, 2.5, 0, 0, "f32", 40),      # N = 2048: xl only (x spills there)
+    (8192, 0.5, 4, 2.5, 1, 0, "f32", 9),        # N >= 8192: packed kernel
+    (4096, 0.75, 3, 2.5, 0, 0, "f32", 50),      # even taper count: packed kernel
+])
+def test_multitaper_kernel_forms_vs_oracle(lib, oracle, torch_cuda, n, overlap, kmax, nw, sub_mean, history_mode, fmt, frames):
+    """Every multitaper kernel form (packed / shared odd taper / LDS-resident tables), with the
+    options that change the gather (overlap, per-hop mean removal, history zeroed in every frame,
+    PCM formats, odd hops, partial frame groups), frame by frame against the oracle."""
+    h = oracle.hop(n, overlap)
+    x = synth(frames * h + 3, seed=n + kmax) + np.float32(0.05)
+    if fmt == "s16":
+        raw = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16)
+        xf, sf = oracle.pcm_s16_to_float(raw), lib.SAMPLES_S16
+    elif fmt == "u8":
+        raw = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8)
+        xf, sf = oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
+    else:
+        raw, xf, sf = x, x, lib.SAMPLES_F32
+    want = oracle.spectrogram_mtm(xf.copy(), n, overlap, nw, kmax, sub_mean=sub_mean, history_mode=history_mode)
+    sp = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=sub_mean,
+                                       history_mode=history_mode, sample_format=sf))
+    got = sp.run(torch_cuda.from_numpy(raw).cuda()).cpu().numpy()
+    assert got.shape == want.shape == (frames, n // 2 + 1)
+    for f in range(frames):
+        assert np.abs(got[f] - want[f]).max() <= TOL * want[f].max(), f
+    # a launch that starts and ends inside frame groups gives the same rows
+    first, count = 5, frames - 8
+    part = sp.run(torch_cuda.from_numpy(raw).cuda(), first_frame=first, nframes=count).cpu().numpy()
+    for f in range(count):
+        assert np.abs(part[f] - want[first + f]).max() <= TOL * want[first + f].max(), f
+
+
 @pytest.mark.parametrize("window", ["hanning", "blackman", "gaussian", "welch", "bartlett", "rectangular",
                                     "hamming", "kaiser"])
 def test_all_windows(lib, oracle, torch_cuda, window):
