@@ -172,7 +172,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch, rocprofv3 PMC (profiles/r01_hbm_traffic*.json)",
                          "algorithmic_bytes_per_launch": frames * b_alg,
-                         "kernel": {"hparma": "hparma_kernel", "fft": "spectro16h_kernel<12>", "mtm": "spectro16xl_kernel<12>"}[args.workload],
+                         "kernel": {"hparma": "hparma_kernel", "fft": "spectro16h_kernel<12>", "mtm": "spectro16y_kernel"}[args.workload],
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_frame": b_alg,
                          "note": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac"},

@@ -442,6 +442,7 @@ static hipError_t launch_real_input(const SpectroParams &sp, int n, hipStream_t 
 }
 
 static hipError_t launch_shared_odd(const SpectroParams &sp, int n, hipStream_t st) {
+  if (n == 4096) return glfer_launch_spectro16y_n12(&sp, st);   // two frames interleaved per wavefront
   if (sp.ltaps) {                      // taper half tables resident in LDS
     switch (n) {
       case 256: return glfer_launch_spectro16xl_n8(&sp, st);
@@ -463,7 +464,9 @@ static hipError_t launch_shared_odd(const SpectroParams &sp, int n, hipStream_t 
 // Kernel choice.  spectro16.hip (two tapers packed per N-point transform) does everything; two
 // specialisations take the frames that lie wholly inside the stream when they apply:
 //   * one taper, PSD only      -> spectro16h.hip, real-input N/2-point transform
-//   * odd taper count >= 3     -> spectro16x.hip, last taper shared by two frames
+//   * odd taper count >= 3     -> last taper shared by two frames: spectro16y.hip (N = 4096, the two
+//                                 frames interleaved per wavefront), spectro16xl.hip (taper half
+//                                 tables in LDS, when they fit), spectro16x.hip otherwise
 // The first ceil(R/H) frames of a stream reach back before sample 0 (zero history, fft.c:103-108);
 // they stay with spectro16.hip, which has the range-checked gather for that.
 static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {

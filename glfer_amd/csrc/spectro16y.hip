@@ -1,0 +1,302 @@
+// spectro16y.hip -- multitaper, odd taper count, N = 4096: the two frames that share their last
+// taper's transform (spectro16x.hip) are also carried through the full rounds TOGETHER, interleaved
+// in every wavefront (stockham16_passes2): while frame A's exchange writes drain through the LDS
+// pipe the wavefront does frame B's butterflies, and every workgroup barrier serves both frames.
+//
+// tools/stampbench on the one-frame-at-a-time kernels: a round is ~36 % butterflies, ~37 % waiting
+// to issue the 2x16 ds_write_b64 of the two exchanges (all four wavefronts of a frame burst into
+// the LDS pipe at the same moment, 80 B/clk) and ~28 % barriers; more resident blocks do not help
+// (2 and 3 per CU measure the same).  Here the overlap is built into the instruction stream.
+//
+// Both frames use the same taper pair in the same round, so one set of 32 prefetch VGPRs serves
+// both; per lane: 2x32 transform registers, 2x16 accumulators, 2x16 samples, 32 taper values,
+// 30 twiddles -- 256 VGPRs, 2 blocks (8 wavefronts) per CU, two 35 KB exchange buffers per block.
+// Per frame the arithmetic is exactly spectro16x.hip's (same pairing, same scales), so the rows are
+// bit-identical to it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "stockham16.hpp"
+
+#ifndef GLFER_PSD_STORE_AUX
+#define GLFER_PSD_STORE_AUX 2      /* non-temporal: PSD rows are written once, never re-read here */
+#endif
+
+namespace glfer {
+
+struct LaunchY {
+  static constexpr int N = 4096, T = 256, PADN = N + N / 16;
+  static constexpr int LDS_WORDS = 2 * PADN + 16 * 17 + 4;       // two exchange buffers, pass-1 twiddles, power partials
+};
+
+template <int FMT>
+__global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
+  using C = Plan16<12>;
+  using L = LaunchY;
+  constexpr int N = L::N, T = L::T, PADN = L::PADN, NPASS = C::NPASS;
+  constexpr int TW1 = 15;
+  constexpr int NT = C::NTW - TW1;
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  typedef float v4f32 __attribute__((ext_vector_type(4)));
+  extern __shared__ v2f32 lds[];                    // L::LDS_WORDS entries (72 KB: above the static limit)
+
+  const unsigned t = threadIdx.x;
+  v2f32 *xbA = lds, *xbB = lds + PADN;
+  v2f32 *tw1 = lds + 2 * PADN;
+  float *red = reinterpret_cast<float *>(lds + 2 * PADN + 16 * 17);   // [2][4]
+
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.tw);
+    const unsigned k = t >> 4, q = t & 15;
+    tw1[k * 17 + q] = q ? tw[(q - 1) * T + k] : v2f32{1.0f, 0.0f};
+  }
+  float twr[NT], twi[NT];
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.tw) + t;
+#pragma unroll
+    for (int e = 0; e < NT; e++) {
+      const v2f32 w = tw[(TW1 + e) * T];
+      twr[e] = w.x;
+      twi[e] = w.y;
+    }
+  }
+  __syncthreads();
+  const v2f32 *tw1row = tw1 + (t & 15) * 17;
+
+  const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.taps), 0, p.npairs * 2 * N * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.xtaps), 0, N * 4, 0x00020000);
+  const unsigned toff = t * 16u;
+  const int NP = p.npairs - 1;                       // full (two-taper) rounds per frame
+  const long long stride = (long long)gridDim.x * 2;
+
+  // Samples of frame f.  Only frames wholly inside the stream reach this kernel (the launcher
+  // sends a stream's first ceil(R/H) frames to spectro16.hip), so every load is in range.
+  auto load_x = [&](float (&dst)[16], long long f) {
+    const long long sblk = (p.frame0 + f) * (long long)p.H - p.R;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      dst[m] = buf_sample<FMT>(xrsrc, t * esz, (unsigned)(T * m) * esz);
+    });
+    if (p.history_mode) {                            // fft.c:103-108 with glfer.first_buffer stuck at TRUE
+      const int d = (int)t - p.R;
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        dst[m] = (d >= -T * m) ? dst[m] : 0.0f;
+      });
+    }
+  };
+  v2f32 pt[16];          // full round: the next taper pair; shared round: pt[0..7] = the last taper
+  auto prefetch_taps = [&](int pair) {
+    const unsigned tap_p = (unsigned)pair * (N * 8u);
+    static_for<0, 8>([&](auto mc) {
+      constexpr int mh = decltype(mc)::value;
+      const v4f32 q = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(trsrc, toff, tap_p + (unsigned)(T * mh) * 16u, 0));
+      pt[2 * mh] = v2f32{q.x, q.y};
+      pt[2 * mh + 1] = v2f32{q.z, q.w};
+    });
+  };
+  auto prefetch_last = [&] {                         // [m/4][T][4] floats: samples t + T*(4*(m/4) + j)
+    static_for<0, 4>([&](auto mc) {
+      constexpr int mq = decltype(mc)::value;
+      const v4f32 q = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, toff, (unsigned)(T * mq) * 16u, 0));
+      pt[2 * mq] = v2f32{q.x, q.y};
+      pt[2 * mq + 1] = v2f32{q.z, q.w};
+    });
+  };
+
+  long long fA = (long long)xcd_block_index() * 2;
+  if (fA >= p.nframes) return;
+  float xA[16], xB[16];
+  load_x(xA, fA);
+  if (fA + 1 < p.nframes) load_x(xB, fA + 1);
+  else {
+#pragma unroll
+    for (int m = 0; m < 16; m++) xB[m] = 0.0f;
+  }
+  prefetch_taps(0);
+
+  constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
+  auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };   // register of bin t + T*m
+  constexpr int kSilent = 0x7fff;
+
+  while (true) {                                     // one iteration: frames A = fA and B = fA + 1
+    const bool hasB = fA + 1 < p.nframes;            // block-uniform
+    const long long nfA = fA + stride;
+    const bool has_next = nfA < p.nframes;
+    float psdA[8], psdB[8], nyqA, nyqB;
+    int hxA, hxB;
+    {
+      float accA[16], accB[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) accA[r] = accB[r] = 0.0f;
+      for (int pair = 0; pair < NP; pair++) {
+        // ---- one full round of both frames: re = x*taper(2*pair), im = x*taper(2*pair+1)
+        float zrA[16], ziA[16], zrB[16], ziB[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          zrA[m] = xA[m] * pt[m].x;
+          ziA[m] = xA[m] * pt[m].y;
+          zrB[m] = xB[m] * pt[m].x;
+          ziB[m] = xB[m] * pt[m].y;
+        }
+        stockham16_passes2<12, NT>(zrA, ziA, xbA, zrB, ziB, xbB, t, tw1row, twr, twi, [&] {
+          if (pair + 1 < NP) prefetch_taps(pair + 1);
+          else prefetch_last();
+        });
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          accA[r] = __builtin_fmaf(zrA[r], zrA[r], __builtin_fmaf(ziA[r], ziA[r], accA[r]));
+          accB[r] = __builtin_fmaf(zrB[r], zrB[r], __builtin_fmaf(ziB[r], ziB[r], accB[r]));
+        }
+      }
+      // ---- mirror fold psd[k] = acc[k] + acc[N-k] of both frames (upper half through LDS, entry
+      // k - N/2) and the frames' powers for the shared round's scales
+      float eA = 0.0f, eB = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        eA += accA[r];
+        eB += accB[r];
+      }
+#pragma unroll
+      for (int w = 1; w < 64; w <<= 1) {
+        eA += __shfl_xor(eA, w);
+        eB += __shfl_xor(eB, w);
+      }
+      float *foldA = reinterpret_cast<float *>(xbA), *foldB = reinterpret_cast<float *>(xbB);
+      static_for<8, 16>([&](auto mc) {               // the buffers are free: barrier after the last reads
+        constexpr int m = decltype(mc)::value;
+        foldA[t + T * (m - 8)] = accA[rho_of(m)];
+        foldB[t + T * (m - 8)] = accB[rho_of(m)];
+      });
+      if ((t & 63) == 0) {
+        red[t >> 6] = eA;
+        red[4 + (t >> 6)] = eB;
+      }
+      __syncthreads();
+      eA = (red[0] + red[1]) + (red[2] + red[3]);
+      eB = (red[4] + red[5]) + (red[6] + red[7]);
+      int ex = __builtin_amdgcn_frexp_expf(eA);      // 0 for e = 0, inf, nan
+      ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
+      hxA = eA == 0.0f ? kSilent : ex >> 1;          // digital silence stays exactly 0 (scale 0)
+      ex = __builtin_amdgcn_frexp_expf(eB);
+      ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
+      hxB = eB == 0.0f ? kSilent : ex >> 1;
+      static_for<0, 8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const int k = T * m + (int)t;
+        float oa = foldA[N / 2 - k], ob = foldB[N / 2 - k];   // acc[N-k]; entry N/2 (k = 0) is never written
+        if constexpr (m == 0) {
+          if (t == 0) {
+            oa = accA[rho_of(0)];
+            ob = accB[rho_of(0)];
+          }
+        }
+        psdA[m] = accA[rho_of(m)] + oa;
+        psdB[m] = accB[rho_of(m)] + ob;
+      });
+      nyqA = 2.0f * accA[rho_of(8)];
+      nyqB = 2.0f * accB[rho_of(8)];
+      __syncthreads();                               // fold buffers read: free for the next writes
+    }
+
+    // ---- shared round: re = sA*(xA*v), im = sB*(xB*v), v the last taper
+    float zr[16], zi[16];
+    {
+      const float sA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxA);
+      const float sB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxB);
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        const float v = (m & 1) ? pt[m / 2].y : pt[m / 2].x;
+        zr[m] = (xA[m] * v) * sA;
+        zi[m] = hasB ? (xB[m] * v) * sB : 0.0f;
+      }
+    }
+    // the next iteration's samples and first taper pair go out after the first exchange's writes
+    stockham16_passes<12, NT>(zr, zi, xbA, t, tw1row, twr, twi, [&] {
+      if (has_next) {
+        prefetch_taps(0);
+        load_x(xA, nfA);
+        if (nfA + 1 < p.nframes) load_x(xB, nfA + 1);
+      }
+    });
+    // separate the two spectra through the mirror pairs (k, N-k): E = Z[k] + conj Z[N-k] = 2 sA Y_A[k],
+    // O = Z[k] - conj Z[N-k] = 2i sB Y_B[k].  Z[k], k >= N/2, goes through LDS (entry k - N/2).
+    static_for<8, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int r = rho_of(m);
+      xbA[t + T * (m - 8)] = v2f32{zr[r], zi[r]};
+    });
+    __syncthreads();
+    {
+      constexpr unsigned ROWB = (N / 2 + 1) * 4u;
+      // a frame past the last one has no records: its stores are dropped by the range check
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)fA * (N / 2 + 1), 0, ROWB, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)(fA + (hasB ? 1 : 0)) * (N / 2 + 1), 0, hasB ? ROWB : 0u, 0x00020000);
+      const unsigned voff = t * 4u;
+      const float uA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxA);
+      const float uB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxB);
+      static_for<0, 8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int r = rho_of(m);
+        const int k = (int)t + T * m;
+        v2f32 b = xbA[N / 2 - k];                    // Z[N-k]; entry N/2 (k = 0) is never written
+        const float ar = zr[r], ai = zi[r];
+        if constexpr (m == 0) {
+          if (t == 0) b = v2f32{ar, ai};             // k = 0 pairs with itself
+        }
+        const float er = ar + b.x, ei = ai - b.y, orr = ar - b.x, oi = ai + b.y;
+        const float pa = __builtin_fmaf(er, er, ei * ei), pb = __builtin_fmaf(orr, orr, oi * oi);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pa, uA, psdA[m])), ra, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pb, uB, psdB[m])), rb, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
+      });
+      if (t == 0) {                                  // k = N/2 pairs with itself: E = 2 Re Z, O = 2i Im Z
+        constexpr int r = rho_of(8);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, nyqA)), ra, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, nyqB)), rb, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
+      }
+    }
+    __syncthreads();                                 // mirror entries read: buffer free
+    if (!has_next) break;
+    fA = nfA;
+    if (fA + 1 >= p.nframes) {
+#pragma unroll
+      for (int m = 0; m < 16; m++) xB[m] = 0.0f;
+    }
+  }
+}
+
+}  // namespace glfer
+
+#ifndef GLFER_NO_LAUNCHERS
+using namespace glfer;
+
+template <int FMT>
+static hipError_t launch16y_fmt(const SpectroParams &p, hipStream_t st) {
+  const long long work = ((long long)p.nframes + 1) / 2;
+  if (work == 0) return hipSuccess;
+  const long long resident = 256LL * 2;
+  unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
+  if (grid >= 64) grid &= ~7u;                       // whole XCD slices: see xcd_block_index()
+  auto kern = spectro16y_kernel<FMT>;
+  constexpr size_t shmem = (size_t)LaunchY::LDS_WORDS * 8;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, st, p);
+  return hipGetLastError();
+}
+
+// N = 4096, odd taper counts >= 3; needs p->xtaps (glfer_hip.cpp builds it)
+extern "C" hipError_t glfer_launch_spectro16y_n12(const SpectroParams *p, hipStream_t st) {
+  if (!p->xtaps || p->npairs < 2 || p->nonlin || p->spec) return hipErrorInvalidValue;
+  if (p->frame0 * (long long)p->H < (long long)p->R) return hipErrorInvalidValue;   // no zero-history path here
+  switch (p->fmt) {
+    case GLFER_FMT_F32: return launch16y_fmt<GLFER_FMT_F32>(*p, st);
+    case GLFER_FMT_S16: return launch16y_fmt<GLFER_FMT_S16>(*p, st);
+    case GLFER_FMT_U8: return launch16y_fmt<GLFER_FMT_U8>(*p, st);
+  }
+  return hipErrorInvalidValue;
+}
+#endif  // GLFER_NO_LAUNCHERS

@@ -53,6 +53,7 @@ hipError_t glfer_launch_spectro16xl_n9(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16xl_n10(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16xl_n11(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16xl_n12(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16y_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n9(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n10(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n11(const SpectroParams *p, hipStream_t st);

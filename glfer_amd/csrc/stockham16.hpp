@@ -193,4 +193,85 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
   });
 }
 
+// Two transforms (two frames, two exchange buffers) interleaved in one wavefront: in every phase
+// between barriers the wavefront first does stream A's butterflies -- its exchange writes leave
+// from inside the last butterfly stage -- and then stream B's, so A's writes drain through the LDS
+// pipe under B's arithmetic, and each barrier serves both transforms (4 per pair of transforms
+// instead of 8).  Same arithmetic per stream as stockham16_passes; requires the
+// barrier-after-reads scheme and radix-16 passes in front of every exchange.
+template <int LOGM, int NT, class Hook>
+__device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA)[16], v2f32 *xbA, float (&zrB)[16],
+                                                   float (&ziB)[16], v2f32 *xbB, unsigned t, const v2f32 *tw1row,
+                                                   const float (&twr)[NT], const float (&twi)[NT],
+                                                   Hook &&after_first_write) {
+  using C = Plan16<LOGM>;
+  constexpr int T = C::T, NPASS = C::NPASS, TW1 = 15;
+  static_assert(GLFER16_BARRIER_AFTER_READS != 0, "stockham16_passes2 relies on the barrier-after-reads scheme");
+  static_for<0, NPASS>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int R = C::radix(i), Ls = C::ls(i), B = 16 / R;
+    auto compute = [&](float (&zr)[16], float (&zi)[16], v2f32 *xb) {
+      if constexpr (i == 1) {
+        static_for<1, 16>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const v2f32 w = tw1row[q];
+          const float a = zr[q], c = zi[q];
+          zr[q] = __builtin_fmaf(a, w.x, -c * w.y);
+          zi[q] = __builtin_fmaf(a, w.y, c * w.x);
+        });
+      } else if constexpr (i > 1) {
+        static_for<0, B>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          static_for<1, R>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int e = C::tw_offset(i) - TW1 + b * (R - 1) + (q - 1);
+            constexpr int m = b + B * q;
+            const float a = zr[m], c = zi[m];
+            zr[m] = __builtin_fmaf(a, twr[e], -c * twi[e]);
+            zi[m] = __builtin_fmaf(a, twi[e], c * twr[e]);
+          });
+        });
+      }
+      if constexpr (i < NPASS - 1) {
+        static_assert(B == 1, "an exchange follows radix-16 passes only");
+        const int k = (int)t & (Ls - 1);
+        const int a0 = ((int)t - k) * R + k;
+        v2f32 *wbase = xb + a0 + (a0 >> 4);
+        constexpr int WS = Ls >= 16 ? Ls + Ls / 16 : 1;
+        dit_emit<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
+          constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
+          wbase[q * WS] = v2f32{zr[reg], zi[reg]};
+        });
+      } else {
+        static_for<0, B>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          dit<R, B, b, 16>(zr, zi);
+        });
+      }
+    };
+    compute(zrA, ziA, xbA);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(zrB, ziB, xbB);
+    if constexpr (i < NPASS - 1) {
+      if constexpr (i == 0) after_first_write();
+      __builtin_amdgcn_sched_barrier(0);
+      frame_sync<T>();                       // both streams' writes are in LDS
+      const v2f32 *ra = xbA + t + (t >> 4), *rb = xbB + t + (t >> 4);
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const v2f32 v = ra[m * (T + T / 16)];
+        zrA[m] = v.x;
+        ziA[m] = v.y;
+      });
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const v2f32 v = rb[m * (T + T / 16)];
+        zrB[m] = v.x;
+        ziB[m] = v.y;
+      });
+      frame_sync<T>();                       // both buffers read: free for the next writes
+    }
+  });
+}
+
 }  // namespace glfer
