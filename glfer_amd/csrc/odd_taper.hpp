@@ -1,0 +1,108 @@
+// odd_taper.hpp -- what the three kernels for odd taper counts (spectro16x / xl / y) have in common:
+// the in-stream gather of a frame, the power-of-two scale of a frame entering the shared transform,
+// and the separation of the shared transform into the two frames' PSD rows.
+#pragma once
+#include "stockham16.hpp"
+
+#ifndef GLFER_PSD_STORE_AUX
+#define GLFER_PSD_STORE_AUX 2      /* non-temporal: PSD rows are written once, never re-read by the kernel */
+#endif
+
+namespace glfer {
+
+// The 16 samples t + T*m of frame (fblk + fl) of the launch.  Only frames that lie wholly inside
+// the stream reach these kernels (the launcher sends a stream's first ceil(R/H) frames to
+// spectro16.hip, which has the zero-history gather), so every load is in range: one shared VGPR
+// offset + immediates.  history_mode 1 (fft.c:103-108 with glfer.first_buffer stuck at TRUE) zeroes
+// the first R samples of every frame afterwards.  A frame slot past the last frame re-reads the
+// last one (its results are dropped).
+template <int FMT, int T>
+__device__ __forceinline__ void load_frame16(const SpectroParams &p, unsigned t, unsigned fl, long long fblk, float (&dst)[16]) {
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  const long long f = fblk + fl;
+  const unsigned flc = f < p.nframes ? fl : (unsigned)(p.nframes - 1 - fblk);
+  const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
+  const unsigned lrel = flc * (unsigned)p.H + t;
+  static_for<0, 16>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    dst[m] = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(T * m) * esz);
+  });
+  if (p.history_mode) {
+    const int d = (int)t - p.R;
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      dst[m] = (d >= -T * m) ? dst[m] : 0.0f;
+    });
+  }
+}
+
+// A frame enters the shared transform scaled by 2^-hx, hx = half the binary exponent of its power
+// summed over the tapers already done, so that both halves of the transform have the same
+// magnitude and each frame sees the rounding of a transform of its own size.  A frame whose power
+// is exactly 0 (digital silence) must stay exactly 0, as in the reference, whatever its partner's
+// rounding leaves in the shared transform: scale 0 (kSilent).
+constexpr int kSilent = 0x7fff;
+__device__ __forceinline__ int scale_exponent(float power) {
+  int ex = __builtin_amdgcn_frexp_expf(power);       // 0 for 0, inf, nan
+  ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
+  return power == 0.0f ? kSilent : ex >> 1;
+}
+__device__ __forceinline__ float scale_in(int hx) { return hx == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hx); }
+__device__ __forceinline__ float scale_out(int hx) { return hx == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hx); }
+
+// After the shared transform Z = FFT(sA*yA + i*sB*yB) (register b + B*brev(q',R) of lane t holds bin
+// t + T*(b + B*q')): the mirror pairs (k, N-k) give E = Z[k] + conj Z[N-k] = 2 sA Y_A[k] and
+// O = Z[k] - conj Z[N-k] = 2i sB Y_B[k]; |E|^2/sA^2 and |O|^2/sB^2 (the 1/4 is folded into the
+// taper) are added to the frames' folded sums and stored.  Z[k], k >= N/2, goes through LDS
+// (entry k - N/2 of xb); the lane keeps its own Z[k], k < N/2.  xb is free again on return.  sumA(mc) / sumB(mc): the folded sum of bin t + T*m,
+// m = 0..7 as a compile-time constant, m = 8 standing for bin N/2 (lane 0 only).
+// Rows go out through buffer descriptors: one shared VGPR offset plus SGPR/immediate offsets, and
+// frame slots past the last frame fall outside num_records, so their stores are dropped.
+template <int LOGN, int FPB, class SumA, class SumB>
+__device__ __forceinline__ void separate_and_store(const SpectroParams &p, const float (&zr)[16], const float (&zi)[16],
+                                                   v2f32 *xb, unsigned t, unsigned fl, long long fblk, int hxA, int hxB,
+                                                   SumA &&sumA, SumB &&sumB) {
+  using C = Plan16<LOGN>;
+  constexpr int N = C::N, T = C::T, RL = C::radix(C::NPASS - 1), BL = 16 / RL;
+  auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };
+  if constexpr (GLFER16_BARRIER_AFTER_READS == 0) frame_sync<T>();      // else the passes left xb free
+  static_for<8, 16>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    constexpr int r = rho_of(m);
+    xb[t + T * (m - 8)] = v2f32{zr[r], zi[r]};
+  });
+  frame_sync<T>();
+  constexpr unsigned ROWB = (N / 2 + 1) * 4u;
+  const long long leftA = p.nframes - fblk, leftB = p.nframes - (fblk + FPB);
+  const unsigned recA = (unsigned)((leftA > FPB ? FPB : leftA) * (long long)ROWB);
+  const unsigned recB = leftB > 0 ? (unsigned)((leftB > FPB ? FPB : leftB) * (long long)ROWB) : 0u;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)fblk * (N / 2 + 1), 0, recA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)(fblk + (leftB > 0 ? FPB : 0)) * (N / 2 + 1), 0, recB, 0x00020000);
+  const unsigned voff = fl * ROWB + t * 4u;
+  const float uA = scale_out(hxA), uB = scale_out(hxB);
+  static_for<0, 8>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    constexpr int r = rho_of(m);
+    const int k = (int)t + T * m;
+    v2f32 b = xb[N / 2 - k];                          // Z[N-k]; entry N/2 (k = 0) is never written
+    const float ar = zr[r], ai = zi[r];
+    if constexpr (m == 0) {
+      if (t == 0) b = v2f32{ar, ai};                  // k = 0 pairs with itself
+    }
+    const float er = ar + b.x, ei = ai - b.y, orr = ar - b.x, oi = ai + b.y;
+    const float pa = __builtin_fmaf(er, er, ei * ei), pb = __builtin_fmaf(orr, orr, oi * oi);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pa, uA, sumA(mc))), ra, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pb, uB, sumB(mc))), rb, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
+  });
+  if (t == 0) {                                       // k = N/2 pairs with itself: E = 2 Re Z, O = 2i Im Z
+    constexpr int r = rho_of(8);
+    constexpr std::integral_constant<int, 8> nyq{};
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, sumA(nyq))), ra, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, sumB(nyq))), rb, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
+  }
+  frame_sync<T>();                                    // mirror entries read: xb is free again
+}
+
+}  // namespace glfer

@@ -20,13 +20,8 @@
 // acc is dead outside a group's full rounds, psdB outside group B's fold .. the shared round.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "stockham16.hpp"
+#include "odd_taper.hpp"
 
-// PSD rows are written once and never read by this kernel: non-temporal stores (aux bit 1 = nt) keep
-// them from displacing the sample stream in L2, which the shared round re-reads
-#ifndef GLFER_PSD_STORE_AUX
-#define GLFER_PSD_STORE_AUX 2
-#endif
 #ifndef GLFER16X_WAVES_PER_SIMD
 #define GLFER16X_WAVES_PER_SIMD 3
 #endif
@@ -96,30 +91,7 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
 
   float px[16];          // samples of the frame group in work (A, then B)
   v2f32 pt[16];          // next full round: taper pair; shared round: pt[0..7] = the odd taper, pt[8..15] = group A's samples
-  // Loads the 16 samples of frame (fblk + fl) into dst[0..15].  The launcher hands this kernel
-  // only frames that lie wholly inside the stream ((frame0+f)*H >= R; the first ceil(R/H) frames
-  // of a stream go to spectro16.hip, which has the zero-history gather), so every load is in
-  // range: one shared VGPR offset + immediates.  history_mode 1 (fft.c:103-108 with
-  // glfer.first_buffer stuck at TRUE) zeroes the first R samples of every frame afterwards.
-  auto load_x = [&](float (&dst)[16], long long fblk) {
-    const long long f = fblk + fl;
-    const unsigned flc = f < p.nframes ? fl : (unsigned)(p.nframes - 1 - fblk);   // clamp: loads stay in range
-    const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
-    const unsigned lrel = flc * (unsigned)p.H + t;
-    static_for<0, 16>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      dst[m] = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(T * m) * esz);
-    });
-    if (p.history_mode) {
-      const int d = (int)t - p.R;
-      static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        dst[m] = (d >= -T * m) ? dst[m] : 0.0f;
-      });
-    }
-  };
+  auto load_x = [&](float (&dst)[16], long long fblk) { load_frame16<FMT, T>(p, t, fl, fblk, dst); };
   auto prefetch_taps = [&](int pair) {
     const unsigned tap_p = (unsigned)pair * (N * 8u);
     static_for<0, 8>([&](auto mc) {
@@ -157,7 +129,6 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
     const int ngroups = hasB ? 2 : 1;
     const long long nfblk = fblk + stride;
     const bool has_next = nfblk < p.nframes;
-    constexpr int kSilent = 0x7fff;
     int hxA = 0, hxB = 0;          // scale into the shared round = 2^-hx, chosen from the frame's power
 
     for (int which = 0; which < ngroups; which++) {
@@ -212,13 +183,8 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
 #pragma unroll
         for (int w = 0; w < WPF; w++) e += red[fl * WPF + w];
       }
-      int ex = __builtin_amdgcn_frexp_expf(e);                 // 0 for e = 0, inf, nan
-      ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
-      // a frame whose power is exactly 0 (digital silence) must stay exactly 0, as in the
-      // reference, whatever its partner's rounding leaves in the shared transform: scale 0
-      const int hx = e == 0.0f ? kSilent : ex >> 1;
-      if (which == 0) hxA = hx;
-      else hxB = hx;
+      if (which == 0) hxA = scale_exponent(e);
+      else hxB = scale_exponent(e);
       float *dstp = part + which * (FPB * L::PART);
       static_for<0, 8>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
@@ -236,8 +202,7 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
     // ---- shared round: re = sA*(xA*v), im = sB*(xB*v), v the odd taper
     {
       float zr[16], zi[16];
-      const float sA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxA);
-      const float sB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxB);
+      const float sA = scale_in(hxA), sB = scale_in(hxB);
 #pragma unroll
       for (int m = 0; m < 16; m++) {
         const float v = (m & 1) ? pt[m / 2].y : pt[m / 2].x;
@@ -251,48 +216,10 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
           load_x(px, nfblk);
         }
       });
-      // separate the two spectra through the mirror pairs (k, N-k).  Z[k] for k >= N/2 goes
-      // through LDS (entry k - N/2); the lane keeps its own Z[k], k < N/2.
-      frame_sync<T>();
-      static_for<8, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        constexpr int r = rho_of(m);
-        xb[t + T * (m - 8)] = v2f32{zr[r], zi[r]};
-      });
-      frame_sync<T>();
-      // rows of the two frame groups through buffer descriptors: one shared VGPR offset plus
-      // SGPR/immediate offsets (no per-store address VGPRs), and rows past the last frame fall
-      // outside num_records, so their stores are dropped by the range check
-      constexpr unsigned ROWB = (N / 2 + 1) * 4u;
-      const long long leftA = p.nframes - fblk, leftB = p.nframes - (fblk + FPB);
-      const unsigned recA = (unsigned)((leftA > FPB ? FPB : leftA) * (long long)ROWB);
-      const unsigned recB = leftB > 0 ? (unsigned)((leftB > FPB ? FPB : leftB) * (long long)ROWB) : 0u;
-      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)fblk * (N / 2 + 1), 0, recA, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)(fblk + (leftB > 0 ? FPB : 0)) * (N / 2 + 1), 0, recB, 0x00020000);
-      const unsigned voff = fl * ROWB + t * 4u;
-      const float uA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxA);
-      const float uB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxB);
       const float *partB = part + FPB * L::PART;
-      static_for<0, 8>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        constexpr int r = rho_of(m);
-        const int k = (int)t + T * m;
-        v2f32 b = xb[N / 2 - k];                        // Z[N-k]; entry N/2 (k = 0) is never written
-        const float ar = zr[r], ai = zi[r];
-        if constexpr (m == 0) {
-          if (t == 0) b = v2f32{ar, ai};                // k = 0 pairs with itself
-        }
-        const float er = ar + b.x, ei = ai - b.y, orr = ar - b.x, oi = ai + b.y;
-        const float pa = __builtin_fmaf(er, er, ei * ei), pb = __builtin_fmaf(orr, orr, oi * oi);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pa, uA, part[k])), ra, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pb, uB, partB[k])), rb, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
-      });
-      if (t == 0) {                                     // k = N/2 pairs with itself: E = 2 Re Z, O = 2i Im Z
-        constexpr int r = rho_of(8);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, part[N / 2])), ra, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, partB[N / 2])), rb, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
-      }
-      if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();   // mirror entries read: buffer free
+      separate_and_store<LOGN, FPB>(p, zr, zi, xb, t, fl, fblk, hxA, hxB,
+                                    [&](auto mc) { return part[decltype(mc)::value == 8 ? N / 2 : T * decltype(mc)::value + (int)t]; },
+                                    [&](auto mc) { return partB[decltype(mc)::value == 8 ? N / 2 : T * decltype(mc)::value + (int)t]; });
     }
     if (!has_next) break;
     fblk = nfblk;

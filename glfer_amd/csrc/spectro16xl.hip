@@ -16,11 +16,7 @@
 // their peak (they are, to rounding; the check guards the identity, not the algorithm).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "stockham16.hpp"
-
-#ifndef GLFER_PSD_STORE_AUX
-#define GLFER_PSD_STORE_AUX 2      /* non-temporal: PSD rows are written once, never re-read here */
-#endif
+#include "odd_taper.hpp"
 
 namespace glfer {
 
@@ -83,27 +79,7 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
   const v2f32 *tw1row = tw1 + (t & 15) * 17;
   const long long stride = (long long)gridDim.x * (2 * FPB);
 
-  // Samples of frame (fblk + fl).  Only frames wholly inside the stream reach this kernel (the
-  // launcher sends a stream's first ceil(R/H) frames to spectro16.hip), so every load is in range.
-  auto load_x = [&](float (&dst)[16], long long fblk) {
-    const long long f = fblk + fl;
-    const unsigned flc = f < p.nframes ? fl : (unsigned)(p.nframes - 1 - fblk);
-    const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
-    const unsigned lrel = flc * (unsigned)p.H + t;
-    static_for<0, 16>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      dst[m] = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(T * m) * esz);
-    });
-    if (p.history_mode) {                            // fft.c:103-108 with glfer.first_buffer stuck at TRUE
-      const int d = (int)t - p.R;
-      static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        dst[m] = (d >= -T * m) ? dst[m] : 0.0f;
-      });
-    }
-  };
+  auto load_x = [&](float (&dst)[16], long long fblk) { load_frame16<FMT, T>(p, t, fl, fblk, dst); };
 
   long long fblk = (long long)xcd_block_index() * (2 * FPB);
   if (fblk >= p.nframes) return;
@@ -117,7 +93,6 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
 
   constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
   auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };   // register of bin t + T*m
-  constexpr int kSilent = 0x7fff;
 
   // One frame group's NP full rounds; leaves the mirror-folded sums psd[k] = acc[k] + acc[N-k]
   // (k = t + T*m, m < 8, and k = N/2 on lane 0) and the exponent of the shared round's scale.
@@ -168,9 +143,7 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
 #pragma unroll
       for (int w = 0; w < WPF; w++) e += red[fl * WPF + w];
     }
-    int ex = __builtin_amdgcn_frexp_expf(e);         // 0 for e = 0, inf, nan
-    ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
-    hx = e == 0.0f ? kSilent : ex >> 1;              // digital silence stays exactly 0 (scale 0)
+    hx = scale_exponent(e);
     static_for<0, 8>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       const int k = T * m + (int)t;
@@ -217,8 +190,7 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
     float zr[16], zi[16];
     GLFER_STAMP(0);                                  // shared round start
     {
-      const float sA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxA);
-      const float sB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxB);
+      const float sA = scale_in(hxA), sB = scale_in(hxB);
       const float *vlo = tl1 + t, *vhi = tl1 + (T - 1 - t);
       static_for<0, 16>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
@@ -234,47 +206,9 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
         if (nfblk + FPB < p.nframes) load_x(xB, nfblk + FPB);
       }
     });
-    // separate the two spectra through the mirror pairs (k, N-k): E = Z[k] + conj Z[N-k] = 2 sA Y_A[k],
-    // O = Z[k] - conj Z[N-k] = 2i sB Y_B[k].  Z[k], k >= N/2, goes through LDS (entry k - N/2).
-    frame_sync<T>();
-    static_for<8, 16>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      constexpr int r = rho_of(m);
-      xb[t + T * (m - 8)] = v2f32{zr[r], zi[r]};
-    });
-    frame_sync<T>();
-    {
-      constexpr unsigned ROWB = (N / 2 + 1) * 4u;
-      const long long leftA = p.nframes - fblk, leftB = p.nframes - (fblk + FPB);
-      const unsigned recA = (unsigned)((leftA > FPB ? FPB : leftA) * (long long)ROWB);
-      const unsigned recB = leftB > 0 ? (unsigned)((leftB > FPB ? FPB : leftB) * (long long)ROWB) : 0u;
-      // rows past the last frame fall outside num_records: their stores are dropped
-      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)fblk * (N / 2 + 1), 0, recA, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)(fblk + (leftB > 0 ? FPB : 0)) * (N / 2 + 1), 0, recB, 0x00020000);
-      const unsigned voff = fl * ROWB + t * 4u;
-      const float uA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxA);
-      const float uB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxB);
-      static_for<0, 8>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        constexpr int r = rho_of(m);
-        const int k = (int)t + T * m;
-        v2f32 b = xb[N / 2 - k];                     // Z[N-k]; entry N/2 (k = 0) is never written
-        const float ar = zr[r], ai = zi[r];
-        if constexpr (m == 0) {
-          if (t == 0) b = v2f32{ar, ai};             // k = 0 pairs with itself
-        }
-        const float er = ar + b.x, ei = ai - b.y, orr = ar - b.x, oi = ai + b.y;
-        const float pa = __builtin_fmaf(er, er, ei * ei), pb = __builtin_fmaf(orr, orr, oi * oi);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pa, uA, psdA[m])), ra, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pb, uB, psdB[m])), rb, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
-      });
-      if (t == 0) {                                  // k = N/2 pairs with itself: E = 2 Re Z, O = 2i Im Z
-        constexpr int r = rho_of(8);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, nyqA)), ra, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, nyqB)), rb, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
-      }
-      if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();   // mirror entries read: buffer free
-    }
+    separate_and_store<LOGN, FPB>(p, zr, zi, xb, t, fl, fblk, hxA, hxB,
+                                  [&](auto mc) { if constexpr (decltype(mc)::value == 8) return nyqA; else return psdA[decltype(mc)::value]; },
+                                  [&](auto mc) { if constexpr (decltype(mc)::value == 8) return nyqB; else return psdB[decltype(mc)::value]; });
     GLFER_STAMP(15);                                 // shared round end (separated, stored)
     if (!has_next) break;
     fblk = nfblk;

@@ -15,11 +15,7 @@
 // bit-identical to it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "stockham16.hpp"
-
-#ifndef GLFER_PSD_STORE_AUX
-#define GLFER_PSD_STORE_AUX 2      /* non-temporal: PSD rows are written once, never re-read here */
-#endif
+#include "odd_taper.hpp"
 
 namespace glfer {
 
@@ -70,24 +66,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
   const int NP = p.npairs - 1;                       // full (two-taper) rounds per frame
   const long long stride = (long long)gridDim.x * 2;
 
-  // Samples of frame f.  Only frames wholly inside the stream reach this kernel (the launcher
-  // sends a stream's first ceil(R/H) frames to spectro16.hip), so every load is in range.
-  auto load_x = [&](float (&dst)[16], long long f) {
-    const long long sblk = (p.frame0 + f) * (long long)p.H - p.R;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
-    static_for<0, 16>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      dst[m] = buf_sample<FMT>(xrsrc, t * esz, (unsigned)(T * m) * esz);
-    });
-    if (p.history_mode) {                            // fft.c:103-108 with glfer.first_buffer stuck at TRUE
-      const int d = (int)t - p.R;
-      static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        dst[m] = (d >= -T * m) ? dst[m] : 0.0f;
-      });
-    }
-  };
+  auto load_x = [&](float (&dst)[16], long long f) { load_frame16<FMT, T>(p, t, 0u, f, dst); };
   v2f32 pt[16];          // full round: the next taper pair; shared round: pt[0..7] = the last taper
   auto prefetch_taps = [&](int pair) {
     const unsigned tap_p = (unsigned)pair * (N * 8u);
@@ -120,7 +99,6 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
 
   constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
   auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };   // register of bin t + T*m
-  constexpr int kSilent = 0x7fff;
 
   while (true) {                                     // one iteration: frames A = fA and B = fA + 1
     const bool hasB = fA + 1 < p.nframes;            // block-uniform
@@ -178,12 +156,8 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
       __syncthreads();
       eA = (red[0] + red[1]) + (red[2] + red[3]);
       eB = (red[4] + red[5]) + (red[6] + red[7]);
-      int ex = __builtin_amdgcn_frexp_expf(eA);      // 0 for e = 0, inf, nan
-      ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
-      hxA = eA == 0.0f ? kSilent : ex >> 1;          // digital silence stays exactly 0 (scale 0)
-      ex = __builtin_amdgcn_frexp_expf(eB);
-      ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
-      hxB = eB == 0.0f ? kSilent : ex >> 1;
+      hxA = scale_exponent(eA);
+      hxB = scale_exponent(eB);
       static_for<0, 8>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         const int k = T * m + (int)t;
@@ -205,8 +179,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
     // ---- shared round: re = sA*(xA*v), im = sB*(xB*v), v the last taper
     float zr[16], zi[16];
     {
-      const float sA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxA);
-      const float sB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, -hxB);
+      const float sA = scale_in(hxA), sB = scale_in(hxB);
 #pragma unroll
       for (int m = 0; m < 16; m++) {
         const float v = (m & 1) ? pt[m / 2].y : pt[m / 2].x;
@@ -222,43 +195,9 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
         if (nfA + 1 < p.nframes) load_x(xB, nfA + 1);
       }
     });
-    // separate the two spectra through the mirror pairs (k, N-k): E = Z[k] + conj Z[N-k] = 2 sA Y_A[k],
-    // O = Z[k] - conj Z[N-k] = 2i sB Y_B[k].  Z[k], k >= N/2, goes through LDS (entry k - N/2).
-    static_for<8, 16>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      constexpr int r = rho_of(m);
-      xbA[t + T * (m - 8)] = v2f32{zr[r], zi[r]};
-    });
-    __syncthreads();
-    {
-      constexpr unsigned ROWB = (N / 2 + 1) * 4u;
-      // a frame past the last one has no records: its stores are dropped by the range check
-      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)fA * (N / 2 + 1), 0, ROWB, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)(fA + (hasB ? 1 : 0)) * (N / 2 + 1), 0, hasB ? ROWB : 0u, 0x00020000);
-      const unsigned voff = t * 4u;
-      const float uA = hxA == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxA);
-      const float uB = hxB == kSilent ? 0.0f : __builtin_amdgcn_ldexpf(1.0f, 2 * hxB);
-      static_for<0, 8>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        constexpr int r = rho_of(m);
-        const int k = (int)t + T * m;
-        v2f32 b = xbA[N / 2 - k];                    // Z[N-k]; entry N/2 (k = 0) is never written
-        const float ar = zr[r], ai = zi[r];
-        if constexpr (m == 0) {
-          if (t == 0) b = v2f32{ar, ai};             // k = 0 pairs with itself
-        }
-        const float er = ar + b.x, ei = ai - b.y, orr = ar - b.x, oi = ai + b.y;
-        const float pa = __builtin_fmaf(er, er, ei * ei), pb = __builtin_fmaf(orr, orr, oi * oi);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pa, uA, psdA[m])), ra, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(pb, uB, psdB[m])), rb, voff, (unsigned)(T * m) * 4u, GLFER_PSD_STORE_AUX);
-      });
-      if (t == 0) {                                  // k = N/2 pairs with itself: E = 2 Re Z, O = 2i Im Z
-        constexpr int r = rho_of(8);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zr[r] * zr[r], uA, nyqA)), ra, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(4.0f * zi[r] * zi[r], uB, nyqB)), rb, voff, (unsigned)(N / 2) * 4u, GLFER_PSD_STORE_AUX);
-      }
-    }
-    __syncthreads();                                 // mirror entries read: buffer free
+    separate_and_store<12, 1>(p, zr, zi, xbA, t, 0u, fA, hxA, hxB,
+                              [&](auto mc) { if constexpr (decltype(mc)::value == 8) return nyqA; else return psdA[decltype(mc)::value]; },
+                              [&](auto mc) { if constexpr (decltype(mc)::value == 8) return nyqB; else return psdB[decltype(mc)::value]; });
     if (!has_next) break;
     fA = nfA;
     if (fA + 1 >= p.nframes) {
