@@ -125,6 +125,25 @@ def test_multitaper_kernel_forms_vs_oracle(lib, oracle, torch_cuda, n, overlap, 
         assert np.abs(part[f] - want[first + f]).max() <= TOL * want[first + f].max(), f
 
 
+@pytest.mark.parametrize("n", [256, 1024, 4096, 16384])
+def test_tiny_frame_counts(lib, oracle, torch_cuda, n):
+    """1..5 frames (fewer than a block's frame group, odd counts, a lone last frame) through the
+    periodogram and the odd- and even-count multitaper paths, with and without overlap."""
+    for overlap in (0.0, 0.5):
+        h = oracle.hop(n, overlap)
+        for frames in (1, 2, 3, 5):
+            x = synth(frames * h, seed=frames + n)
+            want = oracle.spectrogram_fft(x, n, overlap, 0)
+            _, got = _run(lib, torch_cuda, lib.FftParams(n=n, window_type=0, overlap=overlap), x)
+            assert got.shape == want.shape and max(rel_err(got, want)) < TOL, ("fft", overlap, frames)
+            for kmax in (2, 3):
+                want = oracle.spectrogram_mtm(x, n, overlap, 2.0, kmax)
+                _, got = _run(lib, torch_cuda, lib.MtmParams(n=n, overlap=overlap, w=2.0, kmax=kmax), x)
+                assert got.shape == want.shape
+                for f in range(frames):
+                    assert np.abs(got[f] - want[f]).max() <= TOL * want[f].max(), ("mtm", kmax, overlap, frames, f)
+
+
 @pytest.mark.parametrize("window", ["hanning", "blackman", "gaussian", "welch", "bartlett", "rectangular",
                                     "hamming", "kaiser"])
 def test_all_windows(lib, oracle, torch_cuda, window):
