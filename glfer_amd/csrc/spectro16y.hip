@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
       for (int pair = 0; pair < NP; pair++) {
         // ---- one full round of both frames: re = x*taper(2*pair), im = x*taper(2*pair+1)
         float zrA[16], ziA[16], zrB[16], ziB[16];
+        GLFER_STAMP(0);                              // dual round start
 #pragma unroll
         for (int m = 0; m < 16; m++) {
           zrA[m] = xA[m] * pt[m].x;
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
           accA[r] = __builtin_fmaf(zrA[r], zrA[r], __builtin_fmaf(ziA[r], ziA[r], accA[r]));
           accB[r] = __builtin_fmaf(zrB[r], zrB[r], __builtin_fmaf(ziB[r], ziB[r], accB[r]));
         }
+        GLFER_STAMP(15);                             // dual round end
       }
       // ---- mirror fold psd[k] = acc[k] + acc[N-k] of both frames (upper half through LDS, entry
       // k - N/2) and the frames' powers for the shared round's scales
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
 
     // ---- shared round: re = sA*(xA*v), im = sB*(xB*v), v the last taper
     float zr[16], zi[16];
+    GLFER_STAMP(0);                                  // shared round start
     {
       const float sA = scale_in(hxA), sB = scale_in(hxB);
 #pragma unroll
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
     separate_and_store<12, 1>(p, zr, zi, xbA, t, 0u, fA, hxA, hxB,
                               [&](auto mc) { if constexpr (decltype(mc)::value == 8) return nyqA; else return psdA[decltype(mc)::value]; },
                               [&](auto mc) { if constexpr (decltype(mc)::value == 8) return nyqB; else return psdB[decltype(mc)::value]; });
+    GLFER_STAMP(15);                                 // shared round end (separated, stored)
     if (!has_next) break;
     fA = nfA;
     if (fA + 1 >= p.nframes) {

@@ -99,6 +99,17 @@ struct Launch16 {
   static constexpr int LDS_WORDS = FPB * PADN + 16 * 17;       // + pass-1 twiddle table [16][17] (padded rows)
 };
 
+// Padded exchange layout: logical index a lives at entry a + (a >> shift).  Exchange 0 is written
+// 16 consecutive entries per lane (a = 16 t + q): +1 per 16 makes its 16-lane ds_write_b64 groups
+// conflict free, and leaves one 2-way conflict in every 32-lane ds_read_b64 group (33 entries).
+// Later exchanges are written one entry per lane, 16 consecutive lanes to 16 consecutive entries:
+// +1 per 32 is conflict free for those writes AND for the reads (32 consecutive entries).
+// (tools/ldsbench2: reading with the 2-way conflict runs at 108 B/clk/CU, half the pipe's rate.)
+// xpad_offset(i, d): entry distance for a logical distance d that is a compile-time multiple of 16
+// added to a base whose low bits cannot carry into it (asserted by the callers' index algebra).
+__host__ __device__ constexpr int xpad_shift(int exchange) { return exchange == 0 ? 4 : 5; }
+__host__ __device__ constexpr int xpad_offset(int exchange, int d) { return d + (d >> xpad_shift(exchange)); }
+
 // The Stockham passes of one complex 2^LOGM-point transform held 16 points per lane
 // (lane t of T = 2^LOGM/16: points t + T*m on entry; on exit register b + B*brev(q',R) holds
 // bin t + T*(b + B*q'), R = last radix, B = 16/R).  xb: this frame's exchange buffer
@@ -141,11 +152,10 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
       // barrier sits after the previous reads): each output goes to LDS as soon as it exists
       const int k = (int)t & (Ls - 1);
       const int a0 = ((int)t - k) * R + k;
-      v2f32 *wbase = xb + a0 + (a0 >> 4);
-      constexpr int WS = Ls >= 16 ? Ls + Ls / 16 : 1;
+      v2f32 *wbase = xb + a0 + (a0 >> xpad_shift(i));
       dit_emit<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
         constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
-        wbase[q * WS] = v2f32{zr[reg], zi[reg]};
+        wbase[xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
       });
     } else {
       static_for<0, B>([&](auto bc) {
@@ -162,12 +172,11 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
         const int j = (int)t + T * b;
         const int k = j & (Ls - 1);
         const int a0 = (j - k) * R + k;
-        v2f32 *wbase = xb + a0 + (a0 >> 4);
-        constexpr int WS = Ls >= 16 ? Ls + Ls / 16 : 1;
+        v2f32 *wbase = xb + a0 + (a0 >> xpad_shift(i));
         static_for<0, R>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
           constexpr int src = b + B * brev(q, R);
-          wbase[q * WS] = v2f32{zr[src], zi[src]};
+          wbase[xpad_offset(i, q * Ls)] = v2f32{zr[src], zi[src]};
         });
       });
       if constexpr (i == 0) {
@@ -177,10 +186,10 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
       GLFER_STAMP(4 * i + 3);              // writes (and the hook's loads) issued
       frame_sync<T>();
       GLFER_STAMP(4 * i + 4);              // through the post-write barrier
-      const v2f32 *rbase = xb + t + (t >> 4);
+      const v2f32 *rbase = xb + t + (t >> xpad_shift(i));
       static_for<0, 16>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        const v2f32 v = rbase[m * (T + T / 16)];
+        const v2f32 v = rbase[xpad_offset(i, m * T)];
         zr[m] = v.x;
         zi[m] = v.y;
       });
@@ -236,11 +245,10 @@ __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA
         static_assert(B == 1, "an exchange follows radix-16 passes only");
         const int k = (int)t & (Ls - 1);
         const int a0 = ((int)t - k) * R + k;
-        v2f32 *wbase = xb + a0 + (a0 >> 4);
-        constexpr int WS = Ls >= 16 ? Ls + Ls / 16 : 1;
+        v2f32 *wbase = xb + a0 + (a0 >> xpad_shift(i));
         dit_emit<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
           constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
-          wbase[q * WS] = v2f32{zr[reg], zi[reg]};
+          wbase[xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
         });
       } else {
         static_for<0, B>([&](auto bc) {
@@ -250,26 +258,30 @@ __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA
       }
     };
     compute(zrA, ziA, xbA);
+    GLFER_STAMP(4 * i + 1);                  // stream A: pass i done, its writes issued
     __builtin_amdgcn_sched_barrier(0);
     compute(zrB, ziB, xbB);
     if constexpr (i < NPASS - 1) {
       if constexpr (i == 0) after_first_write();
       __builtin_amdgcn_sched_barrier(0);
+      GLFER_STAMP(4 * i + 2);                // stream B: pass i done, its writes (and the hook's loads) issued
       frame_sync<T>();                       // both streams' writes are in LDS
-      const v2f32 *ra = xbA + t + (t >> 4), *rb = xbB + t + (t >> 4);
+      GLFER_STAMP(4 * i + 3);                // through the post-write barrier
+      const v2f32 *ra = xbA + t + (t >> xpad_shift(i)), *rb = xbB + t + (t >> xpad_shift(i));
       static_for<0, 16>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        const v2f32 v = ra[m * (T + T / 16)];
+        const v2f32 v = ra[xpad_offset(i, m * T)];
         zrA[m] = v.x;
         ziA[m] = v.y;
       });
       static_for<0, 16>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        const v2f32 v = rb[m * (T + T / 16)];
+        const v2f32 v = rb[xpad_offset(i, m * T)];
         zrB[m] = v.x;
         ziB[m] = v.y;
       });
       frame_sync<T>();                       // both buffers read: free for the next writes
+      GLFER_STAMP(4 * i + 4);                // both streams' reads landed, through the barrier
     }
   });
 }

@@ -22,8 +22,8 @@ __device__ int g_round;
     }                                                                                                \
   } while (0)
 #define GLFER_NO_LAUNCHERS
-#ifdef STAMP_XD
-#include "spectro16xd.hip"
+#ifdef STAMP_Y
+#include "spectro16y.hip"
 #else
 #include "spectro16xl.hip"
 #endif
@@ -53,24 +53,6 @@ int main(int argc, char **argv) {
   std::vector<float> x(ns);
   unsigned s = 12345;
   for (size_t i = 0; i < ns; i++) { s = s * 1664525u + 1013904223u; x[i] = (float)((s >> 8) * (1.0 / 16777216.0) - 0.5); }
-  std::vector<float> dlane((size_t)19 * 256 * 2);
-  for (int pl = 0; pl < 256; pl++) {
-    const int ka = pl >> 4, i = pl & 15, c = i ^ ((i & 4) ? 3 : 0);
-    for (int kb = 0; kb < 16; kb++) {
-      const double ang = -2.0 * M_PI * (double)((c * (ka + 16 * kb)) % 4096) / 4096.0;
-      dlane[((size_t)kb * 256 + pl) * 2] = (float)cos(ang);
-      dlane[((size_t)kb * 256 + pl) * 2 + 1] = (float)sin(ang);
-    }
-    const int hs[3] = {8, 4, 2};
-    for (int j = 0; j < 3; j++) {
-      const double ang = (c & hs[j]) ? -2.0 * M_PI * (double)(c % hs[j]) / (2.0 * hs[j]) : 0.0;
-      dlane[((size_t)(16 + j) * 256 + pl) * 2] = (float)cos(ang);
-      dlane[((size_t)(16 + j) * 256 + pl) * 2 + 1] = (float)sin(ang);
-    }
-  }
-  float *d_dl;
-  CK(hipMalloc((void **)&d_dl, dlane.size() * 4));
-  CK(hipMemcpy(d_dl, dlane.data(), dlane.size() * 4, hipMemcpyHostToDevice));
   float *d_x, *d_lt, *d_psd;
   float2 *d_tw;
   unsigned long long *d_st;
@@ -87,13 +69,32 @@ int main(int argc, char **argv) {
   SpectroParams sp = {};
   sp.stream = d_x; sp.nframes = nframes; sp.H = H; sp.R = 0; sp.npairs = NP + 1; sp.fmt = GLFER_FMT_F32;
   sp.tw = d_tw; sp.ltaps = d_lt; sp.psd = d_psd;
-#ifdef STAMP_XD
-  const size_t shmem = glfer::LaunchXD::lds_bytes(NP);
-  auto kern = glfer::spectro16xd_kernel<GLFER_FMT_F32>;
-  const char *names[16] = {"round start", "form z + pass0 butterflies", "pre-write barrier", "writes issued", "post-write barrier",
-                           "reads + tw1 + pass1 + tw2", "", "", "", "cross-lane pass 2 (DPP)", "", "", "", "", "", "accumulate / separate+store"};
-  const int NORD = 7;
-  const int order[11] = {0, 1, 2, 3, 4, 5, 9, 15, 0, 0, 0};
+#ifdef STAMP_Y
+  // spectro16y reads the pair tables ([pair][m/2][lane][4]) and the last taper ([m/4][lane][4]) from memory
+  std::vector<float> gt((size_t)2 * (NP + 1) * N, 0.0f), xt(N);
+  for (int j = 0; j < T; j++)
+    for (int i = 0; i < N; i++) {
+      const int t = i % TT, m = i / TT;
+      gt[(size_t)(j / 2) * N * 2 + ((size_t)(m / 2) * TT + t) * 4 + (size_t)(m & 1) * 2 + (j & 1)] =
+          (float)(tapers[(size_t)j * N + i] * sqrt(1.0 / (2.0 * N * (1.0 + sig[j]))));
+    }
+  for (int i = 0; i < N; i++) {
+    const int t = i % TT, m = i / TT;
+    xt[((size_t)(m / 4) * TT + t) * 4 + (size_t)(m & 3)] = (float)(tapers[(size_t)(T - 1) * N + i] * sqrt(1.0 / (4.0 * N * (1.0 + sig[T - 1]))));
+  }
+  float *d_gt, *d_xt;
+  CK(hipMalloc((void **)&d_gt, gt.size() * 4));
+  CK(hipMalloc((void **)&d_xt, xt.size() * 4));
+  CK(hipMemcpy(d_gt, gt.data(), gt.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_xt, xt.data(), xt.size() * 4, hipMemcpyHostToDevice));
+  sp.taps = d_gt; sp.xtaps = d_xt;
+  const size_t shmem = (size_t)glfer::LaunchY::LDS_WORDS * 8;
+  auto kern = glfer::spectro16y_kernel<GLFER_FMT_F32>;
+  const char *names[16] = {"round start", "A: form z + pass0 (+writes)", "B: pass0 (+writes, prefetch)", "post-write barrier 0", "reads A+B, barrier",
+                           "A: twiddle + pass1 (+writes)", "B: pass1 (+writes)", "post-write barrier 1", "reads A+B, barrier",
+                           "A: twiddle + pass2", "", "", "", "", "", "B: pass2, accumulate both"};
+  const int NORD = 10;
+  const int order[11] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15};
 #else
   const size_t shmem = glfer::LaunchXL<LOGN>::lds_bytes(NP);
   auto kern = glfer::spectro16xl_kernel<LOGN, GLFER_FMT_F32>;
@@ -121,20 +122,42 @@ int main(int argc, char **argv) {
   }
   std::vector<unsigned long long> st(64 * 16);
   CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
-  double sum[16] = {0};
-  int cnt = 0;
-  for (int r = 8; r < 56; r++) {                      // steady state
-    bool ok = true;
-    for (int i = 0; i <= NORD; i++) ok = ok && st[r * 16 + order[i]] != 0;
-    if (!ok) continue;
-    for (int i = 1; i <= NORD; i++) sum[order[i]] += (double)(st[r * 16 + order[i]] - st[r * 16 + order[i - 1]]);
-    cnt++;
+#ifdef STAMP_Y
+  const int period = 3, nkinds = 2;                  // dual, dual, shared
+  const char *kind_name[2] = {"dual round (two frames interleaved)", "shared round (one transform for both frames' last taper)"};
+  const char *names_s[16] = {"round start", "form z + pass0 butterflies", "(barrier slot unused)", "writes 0 issued", "post-write barrier 0",
+                             "reads, barrier, pass1", "(barrier slot unused)", "writes 1 issued", "post-write barrier 1",
+                             "reads, barrier, pass2", "", "", "", "", "", "separate + store"};
+#else
+  const int period = 1, nkinds = 1;
+  const char *kind_name[1] = {"round"};
+#endif
+  for (int kind = 0; kind < nkinds; kind++) {
+    double sum[16] = {0};
+    int cnt = 0;
+    for (int r = 9; r < 57; r++) {                    // steady state
+      const bool is_shared = period == 3 && r % 3 == 2;
+      if ((kind == 1) != is_shared) continue;
+      bool ok = true;
+      for (int i = 0; i <= NORD; i++) ok = ok && st[r * 16 + order[i]] != 0;
+      if (!ok) continue;
+      for (int i = 1; i <= NORD; i++) sum[order[i]] += (double)(st[r * 16 + order[i]] - st[r * 16 + order[i - 1]]);
+      cnt++;
+    }
+    if (!cnt) continue;
+    double tot = 0;
+    for (int i = 1; i <= NORD; i++) tot += sum[order[i]] / cnt;
+    printf("wave 0 of block 8, %s: %d averaged; s_memtime ticks.\n", kind_name[kind], cnt);
+    for (int i = 1; i <= NORD; i++) {
+#ifdef STAMP_Y
+      const char *nm = kind == 1 ? names_s[order[i]] : names[order[i]];
+#else
+      const char *nm = names[order[i]];
+#endif
+      printf("  -> %-30s %9.1f  (%4.1f%%)\n", nm, sum[order[i]] / cnt, 100.0 * sum[order[i]] / cnt / tot);
+    }
+    printf("  total %.1f ticks\n", tot);
   }
-  double tot = 0;
-  for (int i = 1; i <= NORD; i++) tot += sum[order[i]] / cnt;
-  printf("wave 0 of block 8, %d rounds averaged (4 full + 1 shared per frame pair); s_memtime ticks.\n"
-         "NOTE: stamp 0 reads a counter from memory, so the first interval carries ~2 k ticks of load latency.\n", cnt);
-  for (int i = 1; i <= NORD; i++) printf("  -> %-28s %9.1f  (%4.1f%%)\n", names[order[i]], sum[order[i]] / cnt, 100.0 * sum[order[i]] / cnt / tot);
-  printf("  round total %.1f ticks; first/last stamp of rounds 8 and 55: %llu .. %llu\n", tot, st[8 * 16], st[55 * 16 + 15]);
+  printf("NOTE: every stamp costs a memory round trip of its own (a few hundred ticks); stamp 0 more.\n");
   return 0;
 }
