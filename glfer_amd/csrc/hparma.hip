@@ -105,11 +105,86 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
       for (int j = 0; j < ncol; j++) Q[j * ncol + i] = (i == j) ? 1.0f : 0.0f;
     wave_fence();
 
-    // ---- one-sided Jacobi (util.c:294-356), cyclic by columns, same order as the reference
+    // ---- one-sided Jacobi (util.c:294-356), cyclic by columns, same order as the reference.
+    // Every lane only ever touches its own rows (i = lane + 64 r) of A and its own row of Q, so LDS
+    // is per-lane storage here (dynamic column index) and needs no fences inside a sweep.  Fast
+    // path (t <= 128, p_e+1 <= 64: two rows of A and one of Q per lane): column j stays in VGPRs
+    // for the whole k loop and column k+1 is fetched while column k's three sums are reduced.
     const int sweepmax = ncol > 12 ? ncol : 12;
     int count = 1, sweep = 0;
+    const bool fast = t <= 128 && ncol <= 64;
     while (count > 0 && sweep <= sweepmax) {
       count = ncol * (ncol - 1) / 2;
+      if (fast) {
+        const int i0 = lane, i1 = lane + 64;
+        const bool v0 = i0 < t, v1 = i1 < t, vq = lane < ncol;
+        for (int j = 0; j < ncol - 1; j++) {
+          float aj0 = v0 ? A[j * t + i0] : 0.0f, aj1 = v1 ? A[j * t + i1] : 0.0f;
+          float qj = vq ? Q[j * ncol + lane] : 0.0f;
+          float ak0 = v0 ? A[(j + 1) * t + i0] : 0.0f, ak1 = v1 ? A[(j + 1) * t + i1] : 0.0f;
+          float qk = vq ? Q[(j + 1) * ncol + lane] : 0.0f;
+          for (int k = j + 1; k < ncol; k++) {
+            float an0 = 0.0f, an1 = 0.0f, qn = 0.0f;                   // column k+1, in flight under the sums
+            if (k + 1 < ncol) {
+              an0 = v0 ? A[(k + 1) * t + i0] : 0.0f;
+              an1 = v1 ? A[(k + 1) * t + i1] : 0.0f;
+              qn = vq ? Q[(k + 1) * ncol + lane] : 0.0f;
+            }
+            double pp = 0.0, qq = 0.0, rr = 0.0;
+            {
+              const double a = aj0, b = ak0;
+              pp += a * b; qq += a * a; rr += b * b;
+            }
+            {
+              const double a = aj1, b = ak1;
+              pp += a * b; qq += a * a; rr += b * b;
+            }
+            pp = wave_sum(pp);
+            qq = wave_sum(qq);
+            rr = wave_sum(rr);
+            bool rotate = true;
+            if (qq * rr < 2.22e-16) { count--; rotate = false; }                       // util.c:316-320
+            else if (pp * pp / (qq * rr) < 1.0e-12) { count--; rotate = false; }       // util.c:321-325
+            if (rotate) {
+              double cs, sn;
+              if (qq < rr) {                                          // util.c:327-335
+                cs = 0.0;
+                sn = 1.0;
+              } else {
+                qq -= rr;
+                const double v = sqrt(4.0 * pp * pp + qq * qq);
+                cs = sqrt((v + qq) / (2.0 * v));
+                sn = pp / (v * cs);
+              }
+              {                                                       // util.c:338-343
+                const double a = aj0, b = ak0;
+                aj0 = (float)(a * cs + b * sn);
+                ak0 = (float)(-a * sn + b * cs);
+              }
+              {
+                const double a = aj1, b = ak1;
+                aj1 = (float)(a * cs + b * sn);
+                ak1 = (float)(-a * sn + b * cs);
+              }
+              {                                                       // util.c:345-350
+                const double a = qj, b = qk;
+                qj = (float)(a * cs + b * sn);
+                qk = (float)(-a * sn + b * cs);
+              }
+              if (v0) A[k * t + i0] = ak0;
+              if (v1) A[k * t + i1] = ak1;
+              if (vq) Q[k * ncol + lane] = qk;
+            }
+            ak0 = an0;
+            ak1 = an1;
+            qk = qn;
+          }
+          if (v0) A[j * t + i0] = aj0;
+          if (v1) A[j * t + i1] = aj1;
+          if (vq) Q[j * ncol + lane] = qj;
+        }
+        wave_fence();
+      } else {
       for (int j = 0; j < ncol - 1; j++) {
         for (int k = j + 1; k < ncol; k++) {
           double pp = 0.0, qq = 0.0, rr = 0.0;
@@ -146,6 +221,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
           }
           wave_fence();
         }
+      }
       }
       sweep++;
     }
