@@ -110,6 +110,38 @@ struct Launch16 {
 __host__ __device__ constexpr int xpad_shift(int exchange) { return exchange == 0 ? 4 : 5; }
 __host__ __device__ constexpr int xpad_offset(int exchange, int d) { return d + (d >> xpad_shift(exchange)); }
 
+// Exchange 0 in ROW layout (GLFER16_X0_ROWS, T >= 32): output q of producer lane t goes to row q,
+// column t (row stride T + 2 entries), so a 16-lane ds_write_b64 group writes 16 consecutive
+// entries; consumer lane 16 u + k reads row k at columns u + 16 m.  (T + 2) = 2 mod 32 puts the
+// 32 (k, u) combinations of a read group on 32 distinct bank pairs: conflict free BOTH ways.
+// The 16 reads of a lane sit T/2 bytes apart, which LLVM's load/store optimiser would fuse into
+// ds_read2_b64 -- half the rate of ds_read_b64 (MI355X_MICROARCH.md, LDS table) -- so they are
+// issued as inline asm; the explicit s_waitcnt that makes their results visible costs nothing,
+// because the buffer-release barrier follows the reads anyway.
+#ifndef GLFER16_X0_ROWS
+#define GLFER16_X0_ROWS 1
+#endif
+template <int BYTE_OFFSET>
+__device__ __forceinline__ void lds_read_b64_asm(unsigned addr, v2f32 &out) {
+  // "memory": the compiler must not move this read across the LDS stores it cannot see it depends on
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(out) : "v"(addr), "n"(BYTE_OFFSET) : "memory");
+}
+// v[m] = base[m * STRIDE] (STRIDE in entries), m = 0..15
+template <int STRIDE>
+__device__ __forceinline__ void lds_read16_strided(const v2f32 *base, v2f32 (&v)[16]) {
+  static_assert(15 * STRIDE * 8 < 65536, "ds offset field");
+  const unsigned addr = (unsigned)(__SIZE_TYPE__)(const __attribute__((address_space(3))) char *)base;
+  static_for<0, 16>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    lds_read_b64_asm<m * STRIDE * 8>(addr, v[m]);
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                 "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+               :
+               : "memory");
+}
+
 // The Stockham passes of one complex 2^LOGM-point transform held 16 points per lane
 // (lane t of T = 2^LOGM/16: points t + T*m on entry; on exit register b + B*brev(q',R) holds
 // bin t + T*(b + B*q'), R = last radix, B = 16/R).  xb: this frame's exchange buffer
@@ -152,10 +184,11 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
       // barrier sits after the previous reads): each output goes to LDS as soon as it exists
       const int k = (int)t & (Ls - 1);
       const int a0 = ((int)t - k) * R + k;
-      v2f32 *wbase = xb + a0 + (a0 >> xpad_shift(i));
+      constexpr bool kRows = GLFER16_X0_ROWS != 0 && i == 0 && T >= 32;
+      v2f32 *wbase = kRows ? xb + t : xb + a0 + (a0 >> xpad_shift(i));
       dit_emit<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
         constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
-        wbase[xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
+        wbase[kRows ? q * (T + 2) : xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
       });
     } else {
       static_for<0, B>([&](auto bc) {
@@ -186,13 +219,23 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
       GLFER_STAMP(4 * i + 3);              // writes (and the hook's loads) issued
       frame_sync<T>();
       GLFER_STAMP(4 * i + 4);              // through the post-write barrier
-      const v2f32 *rbase = xb + t + (t >> xpad_shift(i));
-      static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        const v2f32 v = rbase[xpad_offset(i, m * T)];
-        zr[m] = v.x;
-        zi[m] = v.y;
-      });
+      if constexpr (GLFER16_X0_ROWS != 0 && GLFER16_BARRIER_AFTER_READS != 0 && i == 0 && T >= 32 && B == 1) {
+        v2f32 v[16];
+        lds_read16_strided<T / 16>(xb + (t & 15) * (T + 2) + (t >> 4), v);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          zr[m] = v[m].x;
+          zi[m] = v[m].y;
+        }
+      } else {
+        const v2f32 *rbase = xb + t + (t >> xpad_shift(i));
+        static_for<0, 16>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          const v2f32 v = rbase[xpad_offset(i, m * T)];
+          zr[m] = v.x;
+          zi[m] = v.y;
+        });
+      }
       // With the barrier here (the reads have landed: the barrier waits for lgkmcnt(0)) instead
       // of in front of the next writes, those writes are not fenced off from the butterflies
       // that produce them and can be issued as their data becomes ready.  The buffer is then
@@ -245,10 +288,11 @@ __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA
         static_assert(B == 1, "an exchange follows radix-16 passes only");
         const int k = (int)t & (Ls - 1);
         const int a0 = ((int)t - k) * R + k;
-        v2f32 *wbase = xb + a0 + (a0 >> xpad_shift(i));
+        constexpr bool kRows = GLFER16_X0_ROWS != 0 && i == 0 && T >= 32;
+        v2f32 *wbase = kRows ? xb + t : xb + a0 + (a0 >> xpad_shift(i));
         dit_emit<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
           constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
-          wbase[xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
+          wbase[kRows ? q * (T + 2) : xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
         });
       } else {
         static_for<0, B>([&](auto bc) {
@@ -267,19 +311,33 @@ __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA
       GLFER_STAMP(4 * i + 2);                // stream B: pass i done, its writes (and the hook's loads) issued
       frame_sync<T>();                       // both streams' writes are in LDS
       GLFER_STAMP(4 * i + 3);                // through the post-write barrier
-      const v2f32 *ra = xbA + t + (t >> xpad_shift(i)), *rb = xbB + t + (t >> xpad_shift(i));
-      static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        const v2f32 v = ra[xpad_offset(i, m * T)];
-        zrA[m] = v.x;
-        ziA[m] = v.y;
-      });
-      static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        const v2f32 v = rb[xpad_offset(i, m * T)];
-        zrB[m] = v.x;
-        ziB[m] = v.y;
-      });
+      if constexpr (GLFER16_X0_ROWS != 0 && i == 0 && T >= 32) {
+        v2f32 va[16], vb[16];
+        const int roff = (int)(t & 15) * (T + 2) + (int)(t >> 4);
+        lds_read16_strided<T / 16>(xbA + roff, va);
+        lds_read16_strided<T / 16>(xbB + roff, vb);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          zrA[m] = va[m].x;
+          ziA[m] = va[m].y;
+          zrB[m] = vb[m].x;
+          ziB[m] = vb[m].y;
+        }
+      } else {
+        const v2f32 *ra = xbA + t + (t >> xpad_shift(i)), *rb = xbB + t + (t >> xpad_shift(i));
+        static_for<0, 16>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          const v2f32 v = ra[xpad_offset(i, m * T)];
+          zrA[m] = v.x;
+          ziA[m] = v.y;
+        });
+        static_for<0, 16>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          const v2f32 v = rb[xpad_offset(i, m * T)];
+          zrB[m] = v.x;
+          ziB[m] = v.y;
+        });
+      }
       frame_sync<T>();                       // both buffers read: free for the next writes
       GLFER_STAMP(4 * i + 4);                // both streams' reads landed, through the barrier
     }
