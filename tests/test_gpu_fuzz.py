@@ -1,0 +1,66 @@
+"""GPU parity, randomised: seeded random configurations of the estimator entry (block size, overlap,
+window or taper set, sample format, mean removal, history mode, frame count, a sub-range of frames)
+against the oracle, frame by frame.  Exercises the launcher's splits (zero-history head, aligned
+frame groups, lone tail frames) and every kernel form with parameters nobody hand-picked."""
+import numpy as np
+import pytest
+
+from _signals import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _cases():
+    rng = np.random.default_rng(20260)
+    out = []
+    for i in range(48):
+        n = int(rng.choice([256, 512, 1024, 2048, 4096, 4096, 8192]))
+        overlap = float(rng.choice([0.0, 0.0, 0.25, 0.33, 0.5, 0.75, 0.9]))
+        mode = "mtm" if rng.random() < 0.6 else "fft"
+        kmax = int(rng.integers(1, 7))
+        nw = float(rng.choice([1.5, 2.0, 2.5, 4.0]))
+        window = int(rng.integers(0, 8))
+        fmt = str(rng.choice(["f32", "f32", "s16", "u8"]))
+        sub_mean = int(rng.random() < 0.3)
+        history_mode = int(rng.random() < 0.25)
+        frames = int(rng.integers(1, 90 if n <= 1024 else 30))
+        out.append((i, mode, n, overlap, kmax, nw, window, fmt, sub_mean, history_mode, frames))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: "%d-%s-n%d-o%.2f-k%d-%s-m%d-h%d-f%d" % (c[0], c[1], c[2], c[3], c[4], c[7], c[8], c[9], c[10]))
+def test_random_configuration(lib, oracle, case):
+    import torch
+    i, mode, n, overlap, kmax, nw, window, fmt, sub_mean, history_mode, frames = case
+    h = oracle.hop(n, overlap)
+    x = synth(frames * h + (i % 7), seed=100 + i) + np.float32(0.02 * (i % 3))
+    if fmt == "s16":
+        raw = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16)
+        xf, sf = oracle.pcm_s16_to_float(raw), lib.SAMPLES_S16
+    elif fmt == "u8":
+        raw = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8)
+        xf, sf = oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
+    else:
+        raw, xf, sf = x, x, lib.SAMPLES_F32
+    if mode == "mtm":
+        want = oracle.spectrogram_mtm(xf.copy(), n, overlap, nw, kmax, sub_mean=sub_mean, history_mode=history_mode)
+        params = lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=sub_mean, history_mode=history_mode,
+                               sample_format=sf)
+    else:
+        want = oracle.spectrogram_fft(xf.copy(), n, overlap, window, 0.0, 0, sub_mean, history_mode)
+        params = lib.FftParams(n=n, window_type=window, overlap=overlap, sub_mean=sub_mean, history_mode=history_mode,
+                               sample_format=sf)
+    sp = lib.Spectrogram(params)
+    d = torch.from_numpy(raw).cuda()
+    got = sp.run(d).cpu().numpy()
+    assert got.shape == want.shape == (frames, n // 2 + 1)
+    for f in range(frames):
+        assert np.abs(got[f] - want[f]).max() <= TOL * want[f].max(), f
+    # a sub-range of the frames (arbitrary first frame and count): same rows to rounding
+    if frames >= 3:
+        first = 1 + i % (frames - 2)
+        count = 1 + (i * 7) % (frames - first)
+        part = sp.run(d, first_frame=first, nframes=count).cpu().numpy()
+        for f in range(count):
+            assert np.abs(part[f] - want[first + f]).max() <= TOL * want[first + f].max(), (first, count, f)
