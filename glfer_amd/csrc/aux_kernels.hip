@@ -111,16 +111,27 @@ __global__ __launch_bounds__(256) void floor_kernel(const float *__restrict__ ps
 // K5a.  The sliding sum of avg.c:116-127 per bin, as the same double recurrence
 //   f <  depth : cum += psd[f]                      (shift register still filling)
 //   f >= depth : cum += psd[f] - psd[f-depth]       (avgarray[index][0] is the row f-depth)
-// One thread per in-band bin, frames in order; rows are read coalesced across bins and
-// eight rows are kept in flight to cover latency.  cum is written into the avg rows.
+// One thread per in-band bin, frames in order; rows are read coalesced across bins and eight rows
+// are kept in flight to cover latency.  cum is written into the avg rows.
+// The recurrence is sequential in f, and one thread per bin is only ~2000 threads, so the frames
+// are cut into chunks of AVG_CHUNK that run in parallel: a chunk starts from the sum of the
+// (up to depth) rows before it, added in frame order.  That is the value the recurrence holds at
+// that frame whenever its additions are exact -- float terms in a double accumulator: always,
+// unless a bin's values within depth frames span more than ~2^26 (78 dB); beyond that the two differ
+// in the last bits of a double (the recurrence carries its own rounding history, the restart does
+// not).  131 072 rows: 2.1 M rows/s as one chain per bin, HBM-bound in chunks.
+constexpr int AVG_CHUNK = 128;
 __global__ __launch_bounds__(256) void avg_cum_kernel(const float *__restrict__ psd, long long nframes,
                                                       int bins, int n_out, int depth, int minbin,
                                                       int maxbin, double *__restrict__ avg) {
   const int b = minbin + blockIdx.x * 256 + threadIdx.x;
   if (b >= maxbin) return;
+  const long long f0 = (long long)blockIdx.y * AVG_CHUNK;
+  const long long f1 = f0 + AVG_CHUNK < nframes ? f0 + AVG_CHUNK : nframes;
   double cum = 0.0;
-  long long f = 0;
-  for (; f + 8 <= nframes; f += 8) {
+  for (long long g = f0 > depth ? f0 - depth : 0; g < f0; g++) cum += (double)psd[(size_t)g * bins + b];
+  long long f = f0;
+  for (; f + 8 <= f1; f += 8) {
     float v[8], old[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(256) void avg_cum_kernel(const float *__restrict__ 
       avg[(size_t)(f + u) * n_out + b] = cum;
     }
   }
-  for (; f < nframes; f++) {
+  for (; f < f1; f++) {
     const float v = psd[(size_t)f * bins + b];
     if (f < depth) cum += (double)v;
     else cum += (double)v - (double)psd[(size_t)(f - depth) * bins + b];
@@ -244,7 +255,7 @@ extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframe
                                        double *ret, hipStream_t st) {
   if (nframes == 0) return hipSuccess;
   const int band = maxbin - minbin;
-  hipLaunchKernelGGL(avg_cum_kernel, dim3((unsigned)((band + 255) / 256)), dim3(256), 0, st, psd,
+  hipLaunchKernelGGL(avg_cum_kernel, dim3((unsigned)((band + 255) / 256), (unsigned)((nframes + AVG_CHUNK - 1) / AVG_CHUNK)), dim3(256), 0, st, psd,
                      (long long)nframes, bins, n_out, depth, minbin, maxbin, avg);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

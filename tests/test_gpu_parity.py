@@ -345,6 +345,35 @@ def test_moving_average(lib, torch_cuda, mode_name, mode_id, max0):
         assert np.allclose(ret[:, 2], want_ret[:, 2], rtol=1e-12)
 
 
+@pytest.mark.parametrize("depth", [1, 4, 37, 200])
+def test_moving_average_long_run(lib, oracle, torch_cuda, depth):
+    """1000 rows (the device cuts the per-bin recurrence into 128-row chunks that restart from a
+    direct sum): identical to the oracle's row-by-row recurrence while the sums are exact in double.
+    With an 11-decade burst the reference's running sum keeps the rounding it made while it was
+    large (absolute error up to steps * ulp(largest sum so far)); the restarted chunks do not, so
+    the two agree to that bound -- the reference's own rounding history -- and no closer."""
+    rng = np.random.default_rng(depth)
+    frames, bins = 1000, 257
+    # multiples of 2^-20 in [0.5, 1): any sum of <= 200 of them is exact in a double
+    exact = (rng.integers(2 ** 19, 2 ** 20, (frames, bins)) / 2.0 ** 20).astype(np.float32)
+    wide = (rng.random((frames, bins)) ** 3).astype(np.float32)
+    wide[300:420] *= np.float32(1e11)                 # a burst 110 dB above the rest
+    for p, is_exact in ((exact, True), (wide, False)):
+        avg, ret = lib.update_avg(lib.AVG_PLAIN, torch_cuda.from_numpy(p).cuda(), depth, 3, 250)
+        avg, ret = avg.cpu().numpy(), ret.cpu().numpy()
+        a = oracle.Averager(512, depth)
+        largest = np.zeros(bins)
+        for f in range(frames):
+            r, want, peak, _ = a.update("plain", p[f], 3, 250, n=bins)
+            largest = np.maximum(largest, np.abs(want))
+            if is_exact:
+                assert np.array_equal(avg[f], want), (f, depth)
+                assert ret[f, 1] == peak and ret[f, 0] == r
+            else:
+                bound = (f + 1) * 2.5e-16 * largest
+                assert np.all(np.abs(avg[f] - want) <= bound + 1e-300), (f, depth)
+
+
 def test_shards_reproduce_the_full_run(lib, torch_cuda):
     """glfer_amd.shard: frame ranges computed from each rank's own sample window (hops + left
     halo, addressed through a virtual base pointer) give exactly the rows of the full run."""
