@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void floor_kernel(const float *__restrict__ ps
   __shared__ float red_v[256];
   __shared__ int red_i[256];
   __shared__ double red_d[256];
-  __shared__ uint32_t sel_prefix, sel_need;
+  __shared__ uint32_t sel_prefix, sel_need, wtot[4];
 
   const int tid = threadIdx.x;
   const float *src = psd + (size_t)blockIdx.x * bins;
@@ -62,15 +62,21 @@ __global__ __launch_bounds__(256) void floor_kernel(const float *__restrict__ ps
       if ((k & mask_hi) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t need = sel_need, c = 0;
-      int d = 0;
-      for (; d < 256; d++) {
-        if (c + hist[d] >= need) break;
-        c += hist[d];
-      }
-      sel_prefix = prefix | ((uint32_t)d << shift);
-      sel_need = need - c;
+    // the digit d whose bucket holds the need-th smallest: inclusive scan of the 256 counts (wave
+    // shuffles + 4 wave totals), the one thread with excl < need <= incl owns it
+    const uint32_t need = sel_need, h = hist[tid];
+    uint32_t incl = h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+      if ((tid & 63) >= o) incl += up;
+    }
+    if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+    __syncthreads();
+    for (int w = 0; w < (tid >> 6); w++) incl += wtot[w];
+    if (incl - h < need && need <= incl) {
+      sel_prefix = prefix | ((uint32_t)tid << shift);
+      sel_need = need - (incl - h);
     }
     __syncthreads();
   }
