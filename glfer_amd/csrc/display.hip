@@ -1,9 +1,9 @@
 // display.hip -- the waterfall column mapping that follows the estimator in the reference's draw
 // routine (main_window_draw, g_main.c:1099-1236), batched over frames:
 //   K7a levels_kernel : the autoscale recurrence on (sig, floor) -> display_max/min per frame
-//                       (g_main.c:1111-1139).  The recurrence rounds to float at every frame, so
-//                       it is inherently sequential: one wave walks the frames, its 64 lanes
-//                       only stage the inputs and outputs through LDS.
+//                       (g_main.c:1111-1139).  The recurrence rounds to float at every frame:
+//                       sequential, but contractive -- chunks walk in parallel after a warm-up and a
+//                       fix-up kernel verifies every seam bit for bit (see below).
 //   K7b map_kernel    : PSD (or averaged PSD) -> dB short (levbuf) -> 0..255 -> palette RGB
 //                       (g_main.c:1186-1236).  One block per frame, HBM-bound byte/short stores;
 //                       the 768-byte palette sits in LDS.
@@ -27,44 +27,105 @@ struct LevelsParams {
 };
 
 // levels: [nframes][4] = {display_max, display_min, display_max_lvl, display_min_lvl}
-__global__ __launch_bounds__(64) void levels_kernel(const float *__restrict__ stats, long long nframes,
-                                                    LevelsParams p, float *__restrict__ levels) {
-  __shared__ float sx[2][64];
-  __shared__ float sy[2][64];
+//
+// The recurrence lvl = (float)(0.01 x + 0.99 lvl) rounds to float at every frame: sequential.  It
+// is also a contraction (0.99 per frame), so two walks over the same frames from different states
+// approach each other and, once within an ulp, merge exactly (each frame merges a 1-ulp gap with
+// probability ~1 %).  The frames are therefore cut into chunks of LEV_CHUNK walked in parallel, each
+// chunk warming up over the LEV_WARM frames before it from an arbitrary state (from the true state
+// when that reaches back to frame 0): the chance that a warm-up of 4096 frames has not merged with
+// the true walk is ~1e-11, and it is not left to chance: levels_fixup_kernel compares every chunk's
+// warm-up end state with its predecessor's final state, bit for bit, and re-walks the chunk from
+// the true state where they differ.  131 072 columns: 10 M columns/s as one walk, ~16x that in chunks.
+constexpr int LEV_CHUNK = 4096, LEV_WARM = 4096;
+
+// Lanes 0 / 1 of a 64-lane block carry the max / min chains over frames [from, to); the other lanes
+// stage loads and stores through LDS.  Frames >= out_from get their levels written.
+__device__ __forceinline__ void levels_walk(const float *__restrict__ stats, long long from, long long to,
+                                            long long out_from, const LevelsParams &p, float overlap, float &lvl,
+                                            bool &first, float *__restrict__ levels, float (&sx)[2][64],
+                                            float (&sy)[2][64]) {
   const int lane = threadIdx.x;
-  float lvl = (lane == 0) ? p.max_lvl0 : p.min_lvl0;       // lanes 0 / 1 carry the two chains
-  bool first = p.first_buffer != 0;
-  for (long long base = 0; base < nframes; base += 64) {
+  for (long long base = from; base < to; base += 64) {
     const long long f = base + lane;
-    if (f < nframes) {
+    if (f < to) {
       sx[0][lane] = stats[f * 4 + 0];
       sx[1][lane] = stats[f * 4 + 1];
     }
     __syncthreads();
     if (lane < 2) {
-      const int cnt = (int)((nframes - base < 64) ? (nframes - base) : 64);
+      const int cnt = (int)((to - base < 64) ? (to - base) : 64);
       for (int j = 0; j < cnt; j++) {
         float x = sx[lane][j];
-        if (p.autoscale) {
-          if (first) {                                     // g_main.c:1112-1120
-            if (p.overlap > 0.0) x /= p.overlap;
-            lvl = x;
-            first = false;
-          } else {                                         // g_main.c:1122-1123
-            lvl = (float)((1.0 - 0.99) * (double)x + 0.99 * (double)lvl);
-          }
+        if (first) {                                       // g_main.c:1112-1120
+          if (overlap > 0.0) x /= overlap;
+          lvl = x;
+          first = false;
+        } else {                                           // g_main.c:1122-1123
+          lvl = (float)((1.0 - 0.99) * (double)x + 0.99 * (double)lvl);
         }
         sy[lane][j] = lvl;
       }
     }
     __syncthreads();
-    if (f < nframes) {
+    if (f < to && f >= out_from) {
       const float mx = sy[0][lane], mn = sy[1][lane];
       float *o = levels + f * 4;
       o[0] = p.scale_log ? (float)(10.0 * log10((double)mx)) : mx;   // g_main.c:1132-1139
       o[1] = p.scale_log ? (float)(10.0 * log10((double)mn)) : mn;
       o[2] = mx;
       o[3] = mn;
+    }
+    __syncthreads();
+  }
+}
+
+// chunk state: [chunk][4] = {warm-up end max, min, final max, min}
+__global__ __launch_bounds__(64) void levels_kernel(const float *__restrict__ stats, long long nframes,
+                                                    LevelsParams p, float *__restrict__ levels,
+                                                    float *__restrict__ chunk_state) {
+  __shared__ float sx[2][64];
+  __shared__ float sy[2][64];
+  const int lane = threadIdx.x;
+  const long long c = blockIdx.x, begin = c * LEV_CHUNK;
+  const long long end = begin + LEV_CHUNK < nframes ? begin + LEV_CHUNK : nframes;
+  const long long ws = begin - LEV_WARM;
+  float lvl = (lane == 0) ? p.max_lvl0 : p.min_lvl0;       // the state carried into the call
+  bool first;
+  if (ws <= 0) {                                           // the walk starts at frame 0: the true state
+    first = p.first_buffer != 0;
+    levels_walk(stats, 0, begin, begin, p, p.overlap, lvl, first, levels, sx, sy);
+  } else {                                                 // warm-up from an arbitrary state (lvl = x[ws])
+    first = true;
+    levels_walk(stats, ws, begin, begin, p, 0.0f, lvl, first, levels, sx, sy);
+  }
+  if (lane < 2) chunk_state[c * 4 + lane] = lvl;
+  levels_walk(stats, begin, end, begin, p, p.overlap, lvl, first, levels, sx, sy);
+  if (lane < 2) chunk_state[c * 4 + 2 + lane] = lvl;
+}
+
+// One block: where a chunk's warm-up did not end in its predecessor's final state (bit for bit),
+// walk the chunk again from that state.
+__global__ __launch_bounds__(64) void levels_fixup_kernel(const float *__restrict__ stats, long long nframes,
+                                                          LevelsParams p, float *__restrict__ levels,
+                                                          float *__restrict__ chunk_state, int nchunks) {
+  __shared__ float sx[2][64];
+  __shared__ float sy[2][64];
+  __shared__ int differs;
+  const int lane = threadIdx.x;
+  for (int c = 1; c < nchunks; c++) {
+    if (lane == 0) differs = 0;
+    __syncthreads();
+    if (lane < 2 && __float_as_uint(chunk_state[c * 4 + lane]) != __float_as_uint(chunk_state[(c - 1) * 4 + 2 + lane]))
+      differs = 1;
+    __syncthreads();
+    if (differs) {                                         // block-uniform
+      const long long begin = (long long)c * LEV_CHUNK;
+      const long long end = begin + LEV_CHUNK < nframes ? begin + LEV_CHUNK : nframes;
+      float lvl = lane < 2 ? chunk_state[(c - 1) * 4 + 2 + lane] : 0.0f;
+      bool first = false;
+      levels_walk(stats, begin, end, begin, p, p.overlap, lvl, first, levels, sx, sy);
+      if (lane < 2) chunk_state[c * 4 + 2 + lane] = lvl;
     }
     __syncthreads();
   }
@@ -126,12 +187,19 @@ __global__ __launch_bounds__(256) void map_kernel(const SRC *__restrict__ src, i
 
 using namespace glfer;
 
+extern "C" size_t glfer_levels_scratch_floats(size_t nframes) { return 4 * ((nframes + LEV_CHUNK - 1) / LEV_CHUNK); }
+
+// chunk_state: device scratch of glfer_levels_scratch_floats(nframes) floats
 extern "C" hipError_t glfer_launch_levels(const float *stats, size_t nframes, int scale_log, int autoscale,
                                           int first_buffer, float overlap, float max_lvl0, float min_lvl0,
-                                          float *levels, hipStream_t st) {
+                                          float *levels, float *chunk_state, hipStream_t st) {
   if (nframes == 0) return hipSuccess;
   LevelsParams p{scale_log, autoscale, first_buffer, overlap, max_lvl0, min_lvl0};
-  hipLaunchKernelGGL(levels_kernel, dim3(1), dim3(64), 0, st, stats, (long long)nframes, p, levels);
+  const int nchunks = (int)((nframes + LEV_CHUNK - 1) / LEV_CHUNK);
+  hipLaunchKernelGGL(levels_kernel, dim3(nchunks), dim3(64), 0, st, stats, (long long)nframes, p, levels, chunk_state);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || nchunks == 1) return e;
+  hipLaunchKernelGGL(levels_fixup_kernel, dim3(1), dim3(64), 0, st, stats, (long long)nframes, p, levels, chunk_state, nchunks);
   return hipGetLastError();
 }
 

@@ -100,10 +100,12 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
   float *levels = d_levels;
   float *scratch = nullptr;
   unsigned char *d_tab = nullptr;
-  if (!levels) {
-    HIP_TRY(hipMalloc(&scratch, nframes * 4 * sizeof(float)));
-    levels = scratch;
-  }
+  // one allocation: the levels rows (when the caller does not want them) + the chunk states of the
+  // autoscale walk
+  const size_t lev_floats = levels ? 0 : nframes * 4, st_floats = d->autoscale ? glfer_levels_scratch_floats(nframes) : 0;
+  if (lev_floats + st_floats) HIP_TRY(hipMalloc(&scratch, (lev_floats + st_floats) * sizeof(float)));
+  if (!levels) levels = scratch;
+  float *chunk_state = scratch ? scratch + lev_floats : nullptr;
   int rc = GLFER_OK;
   auto fail = [&](hipError_t err) { rc = hip_fail(err, "glfer_hip_display_device"); };
   hipError_t e = hipMalloc(&d_tab, 768);
@@ -117,7 +119,7 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
   if (rc == GLFER_OK) {
     if (d->autoscale) {
       e = glfer_launch_levels(d_stats, nframes, scale_log, 1, d->first_buffer, d->overlap, d->display_max_lvl,
-                              d->display_min_lvl, levels, st);
+                              d->display_min_lvl, levels, chunk_state, st);
     } else {                                                                   // g_main.c:1125-1139
       float mx = pow(10.0, d->max_level_db / 10.0);
       float mn = pow(10.0, d->min_level_db / 10.0);

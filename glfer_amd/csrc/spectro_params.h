@@ -60,9 +60,10 @@ hipError_t glfer_launch_spectro16h_n11(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n13(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n14(const SpectroParams *p, hipStream_t st);
+size_t glfer_levels_scratch_floats(size_t nframes);
 hipError_t glfer_launch_levels(const float *stats, size_t nframes, int scale_log, int autoscale,
                                int first_buffer, float overlap, float max_lvl0, float min_lvl0,
-                               float *levels, hipStream_t st);
+                               float *levels, float *chunk_state, hipStream_t st);
 hipError_t glfer_launch_levels_fixed(size_t nframes, float dmax, float dmin, float max_lvl, float min_lvl,
                                      float *levels, hipStream_t st);
 hipError_t glfer_launch_map(const float *psd, const double *avg, size_t nframes, int n, int scale_log,

@@ -88,6 +88,30 @@ def test_linear_scale_pixels_are_exact(lib, oracle, torch_cuda):
         assert (d.first_buffer, d.display_max_lvl, d.display_min_lvl) == st
 
 
+def test_autoscale_levels_over_many_chunks(lib, oracle, torch_cuda):
+    """20 000 columns: the device walks the level recurrence in 4096-column chunks in parallel (each
+    after a warm-up, every seam verified bit for bit and re-walked if needed); the result must be
+    the sequential recurrence exactly, whatever the data does at the seams (steps of 6 decades,
+    zeros, a constant stretch)."""
+    rng = np.random.default_rng(5)
+    frames, bins = 20000, 17
+    stats = np.abs(rng.standard_normal((frames, 4))).astype(np.float32) + np.float32(1e-3)
+    stats[:, 1] *= np.float32(0.01)
+    stats[4000:4200] *= np.float32(1e6)              # a burst straddling the first seam
+    stats[8190:8195] = 0.0                           # zeros on the second seam
+    stats[12000:13000] = np.float32(0.25)            # constant input: the walk reaches a fixed point
+    psd = (rng.random((frames, bins)) ** 2).astype(np.float32)
+    for first_buffer, state in ((True, (0.0, 0.0)), (False, (3.5, 0.02))):
+        d = lib.Display(palette=4, scale_type=0, autoscale=1, overlap=0.5, first_buffer=int(first_buffer))
+        d.display_max_lvl, d.display_min_lvl = state
+        rgb, lev, levels = lib.display(d, torch_cuda.from_numpy(psd).cuda(), torch_cuda.from_numpy(stats).cuda())
+        w_rgb, w_lev, w_levels, st = oracle.display(psd, stats, palette_id=4, scale_log=False, autoscale=True,
+                                                    overlap=0.5, first_buffer=first_buffer, state=state)
+        assert np.array_equal(levels.cpu().numpy()[:, :2], w_levels)
+        assert np.array_equal(rgb.cpu().numpy(), w_rgb)
+        assert (d.first_buffer, d.display_max_lvl, d.display_min_lvl) == st
+
+
 def test_state_carries_across_calls(lib, oracle, torch_cuda):
     rng = np.random.default_rng(12)
     psd = (rng.random((257, 513)) ** 4).astype(np.float32)
