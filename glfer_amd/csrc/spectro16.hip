@@ -1,4 +1,8 @@
-// spectro16.hip -- fused frame -> taper(s) -> FFT -> |X|^2 -> taper-sum kernel (gfx950), v3.
+// spectro16.hip -- fused frame -> taper(s) -> FFT -> |X|^2 -> taper-sum kernel (gfx950): the
+// general form.  It serves every configuration; the specialised forms (spectro16h: one taper as a
+// real-input transform; spectro16x / xl / y: odd taper counts) take over where they apply, and
+// this kernel keeps what only it can do: the zero-history frames at the start of a stream, the
+// RA9MB / limiter path, the halfcomplex spectrum output, even taper counts, N = 256 and N >= 8192.
 //
 // Replaces, per audio frame, the reference chain
 //   prepare_audio (fft.c:66-165) -> fft_real_radix2_transform (fft_radix2.c:75-177)
@@ -8,12 +12,10 @@
 // Layout: N/16 lanes per frame, 16 complex points per lane (two real tapered copies of the
 // frame packed as re/im of one complex N-point transform).  Stockham autosort passes of
 // radix 16 (last pass radix N/256 or N/4096), each pass a straight-line in-register DFT,
-// with the frame exchanged through LDS between passes as 8-byte (re,im) words in a
-// +1-per-16 padded layout that is bank-conflict free for both the scattered write and the
-// strided read.  All inter-pass twiddles of a lane are fixed for the whole launch and live
-// in registers (N <= 4096: at most 30 complex).  ~100 VGPRs => 4 waves/SIMD, which is what
-// the FP32 VALU needs to issue at rate on this chip (measured: 1 wave/SIMD issues a v_fma
-// every 8 clocks, 2 waves 78 %, 4 waves 83 %, 8 waves 87 % of 32 lanes/clk).
+// with the frame exchanged through LDS between passes (stockham16.hpp: layouts that are
+// bank-conflict free for writes and reads).  All inter-pass twiddles of a lane are fixed for
+// the whole launch and live in registers (N <= 4096: at most 30 complex).  168 VGPRs, three
+// 256-lane blocks per CU at N = 4096.
 //
 // Because taper weights and 1/N are folded into the tapers,
 //   sum_j w_j |Y_j[k]|^2 = sum_pairs (|Z_k|^2 + |Z_{N-k}|^2)/2,
