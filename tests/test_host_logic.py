@@ -114,3 +114,20 @@ def test_palettes_match_reference_tables(lib, oracle):
         assert np.array_equal(lib.palette(p_n), g["palettes"][p_n]), name
         assert np.array_equal(lib.palette(p_n), oracle.palette(p_n)), name
     assert np.array_equal(lib.palette(-3), lib.palette(lib.PALETTES["bw"]))
+
+
+def test_headers_compile_as_c99(tmp_path):
+    """include/*.h are the boundary a C caller (glfer itself) binds: a C99 translation unit that
+    uses both headers must compile cleanly, and its undefined symbols must all be exported."""
+    import subprocess
+    obj = tmp_path / "probe.o"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c",
+                    os.path.join(ROOT, "tests", "c_abi_probe.c"), "-o", str(obj)], check=True)
+    und = subprocess.run(["nm", "-u", str(obj)], check=True, capture_output=True, text=True).stdout.split()
+    wanted = {s for s in und if s.startswith(("glfer_", "fft_", "mtm_"))}
+    have = set()
+    for so in ("libglfer_hip.so", "libglfer_compat.so"):
+        out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "glfer_amd", "lib", so)], check=True,
+                             capture_output=True, text=True).stdout
+        have |= {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert wanted and wanted <= have, wanted - have
