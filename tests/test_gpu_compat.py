@@ -165,3 +165,28 @@ def test_hparma_do_hop_by_hop(compat, oracle):
         _set(compat, "glfer_compat_first_buffer", 0)
         assert max(rel_err(1.0 / psd[:n // 2].astype(np.float64), 1.0 / want[f, :n // 2].astype(np.float64))) < 1e-4
     compat.hparma_close(C.byref(p))
+
+
+@pytest.mark.parametrize("mode,n,overlap", [("fft", 1024, 0.5), ("mtm", 4096, 0.75)])
+def test_c_program_against_the_shim(oracle, tmp_path, mode, n, overlap):
+    """A C program that calls the reference's own entry points hop by hop, compiled with gcc and
+    linked against libglfer_compat.so (no Python, no ctypes in the data path), against the oracle."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "glfer_amd", "lib")
+    exe = tmp_path / "c_compat_demo"
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_compat_demo.c"), "-o", str(exe), "-L", libdir, "-lglfer_compat",
+                    "-lglfer_hip", "-Wl,-rpath," + libdir], check=True)
+    h = oracle.hop(n, overlap)
+    x = synth(7 * h, seed=31) + np.float32(0.03)
+    (tmp_path / "in.f32").write_bytes(x.tobytes())
+    subprocess.run([str(exe), mode, str(n), repr(overlap), str(tmp_path / "in.f32"), str(tmp_path / "out.f32")],
+                   check=True, timeout=120)
+    got = np.fromfile(tmp_path / "out.f32", np.float32).reshape(7, n // 2 + 1)
+    if mode == "fft":
+        want = oracle.spectrogram_fft(x, n, overlap, 0, sub_mean=1)       # autoscale on: mean removal (fft.c:186)
+    else:
+        want = oracle.spectrogram_mtm(x, n, overlap, 2.5, 4, sub_mean=1)
+    for f in range(7):
+        assert np.abs(got[f] - want[f]).max() <= TOL * want[f].max(), f
