@@ -55,6 +55,8 @@ def main():
     fft_case("c2_fft4096_hann_ovl75_s0", 4096, 0.75, "hanning", 12, 48000.0, 0)
     mtm_case("c3_mtm4096_nw25_k4_ovl0_s0", 4096, 0.0, 2.5, 4, 6, 48000.0, 0)
     mtm_case("c3_mtm4096_nw25_k4_ovl75_s1", 4096, 0.75, 2.5, 4, 10, 48000.0, 1)
+    # BASELINE config 4: N=16384, NW=4.5, 9 tapers (three frames keep the file small)
+    mtm_case("c4_mtm16384_nw45_k8_ovl0_s0", 16384, 0.0, 4.5, 8, 3, 48000.0, 0)
     # BASELINE config 5: HP-ARMA t=128, p_e=32, N=4096 (psd + AR vector + rank per frame)
     x = synth(4 * 4096, seed=5)
     fr = O.hparma_frames(x, 4096, 0.0, 128, 32)
