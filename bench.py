@@ -106,6 +106,8 @@ def main():
         n, overlap, nw, kmax = 4096, 0.75, 0.0, 0
         params = G.FftParams(n=n, window_type=G.WINDOWS["hanning"], overlap=overlap)
         name = "C2: periodogram Hanning N=4096, overlap 75%, 48 kHz mono f32"
+        if args.frames == 262144:
+            args.frames = 1048576                     # a 2^30-sample stream per GPU
     sp = G.Spectrogram(params, device=local)
     hop, bins = sp.hop, sp.bins
     frames = args.frames

@@ -46,7 +46,7 @@ for r in csv.DictReader(open(one("sq/*/*_counter_collection.csv"))):
     if r["Kernel_Name"] == KNAME:
         sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
 sq = {n: sum(v) / len(v) for n, v in sq.items()}
-frames, hop, bins = (262144, 4096, 2049) if workload == "mtm" else (262144, 1024, 2049)
+frames, hop, bins = (262144, 4096, 2049) if workload == "mtm" else (1048576, 1024, 2049)
 alg = frames * (4 * hop + 4 * bins)
 # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports exactly half
 # the bytes of a coalesced streaming read -> doubled here; WRITE_SIZE reads the bytes exactly.
