@@ -107,7 +107,6 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   }
   __syncthreads();
   const v2f32 *tw1row = tw1 + (t & 15) * 17;
-  const long long stride = (long long)gridDim.x * FPB;
 
   v2f32 px[16];
   // The launcher hands this kernel only frames that lie wholly inside the stream
@@ -140,8 +139,13 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     }
   };
 
-  long long fblk = (long long)xcd_block_index() * FPB;
-  if (fblk >= p.nframes) return;
+  // Each block walks a CONTIGUOUS range of frame groups: with overlapped frames the samples a frame
+  // shares with its predecessor were read by this same block one iteration earlier (L1/L2 hits),
+  // whatever the other blocks are doing.  (Neighbouring ranges sit on the same XCD: xcd_block_index.)
+  const long long groups = (p.nframes + FPB - 1) / FPB, per = (groups + gridDim.x - 1) / gridDim.x;
+  long long fblk = (long long)xcd_block_index() * per * FPB;
+  const long long fend = (fblk + per * FPB < p.nframes) ? fblk + per * FPB : (long long)p.nframes;
+  if (fblk >= fend) return;
   prefetch_x(fblk);
 
   constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
@@ -157,8 +161,8 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       zr[m] = px[m].x * w.x;
       zi[m] = px[m].y * w.y;
     }
-    const long long nfblk = fblk + stride;
-    const bool has_next = nfblk < p.nframes;
+    const long long nfblk = fblk + FPB;
+    const bool has_next = nfblk < fend;
 
     stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
       if (has_next) prefetch_x(nfblk);
