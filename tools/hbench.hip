@@ -91,6 +91,10 @@ int main(int argc, char **argv) {
   timeit("real-input N/2, WPS=4 var1, grid 4096", [&] { hipLaunchKernelGGL((KH(4, 1)), dim3(4096), dim3(256), 0, 0, sp); });
   timeit("real-input N/2, WPS=3 var2, grid 3072", [&] { hipLaunchKernelGGL((KH(3, 2)), dim3(3072), dim3(256), 0, 0, sp); });
   timeit("real-input N/2, WPS=4 var2, grid 4096", [&] { hipLaunchKernelGGL((KH(4, 2)), dim3(4096), dim3(256), 0, 0, sp); });
+  timeit("real-input N/2, WPS=3 var2, grid 768", [&] { hipLaunchKernelGGL((KH(3, 2)), dim3(768), dim3(256), 0, 0, sp); });
+  timeit("real-input N/2, WPS=3 var2, grid 1536", [&] { hipLaunchKernelGGL((KH(3, 2)), dim3(1536), dim3(256), 0, 0, sp); });
+  timeit("real-input N/2, WPS=3 var2, grid 6144", [&] { hipLaunchKernelGGL((KH(3, 2)), dim3(6144), dim3(256), 0, 0, sp); });
+  timeit("real-input N/2, WPS=3 var2, grid 12288", [&] { hipLaunchKernelGGL((KH(3, 2)), dim3(12288), dim3(256), 0, 0, sp); });
   timeit("real-input N/2, WPS=3 var0 again", [&] { hipLaunchKernelGGL((KH(3, 0)), dim3(3072), dim3(256), 0, 0, sp); });
   std::vector<float> a((size_t)256 * P), b((size_t)256 * P);
   CK(hipMemcpy(a.data(), d_psd1, a.size() * 4, hipMemcpyDeviceToHost));
