@@ -12,6 +12,7 @@
 #define GLFER_NO_LAUNCHERS
 #include "spectro16.hip"
 #include "spectro16x.hip"
+#include "spectro16y.hip"
 #include "host_tables.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -84,6 +85,16 @@ int main(int argc, char **argv) {
   timeit("shared odd taper, WPS=2, grid 2048", [&] { hipLaunchKernelGGL((KX(2)), dim3(2048), dim3(256), 0, 0, sp); });
   timeit("shared odd taper, WPS=2, grid 512", [&] { hipLaunchKernelGGL((KX(2)), dim3(512), dim3(256), 0, 0, sp); });
   timeit("shared odd taper, WPS=3, grid 3072 again", [&] { hipLaunchKernelGGL((KX(3)), dim3(3072), dim3(256), 0, 0, sp); });
+  {
+    auto ky = glfer::spectro16y_kernel<GLFER_FMT_F32>;
+    const size_t shy = (size_t)glfer::LaunchY::LDS_WORDS * 8;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(ky), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shy));
+    for (unsigned g : {512u, 1024u, 2048u, 4096u, 8192u}) {
+      char label[64];
+      snprintf(label, sizeof label, "two frames/wavefront (y), grid %u", g);
+      timeit(label, [&] { hipLaunchKernelGGL(ky, dim3(g), dim3(256), shy, 0, sp); });
+    }
+  }
   std::vector<float> a((size_t)256 * P), b((size_t)256 * P);
   CK(hipMemcpy(a.data(), d_psd1, a.size() * 4, hipMemcpyDeviceToHost));
   CK(hipMemcpy(b.data(), d_psd2, b.size() * 4, hipMemcpyDeviceToHost));
