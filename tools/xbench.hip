@@ -85,11 +85,23 @@ int main(int argc, char **argv) {
   timeit("shared odd taper, WPS=2, grid 2048", [&] { hipLaunchKernelGGL((KX(2)), dim3(2048), dim3(256), 0, 0, sp); });
   timeit("shared odd taper, WPS=2, grid 512", [&] { hipLaunchKernelGGL((KX(2)), dim3(512), dim3(256), 0, 0, sp); });
   timeit("shared odd taper, WPS=3, grid 3072 again", [&] { hipLaunchKernelGGL((KX(3)), dim3(3072), dim3(256), 0, 0, sp); });
+  timeit("shared odd taper, WPS=3, grid 6144", [&] { hipLaunchKernelGGL((KX(3)), dim3(6144), dim3(256), 0, 0, sp); });
+  timeit("shared odd taper, WPS=3, grid 12288", [&] { hipLaunchKernelGGL((KX(3)), dim3(12288), dim3(256), 0, 0, sp); });
+  sp.psd = d_psd1;
+  timeit("packed, WPS=3, grid 6144", [&] { hipLaunchKernelGGL((glfer::spectro16_kernel<LOGN, GLFER_FMT_F32, false, 3>), dim3(6144), dim3(256), 0, 0, sp); });
+  timeit("packed, WPS=3, grid 12288", [&] { hipLaunchKernelGGL((glfer::spectro16_kernel<LOGN, GLFER_FMT_F32, false, 3>), dim3(12288), dim3(256), 0, 0, sp); });
+  timeit("packed, WPS=3, grid 24576", [&] { hipLaunchKernelGGL((glfer::spectro16_kernel<LOGN, GLFER_FMT_F32, false, 3>), dim3(24576), dim3(256), 0, 0, sp); });
+  timeit("packed, WPS=3, grid 65536", [&] { hipLaunchKernelGGL((glfer::spectro16_kernel<LOGN, GLFER_FMT_F32, false, 3>), dim3(65536), dim3(256), 0, 0, sp); });
+  timeit("packed, WPS=3, grid 4608", [&] { hipLaunchKernelGGL((glfer::spectro16_kernel<LOGN, GLFER_FMT_F32, false, 3>), dim3(4608), dim3(256), 0, 0, sp); });
+  sp.psd = d_psd2;
+  timeit("shared odd taper, WPS=3, grid 24576", [&] { hipLaunchKernelGGL((KX(3)), dim3(24576), dim3(256), 0, 0, sp); });
+  timeit("shared odd taper, WPS=3, grid 65536", [&] { hipLaunchKernelGGL((KX(3)), dim3(65536), dim3(256), 0, 0, sp); });
+  sp.psd = d_psd2;
   {
     auto ky = glfer::spectro16y_kernel<GLFER_FMT_F32>;
     const size_t shy = (size_t)glfer::LaunchY::LDS_WORDS * 8;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(ky), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shy));
-    for (unsigned g : {512u, 1024u, 2048u, 4096u, 8192u}) {
+    for (unsigned g : {2048u, 8192u, 16384u, 32768u, 65536u, 131072u}) {
       char label[64];
       snprintf(label, sizeof label, "two frames/wavefront (y), grid %u", g);
       timeit(label, [&] { hipLaunchKernelGGL(ky, dim3(g), dim3(256), shy, 0, sp); });
