@@ -24,7 +24,8 @@ struct LaunchY {
   static constexpr int LDS_WORDS = 2 * PADN + 16 * 17 + 4;       // two exchange buffers, pass-1 twiddles, power partials
 };
 
-template <int FMT>
+// ABL (tools/xbench timing ablations only; results are wrong): 1 = skip the shared round
+template <int FMT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
   using C = Plan16<12>;
   using L = LaunchY;
@@ -178,6 +179,17 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
       __syncthreads();                               // fold buffers read: free for the next writes
     }
 
+    if constexpr (ABL == 1) {
+      if (has_next) {
+        prefetch_taps(0);
+        load_x(xA, nfA);
+        if (nfA + 1 < p.nframes) load_x(xB, nfA + 1);
+      }
+      if (t == 0) p.psd[(size_t)fA * (N / 2 + 1)] = psdA[0] + psdB[0] + nyqA + nyqB + (float)(hxA + hxB);
+      if (!has_next) break;
+      fA = nfA;
+      continue;
+    }
     // ---- shared round: re = sA*(xA*v), im = sB*(xB*v), v the last taper
     float zr[16], zi[16];
     GLFER_STAMP(0);                                  // shared round start

@@ -107,6 +107,16 @@ int main(int argc, char **argv) {
       timeit(label, [&] { hipLaunchKernelGGL(ky, dim3(g), dim3(256), shy, 0, sp); });
     }
   }
+  {
+    auto k1 = glfer::spectro16y_kernel<GLFER_FMT_F32, 1>;
+    const size_t shy = (size_t)glfer::LaunchY::LDS_WORDS * 8;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shy));
+    auto k0 = glfer::spectro16y_kernel<GLFER_FMT_F32, 0>;
+    for (int rep = 0; rep < 2; rep++) {
+      timeit("y, grid 8192", [&] { hipLaunchKernelGGL(k0, dim3(8192), dim3(256), shy, 0, sp); });
+      timeit("y, grid 8192, ABL: no shared round", [&] { hipLaunchKernelGGL(k1, dim3(8192), dim3(256), shy, 0, sp); });
+    }
+  }
   std::vector<float> a((size_t)256 * P), b((size_t)256 * P);
   CK(hipMemcpy(a.data(), d_psd1, a.size() * 4, hipMemcpyDeviceToHost));
   CK(hipMemcpy(b.data(), d_psd2, b.size() * 4, hipMemcpyDeviceToHost));
