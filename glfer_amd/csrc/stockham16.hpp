@@ -80,9 +80,14 @@ __device__ __forceinline__ unsigned xcd_block_index() {
   return (g & 7u) ? w : (w & 7u) * (g >> 3) + (w >> 3);
 }
 
+// GLFER_ABL (tools/xbench timing ablations only; results are wrong): bit 0 = no workgroup barriers,
+// bit 1 = no exchange writes, bit 2 = no exchange reads
+#ifndef GLFER_ABL
+#define GLFER_ABL 0
+#endif
 template <int T>
 __device__ __forceinline__ void frame_sync() {
-  if constexpr (T > 64) {
+  if constexpr (T > 64 && !(GLFER_ABL & 1)) {
     __syncthreads();
   } else {                       // the frame lives in one wave: LDS ops of a wave are in order
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -188,7 +193,7 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
       v2f32 *wbase = kRows ? xb + t : xb + a0 + (a0 >> xpad_shift(i));
       dit_emit<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
         constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
-        wbase[kRows ? q * (T + 2) : xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
+        if constexpr (!(GLFER_ABL & 2)) wbase[kRows ? q * (T + 2) : xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
       });
     } else {
       static_for<0, B>([&](auto bc) {
@@ -219,7 +224,8 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
       GLFER_STAMP(4 * i + 3);              // writes (and the hook's loads) issued
       frame_sync<T>();
       GLFER_STAMP(4 * i + 4);              // through the post-write barrier
-      if constexpr (GLFER16_X0_ROWS != 0 && GLFER16_BARRIER_AFTER_READS != 0 && i == 0 && T >= 32 && B == 1) {
+      if constexpr (GLFER_ABL & 4) {
+      } else if constexpr (GLFER16_X0_ROWS != 0 && GLFER16_BARRIER_AFTER_READS != 0 && i == 0 && T >= 32 && B == 1) {
         v2f32 v[16];
         lds_read16_strided<T / 16>(xb + (t & 15) * (T + 2) + (t >> 4), v);
 #pragma unroll
@@ -292,7 +298,7 @@ __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA
         v2f32 *wbase = kRows ? xb + t : xb + a0 + (a0 >> xpad_shift(i));
         dit_emit<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
           constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
-          wbase[kRows ? q * (T + 2) : xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
+          if constexpr (!(GLFER_ABL & 2)) wbase[kRows ? q * (T + 2) : xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
         });
       } else {
         static_for<0, B>([&](auto bc) {
@@ -311,7 +317,8 @@ __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA
       GLFER_STAMP(4 * i + 2);                // stream B: pass i done, its writes (and the hook's loads) issued
       frame_sync<T>();                       // both streams' writes are in LDS
       GLFER_STAMP(4 * i + 3);                // through the post-write barrier
-      if constexpr (GLFER16_X0_ROWS != 0 && i == 0 && T >= 32) {
+      if constexpr (GLFER_ABL & 4) {
+      } else if constexpr (GLFER16_X0_ROWS != 0 && i == 0 && T >= 32) {
         v2f32 va[16], vb[16];
         const int roff = (int)(t & 15) * (T + 2) + (int)(t >> 4);
         lds_read16_strided<T / 16>(xbA + roff, va);
