@@ -472,7 +472,12 @@ static hipError_t launch_shared_odd(const SpectroParams &sp, int n, hipStream_t 
 // The first ceil(R/H) frames of a stream reach back before sample 0 (zero history, fft.c:103-108);
 // they stay with spectro16.hip, which has the range-checked gather for that.
 static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
-  const bool real_input = sp.htaps && sp.npairs == 1 && n >= 512;
+  // spectro16h.hip fetches y[2j], y[2j+1] with one load: integer samples must then sit on naturally
+  // aligned pairs (even hop, so every frame starts on an even sample, and an aligned stream)
+  const unsigned esz = sp.fmt == GLFER_FMT_F32 ? 4u : (sp.fmt == GLFER_FMT_S16 ? 2u : 1u);
+  const bool pairs_aligned = sp.fmt == GLFER_FMT_F32 ||
+                             ((sp.H & 1) == 0 && (reinterpret_cast<uintptr_t>(sp.stream) & (2u * esz - 1u)) == 0);
+  const bool real_input = sp.htaps && sp.npairs == 1 && n >= 512 && pairs_aligned;
   // built where it fits 3 waves/SIMD without spilling (N = 2048 and N >= 8192 do not: they stay packed)
   const bool shared_odd = sp.xtaps && sp.npairs >= 2 && (sp.ltaps || n <= 1024 || n == 4096);
   if (sp.spec || sp.nonlin || !(real_input || shared_odd)) return launch_packed(sp, n, st);

@@ -34,6 +34,15 @@
 #define GLFER_LOGN_OR(d) d
 #endif
 
+// GLFER_H_ABL (tools/hbench timing ablations only; results are wrong): bit 0 = no PSD stores,
+// bit 1 = no sample loads after a block's first frame
+#ifndef GLFER_H_ABL
+#define GLFER_H_ABL 0
+#endif
+#ifndef GLFER16H_STORE_AUX
+#define GLFER16H_STORE_AUX 2       /* non-temporal: rows are written once (tools/hbench: +3 % over aux 0) */
+#endif
+
 namespace glfer {
 
 template <int LOGN>
@@ -57,6 +66,10 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   constexpr int NTWR = C::NTW - TW1;
   constexpr int NT = NTWR > 0 ? NTWR : 1;
   constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  // integer samples stay raw in their registers until the frame is formed (a conversion next to the
+  // load would wait for it: no prefetch), and their power-of-two scale (wav_fmt.c:104-117) rides in
+  // the window -- (x/32768)*w and x*(w/32768) are the same float
+  constexpr float kSampleScale = FMT == GLFER_FMT_F32 ? 1.0f : (FMT == GLFER_FMT_S16 ? 1.0f / 32768.0f : 1.0f / 128.0f);
   __shared__ v2f32 lds[L::LDS_WORDS + (VAR == 2 ? M : 0)];
 
   const unsigned tid = threadIdx.x;
@@ -92,8 +105,8 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
 #pragma unroll
     for (int mh = 0; mh < 8; mh++) {
       const v4f32 q = ht[T * mh];
-      wn[2 * mh] = v2f32{q.x, q.y};
-      wn[2 * mh + 1] = v2f32{q.z, q.w};
+      wn[2 * mh] = v2f32{q.x, q.y} * kSampleScale;
+      wn[2 * mh + 1] = v2f32{q.z, q.w} * kSampleScale;
     }
   };
   v2f32 *wl = lds + L::LDS_WORDS;                 // VAR 2: wl[m*T + t]
@@ -120,23 +133,38 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
     const unsigned lrel = flc * (unsigned)p.H + 2u * t;
+    // y[2n] and y[2n+1] are adjacent: ONE load per pair in every format (the launcher sends streams
+    // whose pairs are not naturally aligned to spectro16.hip)
     static_for<0, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       if constexpr (FMT == GLFER_FMT_F32) {
         px[m] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, lrel * 4u, (unsigned)(2 * T * m) * 4u, 0));
+      } else if constexpr (FMT == GLFER_FMT_S16) {
+        px[m].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, lrel * 2u, (unsigned)(2 * T * m) * 2u, 0));
       } else {
-        px[m].x = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(2 * T * m) * esz);
-        px[m].y = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(2 * T * m + 1) * esz);
+        px[m].x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, lrel, (unsigned)(2 * T * m), 0));
       }
     });
-    if (p.history_mode) {
-      const int d = 2 * (int)t - p.R;                  // sample j = 2*(t + T*m) + e is kept iff j >= R
-      static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        px[m].x = (d >= -2 * T * m) ? px[m].x : 0.0f;
-        px[m].y = (d + 1 >= -2 * T * m) ? px[m].y : 0.0f;
-      });
+  };
+  // the pair as floats (integer formats: unscaled, see kSampleScale), with history_mode 1's zeroing
+  auto sample_pair = [&](auto mc) -> v2f32 {
+    constexpr int m = decltype(mc)::value;
+    v2f32 x;
+    if constexpr (FMT == GLFER_FMT_F32) {
+      x = px[m];
+    } else if constexpr (FMT == GLFER_FMT_S16) {
+      const int raw = (int)__float_as_uint(px[m].x);
+      x = v2f32{(float)(short)(raw & 0xffff), (float)(raw >> 16)};
+    } else {
+      const unsigned raw = __float_as_uint(px[m].x);
+      x = v2f32{(float)(raw & 0xffu) - 128.0f, (float)((raw >> 8) & 0xffu) - 128.0f};
     }
+    if (p.history_mode) {                              // sample j = 2*(t + T*m) + e is kept iff j >= R
+      const int d = 2 * (int)t - p.R;
+      x.x = (d >= -2 * T * m) ? x.x : 0.0f;
+      x.y = (d + 1 >= -2 * T * m) ? x.y : 0.0f;
+    }
+    return x;
   };
 
   // Each block walks a CONTIGUOUS range of frame groups: with overlapped frames the samples a frame
@@ -155,17 +183,24 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   while (true) {
     float zr[16], zi[16];
     if constexpr (VAR == 1) load_window();
+    v2f32 xs[16];
+    static_for<0, 16>([&](auto mc) { xs[decltype(mc)::value] = sample_pair(mc); });
 #pragma unroll
     for (int m = 0; m < 16; m++) {
       const v2f32 w = VAR == 2 ? wl[m * T + t] : wn[m];
-      zr[m] = px[m].x * w.x;
-      zi[m] = px[m].y * w.y;
+      zr[m] = xs[m].x * w.x;
+      zi[m] = xs[m].y * w.y;
     }
     const long long nfblk = fblk + FPB;
     const bool has_next = nfblk < fend;
 
     stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
-      if (has_next) prefetch_x(nfblk);
+      if constexpr (GLFER_H_ABL & 2) {                 // timing ablation: no sample loads after the first frame
+#pragma unroll
+        for (int m = 0; m < 16; m++) px[m] = px[m] * 0.999f;
+      } else {
+        if (has_next) prefetch_x(nfblk);
+      }
     });
 
     // ---- mirror step: Z[k], k >= M/2, through LDS (entry u = k - M/2)
@@ -176,9 +211,22 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       xb[t + T * (m - 8)] = v2f32{zr[r], zi[r]};
     });
     frame_sync<T>();
-    const long long f = fblk + fl;
-    if (f < p.nframes) {
-      float *o = p.psd + (size_t)f * (N / 2 + 1);
+    {
+      // rows go out through a buffer descriptor over this block's frames: one VGPR offset per
+      // direction (bins k upwards, bins M-k downwards) plus scalar offsets, no address arithmetic,
+      // and frame slots past the last frame fall outside num_records (their stores are dropped)
+      constexpr unsigned ROWB = (unsigned)(M + 1) * 4u;
+      const long long left = p.nframes - fblk;
+      const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+          p.psd + (size_t)fblk * (M + 1), 0, (unsigned)((left > FPB ? FPB : left) * (long long)ROWB), 0x00020000);
+      const unsigned vup = fl * ROWB + t * 4u, vdown = fl * ROWB + (unsigned)(M - 7 * T - (int)t) * 4u;
+      auto put = [&](float v, unsigned voff, unsigned soff) {
+        if constexpr (GLFER_H_ABL & 1) {               // timing ablation: arithmetic kept live, no store traffic
+          if (v == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, voff, soff, GLFER16H_STORE_AUX);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, voff, soff, GLFER16H_STORE_AUX);
+        }
+      };
       static_for<0, 8>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         constexpr int r = rho_of(m);
@@ -197,12 +245,12 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
         const float pr = __builtin_fmaf(c, oi, -s * orr);
         const float pi = -__builtin_fmaf(c, orr, s * oi);
         const float x1r = er + pr, x1i = ei + pi, x2r = er - pr, x2i = ei - pi;
-        o[k] = __builtin_fmaf(x1r, x1r, x1i * x1i);
-        o[M - k] = __builtin_fmaf(x2r, x2r, x2i * x2i);
+        put(__builtin_fmaf(x1r, x1r, x1i * x1i), vup, (unsigned)(T * m) * 4u);              // bin k
+        put(__builtin_fmaf(x2r, x2r, x2i * x2i), vdown, (unsigned)(T * (7 - m)) * 4u);     // bin M - k
       });
       if (t == 0) {                                    // k = M/2 pairs with itself: X = conj(Z)
         constexpr int r = rho_of(8);
-        o[M / 2] = 4.0f * __builtin_fmaf(zr[r], zr[r], zi[r] * zi[r]);
+        put(4.0f * __builtin_fmaf(zr[r], zr[r], zi[r] * zi[r]), vup, (unsigned)(M / 2) * 4u);
       }
     }
     if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();     // mirror entries read: buffer free
@@ -241,6 +289,11 @@ extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16h_n, GLFER_LOGN)(const Spe
   if (!p->htaps || !p->htw || !p->hrot || p->nonlin || p->spec) return hipErrorInvalidValue;
   // the gather has no zero-history path: every frame must lie wholly inside the stream
   if (p->frame0 * (long long)p->H < (long long)p->R) return hipErrorInvalidValue;
+  // integer samples are fetched in pairs (y[2j], y[2j+1]) with one load: pairs must be naturally aligned
+  if (p->fmt != GLFER_FMT_F32) {
+    const unsigned pair = p->fmt == GLFER_FMT_S16 ? 4u : 2u;
+    if ((p->H & 1) || (reinterpret_cast<uintptr_t>(p->stream) & (pair - 1u))) return hipErrorInvalidValue;
+  }
   switch (p->fmt) {
     case GLFER_FMT_F32: return launch16h_fmt<GLFER_FMT_F32>(*p, st);
     case GLFER_FMT_S16: return launch16h_fmt<GLFER_FMT_S16>(*p, st);

@@ -214,6 +214,30 @@ def test_real_input_kernel_agrees_with_packed_kernel(lib, oracle, torch_cuda, n,
         assert np.abs(half[f] - want[f]).max() <= TOL * want[f].max()
 
 
+@pytest.mark.parametrize("fmt,shift", [("s16", 1), ("u8", 1), ("s16", 2), ("u8", 3)])
+def test_integer_streams_off_the_pair_alignment(lib, oracle, torch_cuda, fmt, shift):
+    # The real-input kernel fetches the integer pair (y[2j], y[2j+1]) with one 4- or 2-byte load, so
+    # it needs naturally aligned pairs; a stream that starts `shift` samples into an allocation (a
+    # tensor slice) or an odd hop must be routed to the packed kernel and give the same rows.
+    n, overlap, frames = 2048, 0.5, 70
+    h = oracle.hop(n, overlap)
+    x = synth(frames * h + n + 8, seed=77)
+    if fmt == "s16":
+        raw = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16)
+        conv, sf = oracle.pcm_s16_to_float, lib.SAMPLES_S16
+    else:
+        raw = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8)
+        conv, sf = oracle.pcm_u8_to_float, lib.SAMPLES_U8
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=1, overlap=overlap, sample_format=sf))
+    d = torch_cuda.from_numpy(raw).cuda()
+    got = sp.run(d[shift:].contiguous() if False else d[shift:]).cpu().numpy()
+    want = oracle.spectrogram_fft(conv(raw[shift:]), n, overlap, 1)
+    assert got.shape == want.shape
+    assert max(rel_err(got, want)) < TOL
+    aligned = sp.run(d[shift:].clone()).cpu().numpy()          # same samples in a fresh (aligned) allocation
+    assert rel_err(got, aligned)[0] < 2e-6
+
+
 @pytest.mark.parametrize("n,kmax,nw", [(4096, 4, 2.5), (1024, 2, 2.0), (512, 6, 4.0)])
 def test_quiet_frame_between_loud_frames(lib, oracle, torch_cuda, n, kmax, nw):
     # Odd taper counts: the last taper of two neighbouring frames shares one complex transform
