@@ -2,6 +2,8 @@
 window or taper set, sample format, mean removal, history mode, frame count, a sub-range of frames)
 against the oracle, frame by frame.  Exercises the launcher's splits (zero-history head, aligned
 frame groups, lone tail frames) and every kernel form with parameters nobody hand-picked."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,9 +14,10 @@ TOL = 1e-5
 
 
 def _cases():
-    rng = np.random.default_rng(20260)
+    # GLFER_FUZZ_SEED / GLFER_FUZZ_CASES: a wider one-off sweep (default: the 48 committed cases)
+    rng = np.random.default_rng(int(os.environ.get("GLFER_FUZZ_SEED", "20260")))
     out = []
-    for i in range(48):
+    for i in range(int(os.environ.get("GLFER_FUZZ_CASES", "48"))):
         n = int(rng.choice([256, 512, 1024, 2048, 4096, 4096, 8192]))
         overlap = float(rng.choice([0.0, 0.0, 0.25, 0.33, 0.5, 0.75, 0.9]))
         mode = "mtm" if rng.random() < 0.6 else "fft"
