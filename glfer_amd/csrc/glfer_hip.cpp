@@ -16,8 +16,10 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_tables.h"
@@ -590,6 +592,104 @@ int glfer_hip_spectrum_device(glfer_hip_plan *p, const void *d_stream, size_t ns
   return run_device(p, d_stream, nsamples, first, nframes, d_psd, d_spec, hip_stream);
 }
 
+// memcpy spread over a few threads: the destination is usually fresh pageable memory, where the
+// page faults, not the copy, set the pace
+static void copy_wide(void *dst, const void *src, size_t bytes) {
+  const size_t kMin = (size_t)8 << 20;
+  unsigned nt = bytes < 2 * kMin ? 1u : (unsigned)std::min<size_t>(8, bytes / kMin);
+  const unsigned hw = std::thread::hardware_concurrency();
+  if (hw && nt > hw) nt = hw;
+  if (nt <= 1) { memcpy(dst, src, bytes); return; }
+  std::vector<std::thread> th;
+  const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+  for (unsigned i = 0; i < nt; i++) {
+    const size_t off = (size_t)i * per;
+    if (off >= bytes) break;
+    const size_t len = std::min(per, bytes - off);
+    th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, len); });
+  }
+  for (auto &t : th) t.join();
+}
+
+// Host samples -> host PSD rows, in chunks of whole frames through pinned buffers.  Per chunk:
+// H2D, the estimator, D2H on one stream; while the GPU works on chunk c the host fetches chunk c+1's
+// samples (reader) and moves chunk c-1's rows from their pinned buffer to the caller's memory.  Each
+// device buffer starts with the N-H samples carried over from the previous chunk, and the kernel is
+// given a virtual stream base so that frame indices -- and the zero history of the very first
+// frames -- come out as in a one-shot run.  reader(dst, nframes) fills dst with nframes*hop samples
+// and returns the number of whole frames it delivered.
+static int ingest_chunks(glfer_hip_plan *p, size_t frames, size_t chunk_frames,
+                         const std::function<size_t(unsigned char *, size_t)> &reader, float *h_psd, size_t *nframes_out) {
+  const size_t esz = p->cfg.sample_format == GLFER_SAMPLES_F32 ? 4 : (p->cfg.sample_format == GLFER_SAMPLES_S16 ? 2 : 1);
+  const size_t hop = (size_t)p->hop, bins = (size_t)p->bins;
+  // history kept on the device between chunks: whole hops covering the N-H overlap
+  const size_t halo = (size_t)((p->keep + p->hop - 1) / p->hop) * hop;
+  if (chunk_frames == 0) {                                     // default: 16384 frames, at most 256 MiB of samples
+    chunk_frames = 16384;
+    const size_t cap = ((size_t)256 << 20) / (hop * esz);
+    if (chunk_frames > cap) chunk_frames = cap;
+  }
+  if (chunk_frames < 2 * (halo / hop)) chunk_frames = 2 * (halo / hop);     // halo copy must not overlap itself
+  if (chunk_frames < 1) chunk_frames = 1;
+  chunk_frames = (chunk_frames + GLFER_FRAME_ALIGN - 1) / GLFER_FRAME_ALIGN * GLFER_FRAME_ALIGN;   // see launch_by_n
+  if (chunk_frames > frames) chunk_frames = frames;
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  unsigned char *h_in[2] = {nullptr, nullptr};
+  float *h_out[2] = {nullptr, nullptr}, *d_out = nullptr;
+  unsigned char *d_in = nullptr;
+  hipStream_t st = nullptr;
+  const size_t chunk_bytes = chunk_frames * hop * esz, out_bytes = chunk_frames * bins * sizeof(float);
+  hipError_t e = hipStreamCreate(&st);
+  for (int b = 0; b < 2 && e == hipSuccess; b++) {
+    e = hipHostMalloc((void **)&h_in[b], chunk_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h_out[b], out_bytes, hipHostMallocDefault);
+  }
+  if (e == hipSuccess) e = hipMalloc((void **)&d_in, (halo + chunk_frames * hop) * esz);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_out, out_bytes);
+  int rc = (e == hipSuccess) ? GLFER_OK : hip_fail(e, "ingest: allocate");
+  size_t done = 0, nread = 0, prev_nf = 0, prev_done = 0;
+  int cur = 0;
+  if (rc == GLFER_OK) nread = reader(h_in[0], std::min(chunk_frames, frames));
+  while (rc == GLFER_OK && done < frames && nread > 0) {
+    const size_t nf = nread;
+    // chunk samples land behind the halo; sample 0 of the stream sits at d_in + halo - done*hop
+    e = hipMemcpyAsync(d_in + halo * esz, h_in[cur], nf * hop * esz, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
+    const unsigned char *vbase = d_in + halo * esz - done * hop * esz;   // virtual address of stream sample 0
+    rc = run_device(p, vbase, (done + nf) * hop, done, nf, d_out, nullptr, st);
+    if (rc) break;
+    e = hipMemcpyAsync(h_out[cur], d_out, nf * bins * sizeof(float), hipMemcpyDeviceToHost, st);
+    // keep the last `halo` samples of this chunk in front of the next one (only a full chunk is
+    // ever followed by another, and a full chunk is at least one halo long)
+    if (e == hipSuccess && halo && done + nf < frames)
+      e = hipMemcpyAsync(d_in, d_in + nf * hop * esz, halo * esz, hipMemcpyDeviceToDevice, st);
+    // while the GPU works: fetch the next chunk's samples, hand the previous chunk's rows over
+    // (side by side: both are host memory copies)
+    const size_t want = std::min(chunk_frames, frames - done - nf);
+    nread = 0;
+    std::thread fetch;
+    if (want) fetch = std::thread([&] { nread = reader(h_in[cur ^ 1], want); });
+    if (prev_nf) copy_wide(h_psd + prev_done * bins, h_out[cur ^ 1], prev_nf * bins * sizeof(float));
+    if (fetch.joinable()) fetch.join();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { rc = hip_fail(e, "ingest: chunk"); break; }
+    prev_nf = nf;
+    prev_done = done;
+    done += nf;
+    cur ^= 1;
+  }
+  if (rc == GLFER_OK && prev_nf) copy_wide(h_psd + prev_done * bins, h_out[cur ^ 1], prev_nf * bins * sizeof(float));
+  *nframes_out = done;
+  for (int b = 0; b < 2; b++) {
+    if (h_in[b]) (void)hipHostFree(h_in[b]);
+    if (h_out[b]) (void)hipHostFree(h_out[b]);
+  }
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}
+
 int glfer_hip_spectrogram_host(glfer_hip_plan *p, const void *h_stream, size_t nsamples, float *h_psd,
                                size_t *nframes_out) {
   if (!p || !h_stream || !nframes_out) return GLFER_E_ARG;
@@ -597,28 +697,15 @@ int glfer_hip_spectrogram_host(glfer_hip_plan *p, const void *h_stream, size_t n
   *nframes_out = frames;
   if (frames == 0) return GLFER_OK;
   if (!h_psd) return GLFER_E_ARG;
-  HIP_TRY(hipSetDevice(p->cfg.device));
   const size_t esz = p->cfg.sample_format == GLFER_SAMPLES_F32 ? 4 : (p->cfg.sample_format == GLFER_SAMPLES_S16 ? 2 : 1);
-  const size_t used = frames * (size_t)p->hop;
-  void *d_in = nullptr;
-  float *d_out = nullptr;
-  hipStream_t st = nullptr;
-  int rc = GLFER_OK;
-  hipError_t e = hipStreamCreate(&st);
-  if (e == hipSuccess) e = hipMalloc(&d_in, used * esz);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_out, frames * (size_t)p->bins * sizeof(float));
-  if (e == hipSuccess) e = hipMemcpyAsync(d_in, h_stream, used * esz, hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: staging");
-  if (rc == GLFER_OK) rc = run_device(p, d_in, used, 0, frames, d_out, nullptr, st);
-  if (rc == GLFER_OK) {
-    e = hipMemcpyAsync(h_psd, d_out, frames * (size_t)p->bins * sizeof(float), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: copy back");
-  }
-  if (d_in) (void)hipFree(d_in);
-  if (d_out) (void)hipFree(d_out);
-  if (st) (void)hipStreamDestroy(st);
-  return rc;
+  const size_t hop_bytes = (size_t)p->hop * esz;
+  size_t given = 0;
+  auto reader = [&](unsigned char *dst, size_t want) {
+    copy_wide(dst, (const unsigned char *)h_stream + given * hop_bytes, want * hop_bytes);
+    given += want;
+    return want;
+  };
+  return ingest_chunks(p, frames, 0, reader, h_psd, nframes_out);
 }
 
 // ---- ingest (wav_fmt.c:45-121, source.c:118-128) ------------------------------------------
@@ -656,74 +743,18 @@ int glfer_hip_spectrogram_wav(glfer_hip_plan *p, const char *path, float *h_psd,
   if (rc) return rc;
   const int fmt = wi.bits_per_sample == 8 ? GLFER_SAMPLES_U8 : GLFER_SAMPLES_S16;
   if (p->cfg.sample_format != fmt) return GLFER_E_ARG;
-  const size_t esz = (size_t)wi.bits_per_sample / 8, hop = (size_t)p->hop, bins = (size_t)p->bins;
+  const size_t esz = (size_t)wi.bits_per_sample / 8, hop = (size_t)p->hop;
   size_t frames = wi.nsamples / hop;                             // whole blocks only, wav_fmt.c:119
   if (frames > max_frames) frames = max_frames;
   *nframes_out = frames;
   if (frames == 0) return GLFER_OK;
   if (!h_psd) return GLFER_E_ARG;
-  // history kept on the device between chunks: whole hops covering the N-H overlap
-  const size_t halo = (size_t)((p->keep + p->hop - 1) / p->hop) * hop;
-  if (chunk_frames == 0) chunk_frames = 16384;
-  if (chunk_frames < 2 * (halo / hop)) chunk_frames = 2 * (halo / hop);     // halo copy must not overlap itself
-  if (chunk_frames < 1) chunk_frames = 1;
-  chunk_frames = (chunk_frames + GLFER_FRAME_ALIGN - 1) / GLFER_FRAME_ALIGN * GLFER_FRAME_ALIGN;   // see launch_by_n
-  if (chunk_frames > frames) chunk_frames = frames;
   FILE *f = fopen(path, "rb");
   if (!f) return GLFER_E_ARG;
   if (fseek(f, (long)wi.data_offset, SEEK_SET) != 0) { fclose(f); return GLFER_E_ARG; }
-  HIP_TRY(hipSetDevice(p->cfg.device));
-  unsigned char *h_in[2] = {nullptr, nullptr};
-  float *h_out = nullptr, *d_out = nullptr;
-  unsigned char *d_in = nullptr;
-  hipStream_t st = nullptr;
-  hipEvent_t up_done[2] = {nullptr, nullptr};
-  const size_t chunk_bytes = chunk_frames * hop * esz;
-  hipError_t e = hipStreamCreate(&st);
-  for (int b = 0; b < 2 && e == hipSuccess; b++) {
-    e = hipHostMalloc((void **)&h_in[b], chunk_bytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipEventCreate(&up_done[b]);
-  }
-  if (e == hipSuccess) e = hipHostMalloc((void **)&h_out, chunk_frames * bins * sizeof(float), hipHostMallocDefault);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_in, (halo + chunk_frames * hop) * esz);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_out, chunk_frames * bins * sizeof(float));
-  rc = (e == hipSuccess) ? GLFER_OK : hip_fail(e, "spectrogram_wav: allocate");
-  size_t done = 0, nread = 0;
-  int cur = 0;
-  if (rc == GLFER_OK) nread = fread(h_in[0], 1, std::min(chunk_frames, frames) * hop * esz, f) / (hop * esz);
-  while (rc == GLFER_OK && done < frames && nread > 0) {
-    const size_t nf = nread;
-    // chunk samples land behind the halo; sample 0 of the file sits at d_in + halo - done*hop
-    e = hipMemcpyAsync(d_in + halo * esz, h_in[cur], nf * hop * esz, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipEventRecord(up_done[cur], st);
-    if (e != hipSuccess) { rc = hip_fail(e, "spectrogram_wav: upload"); break; }
-    const unsigned char *vbase = d_in + halo * esz - done * hop * esz;   // virtual address of file sample 0
-    rc = run_device(p, vbase, (done + nf) * hop, done, nf, d_out, nullptr, st);
-    if (rc) break;
-    e = hipMemcpyAsync(h_out, d_out, nf * bins * sizeof(float), hipMemcpyDeviceToHost, st);
-    // keep the last `halo` samples of this chunk in front of the next one (only a full chunk is
-    // ever followed by another, and a full chunk is at least one halo long)
-    if (e == hipSuccess && halo && done + nf < frames)
-      e = hipMemcpyAsync(d_in, d_in + nf * hop * esz, halo * esz, hipMemcpyDeviceToDevice, st);
-    // read the next block from the file while the GPU works
-    const size_t want = std::min(chunk_frames, frames - done - nf);
-    nread = want ? fread(h_in[cur ^ 1], 1, want * hop * esz, f) / (hop * esz) : 0;
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { rc = hip_fail(e, "spectrogram_wav: chunk"); break; }
-    memcpy(h_psd + done * bins, h_out, nf * bins * sizeof(float));
-    done += nf;
-    cur ^= 1;
-  }
-  *nframes_out = done;
+  auto reader = [&](unsigned char *dst, size_t want) { return fread(dst, 1, want * hop * esz, f) / (hop * esz); };
+  rc = ingest_chunks(p, frames, chunk_frames, reader, h_psd, nframes_out);
   fclose(f);
-  for (int b = 0; b < 2; b++) {
-    if (h_in[b]) (void)hipHostFree(h_in[b]);
-    if (up_done[b]) (void)hipEventDestroy(up_done[b]);
-  }
-  if (h_out) (void)hipHostFree(h_out);
-  if (d_in) (void)hipFree(d_in);
-  if (d_out) (void)hipFree(d_out);
-  if (st) (void)hipStreamDestroy(st);
   return rc;
 }
 
