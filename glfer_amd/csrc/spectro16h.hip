@@ -39,6 +39,9 @@
 #ifndef GLFER_H_ABL
 #define GLFER_H_ABL 0
 #endif
+#ifndef GLFER16H_PREFETCH_TOP
+#define GLFER16H_PREFETCH_TOP 0    /* 1: next frame's samples requested at the top of the iteration, not after exchange 0's writes */
+#endif
 #ifndef GLFER16H_STORE_AUX
 #define GLFER16H_STORE_AUX 2       /* non-temporal: rows are written once (tools/hbench: +3 % over aux 0) */
 #endif
@@ -193,12 +196,15 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     }
     const long long nfblk = fblk + FPB;
     const bool has_next = nfblk < fend;
+    if constexpr (GLFER16H_PREFETCH_TOP != 0 && !(GLFER_H_ABL & 2)) {
+      if (has_next) prefetch_x(nfblk);                 // px is free as soon as xs is formed
+    }
 
     stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
       if constexpr (GLFER_H_ABL & 2) {                 // timing ablation: no sample loads after the first frame
 #pragma unroll
         for (int m = 0; m < 16; m++) px[m] = px[m] * 0.999f;
-      } else {
+      } else if constexpr (GLFER16H_PREFETCH_TOP == 0) {
         if (has_next) prefetch_x(nfblk);
       }
     });
