@@ -55,7 +55,8 @@ struct glfer_hip_plan {
   std::vector<double> sig;          // [ntapers]
   float *d_taps = nullptr;          // [npairs][8][n/16][4] scaled tables (tap_slot)
   float2 *d_tw = nullptr;           // [64][lanes]
-  float *d_htaps = nullptr;         // real-input form (spectro16h.hip): window pairs, [8][n/32][4]
+  float *d_htaps = nullptr;         // real-input form (spectro16h.hip): window pairs, [htapers][8][n/32][4]
+  int htapers = 0;                  // 1: periodogram window; > 1: the tapers of the multitaper form (n >= 8192)
   float2 *d_htw = nullptr;          //   twiddles of the n/2-point transform
   float2 *d_hrot = nullptr;         //   (cos,sin)(2 pi t/n), t < n/32
   float *d_xtaps = nullptr;         // odd taper counts (spectro16x.hip): the last taper alone, [4][n/16][4]
@@ -246,18 +247,28 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   // --- real-input form of the linear periodogram (spectro16h.hip): z[i] = y[2i] + i*y[2i+1],
   // lane t of n/32 holds points i = t + (n/32)*m; |X|^2/N needs the inputs scaled by sqrt(1/(4N))
   std::vector<float> htaps, htw, hrot;
-  if (cfg->mode == GLFER_MODE_FFT && !p->nonlin && n >= 512) {
+  // Multitaper at N >= 8192 takes the same form, one taper after the other on the frame held in
+  // registers: the packed N-point form would need the whole N-point exchange buffer (139 KB at
+  // N = 16384: one workgroup per CU), the real-input form half of it.  Each taper carries its weight:
+  // sqrt(1 / (4N (1 + sig_j))).
+  const bool h_periodogram = cfg->mode == GLFER_MODE_FFT && !p->nonlin && n >= 512;
+  const bool h_multitaper = cfg->mode == GLFER_MODE_MTM && n >= 8192;
+  if (h_periodogram || h_multitaper) {
     const int th = n / 32;
-    const double scale = std::sqrt(1.0 / (4.0 * n));
-    const bool rect = (cfg->window_type == GLFER_WIN_RECTANGULAR);
-    htaps.resize((size_t)n);
-    for (int m = 0; m < 16; m++)
-      for (int t = 0; t < th; t++)
-        for (int e = 0; e < 2; e++) {
-          const int i = 2 * (t + th * m) + e;
-          const double w = rect ? 1.0 : (double)p->window[i];
-          htaps[((size_t)(m / 2) * th + t) * 4 + (size_t)(m & 1) * 2 + e] = (float)(w * scale);
-        }
+    const int nwin = h_multitaper ? p->ntapers : 1;
+    const bool rect = h_periodogram && (cfg->window_type == GLFER_WIN_RECTANGULAR);
+    htaps.resize((size_t)nwin * n);
+    for (int j = 0; j < nwin; j++) {
+      const double scale = std::sqrt(1.0 / (4.0 * n * (h_multitaper ? 1.0 + p->sig[j] : 1.0)));
+      for (int m = 0; m < 16; m++)
+        for (int t = 0; t < th; t++)
+          for (int e = 0; e < 2; e++) {
+            const int i = 2 * (t + th * m) + e;
+            const double w = h_multitaper ? p->tapers[(size_t)j * n + i] : (rect ? 1.0 : (double)p->window[i]);
+            htaps[(size_t)j * n + ((size_t)(m / 2) * th + t) * 4 + (size_t)(m & 1) * 2 + e] = (float)(w * scale);
+          }
+    }
+    p->htapers = nwin;
     htw.resize((size_t)2 * glfer::make_twiddles16(logn - 1, nullptr) * th);
     glfer::make_twiddles16(logn - 1, htw.data());
     hrot.resize((size_t)2 * th);
@@ -479,7 +490,7 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   const unsigned esz = sp.fmt == GLFER_FMT_F32 ? 4u : (sp.fmt == GLFER_FMT_S16 ? 2u : 1u);
   const bool pairs_aligned = sp.fmt == GLFER_FMT_F32 ||
                              ((sp.H & 1) == 0 && (reinterpret_cast<uintptr_t>(sp.stream) & (2u * esz - 1u)) == 0);
-  const bool real_input = sp.htaps && sp.npairs == 1 && n >= 512 && pairs_aligned;
+  const bool real_input = sp.htaps && (sp.npairs == 1 || sp.htapers > 1) && n >= 512 && pairs_aligned;
   // built where it fits 3 waves/SIMD without spilling (N = 2048 and N >= 8192 do not: they stay packed)
   const bool shared_odd = sp.xtaps && sp.npairs >= 2 && (sp.ltaps || n <= 1024 || n == 4096);
   if (sp.spec || sp.nonlin || !(real_input || shared_odd)) return launch_packed(sp, n, st);
@@ -544,6 +555,7 @@ static int run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, 
   sp.taps = p->d_taps;
   sp.tw = p->d_tw;
   sp.htaps = p->d_htaps;
+  sp.htapers = p->htapers;
   sp.htw = p->d_htw;
   sp.hrot = p->d_hrot;
   sp.xtaps = p->d_xtaps;

@@ -43,7 +43,7 @@
 #define GLFER16H_PREFETCH_TOP 0    /* 1: next frame's samples requested at the top of the iteration, not after exchange 0's writes */
 #endif
 #ifndef GLFER16H_STORE_AUX
-#define GLFER16H_STORE_AUX 2       /* non-temporal: rows are written once (tools/hbench: +3 % over aux 0) */
+#define GLFER16H_STORE_AUX (GLFER_LOGN_OR(12) >= 12 ? 2 : 0)   /* non-temporal from N = 4096 up (rows written once; +3 %, N = 8192 +25 %); below that a store covers only part of a line per frame and must merge in L2 (nt: -17 % at N = 1024, -40 % at N = 512) */
 #endif
 
 namespace glfer {
@@ -60,8 +60,13 @@ struct LaunchH {
 
 // VAR (where the window lives): 0 = 32 VGPRs for the whole launch, 1 = re-read from the table
 // at the top of every frame, 2 = in LDS ([16][T] pairs, shared by the block's frames)
-template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR>
+// MT = 1: multitaper through the same transform -- p.htapers windows (each taper with its weight
+// folded in) applied in turn to the frame held in registers, |X|^2 summed per bin in 17 more
+// registers and stored after the last one.  Used where a frame's N-point exchange buffer would leave
+// one workgroup per CU (N >= 8192): the real-input form needs half of it.  VAR must be 1.
+template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0>
 __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(SpectroParams p) {
+  static_assert(MT == 0 || VAR == 1, "the multitaper form re-reads its window per taper");
   using L = LaunchH<LOGN>;
   using C = typename L::C;
   constexpr int N = 1 << LOGN, M = L::M, T = L::TH, FPB = L::FPB, PADM = L::PADM, NPASS = C::NPASS;
@@ -103,8 +108,8 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   // the window, in the lane's point order: wn[m] = (w[2n], w[2n+1]), n = t + T*m
   v2f32 wn[16];
   typedef float v4f32 __attribute__((ext_vector_type(4)));
-  auto load_window = [&] {
-    const v4f32 *ht = reinterpret_cast<const v4f32 *>(p.htaps) + t;
+  auto load_window = [&](int j = 0) {
+    const v4f32 *ht = reinterpret_cast<const v4f32 *>(p.htaps) + (size_t)j * (N / 4) + t;
 #pragma unroll
     for (int mh = 0; mh < 8; mh++) {
       const v4f32 q = ht[T * mh];
@@ -148,8 +153,25 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
         px[m].x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, lrel, (unsigned)(2 * T * m), 0));
       }
     });
+    if (p.history_mode) {        // history_mode 1: sample j = 2*(t + T*m) + e is kept iff j >= R.  Zeroed in
+      const int d = 2 * (int)t - p.R;                  // place (this waits for the loads; a rare mode)
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const bool k0 = d >= -2 * T * m, k1 = d + 1 >= -2 * T * m;
+        if constexpr (FMT == GLFER_FMT_F32) {
+          px[m].x = k0 ? px[m].x : 0.0f;
+          px[m].y = k1 ? px[m].y : 0.0f;
+        } else if constexpr (FMT == GLFER_FMT_S16) {   // raw 0 is sample 0.0
+          const unsigned raw = __float_as_uint(px[m].x);
+          px[m].x = __uint_as_float((k0 ? raw & 0xffffu : 0u) | (k1 ? raw & 0xffff0000u : 0u));
+        } else {                                       // raw 128 is sample 0.0
+          const unsigned raw = __float_as_uint(px[m].x);
+          px[m].x = __uint_as_float((k0 ? raw & 0xffu : 0x80u) | (k1 ? raw & 0xff00u : 0x8000u));
+        }
+      });
+    }
   };
-  // the pair as floats (integer formats: unscaled, see kSampleScale), with history_mode 1's zeroing
+  // the pair as floats (integer formats: unscaled, see kSampleScale)
   auto sample_pair = [&](auto mc) -> v2f32 {
     constexpr int m = decltype(mc)::value;
     v2f32 x;
@@ -161,11 +183,6 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     } else {
       const unsigned raw = __float_as_uint(px[m].x);
       x = v2f32{(float)(raw & 0xffu) - 128.0f, (float)((raw >> 8) & 0xffu) - 128.0f};
-    }
-    if (p.history_mode) {                              // sample j = 2*(t + T*m) + e is kept iff j >= R
-      const int d = 2 * (int)t - p.R;
-      x.x = (d >= -2 * T * m) ? x.x : 0.0f;
-      x.y = (d + 1 >= -2 * T * m) ? x.y : 0.0f;
     }
     return x;
   };
@@ -183,9 +200,19 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   // register holding bin t + T*m after the last pass
   auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };
 
+  const int ntap = MT ? p.htapers : 1;
   while (true) {
+    const long long nfblk = fblk + FPB;
+    const bool has_next = nfblk < fend;
+    float acc[MT ? 17 : 1];                            // MT: bins k = t + T*m (m < 8), M - k (8 + m), M/2 (16)
+    if constexpr (MT != 0) {
+#pragma unroll
+      for (int i = 0; i < 17; i++) acc[i] = 0.0f;
+    }
+   for (int j = 0; j < ntap; j++) {
+    const bool last = j == ntap - 1;
     float zr[16], zi[16];
-    if constexpr (VAR == 1) load_window();
+    if constexpr (VAR == 1) load_window(j);
     v2f32 xs[16];
     static_for<0, 16>([&](auto mc) { xs[decltype(mc)::value] = sample_pair(mc); });
 #pragma unroll
@@ -194,10 +221,8 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       zr[m] = xs[m].x * w.x;
       zi[m] = xs[m].y * w.y;
     }
-    const long long nfblk = fblk + FPB;
-    const bool has_next = nfblk < fend;
     if constexpr (GLFER16H_PREFETCH_TOP != 0 && !(GLFER_H_ABL & 2)) {
-      if (has_next) prefetch_x(nfblk);                 // px is free as soon as xs is formed
+      if (has_next && last) prefetch_x(nfblk);         // px is free as soon as xs is formed
     }
 
     stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
 #pragma unroll
         for (int m = 0; m < 16; m++) px[m] = px[m] * 0.999f;
       } else if constexpr (GLFER16H_PREFETCH_TOP == 0) {
-        if (has_next) prefetch_x(nfblk);
+        if (has_next && last) prefetch_x(nfblk);       // the frame's last use of px is behind us
       }
     });
 
@@ -251,15 +276,31 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
         const float pr = __builtin_fmaf(c, oi, -s * orr);
         const float pi = -__builtin_fmaf(c, orr, s * oi);
         const float x1r = er + pr, x1i = ei + pi, x2r = er - pr, x2i = ei - pi;
-        put(__builtin_fmaf(x1r, x1r, x1i * x1i), vup, (unsigned)(T * m) * 4u);              // bin k
-        put(__builtin_fmaf(x2r, x2r, x2i * x2i), vdown, (unsigned)(T * (7 - m)) * 4u);     // bin M - k
+        if constexpr (MT != 0) {
+          acc[m] = __builtin_fmaf(x1r, x1r, __builtin_fmaf(x1i, x1i, acc[m]));
+          acc[8 + m] = __builtin_fmaf(x2r, x2r, __builtin_fmaf(x2i, x2i, acc[8 + m]));
+          if (last) {
+            put(acc[m], vup, (unsigned)(T * m) * 4u);
+            put(acc[8 + m], vdown, (unsigned)(T * (7 - m)) * 4u);
+          }
+        } else {
+          put(__builtin_fmaf(x1r, x1r, x1i * x1i), vup, (unsigned)(T * m) * 4u);              // bin k
+          put(__builtin_fmaf(x2r, x2r, x2i * x2i), vdown, (unsigned)(T * (7 - m)) * 4u);     // bin M - k
+        }
       });
-      if (t == 0) {                                    // k = M/2 pairs with itself: X = conj(Z)
+      {                                                // k = M/2 pairs with itself: X = conj(Z) (lane 0's value is the bin)
         constexpr int r = rho_of(8);
-        put(4.0f * __builtin_fmaf(zr[r], zr[r], zi[r] * zi[r]), vup, (unsigned)(M / 2) * 4u);
+        const float nyq = 4.0f * __builtin_fmaf(zr[r], zr[r], zi[r] * zi[r]);
+        if constexpr (MT != 0) {
+          acc[16] += nyq;
+          if (t == 0 && last) put(acc[16], vup, (unsigned)(M / 2) * 4u);
+        } else {
+          if (t == 0) put(nyq, vup, (unsigned)(M / 2) * 4u);
+        }
       }
     }
     if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();     // mirror entries read: buffer free
+   }
     if (!has_next) break;
     fblk = nfblk;
   }
@@ -286,6 +327,13 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
   const long long resident = 256LL * per_cu;
   unsigned grid = (unsigned)(work < 8 * resident ? work : 8 * resident);   // tools/hbench: 8x beats 4x by ~2 % with contiguous ranges
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
+#if GLFER_LOGN >= 13
+  if (p.htapers > 1) {
+    hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, 1, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    return hipGetLastError();
+  }
+#endif
+  if (p.htapers > 1) return hipErrorInvalidValue;      // the multitaper form is built for N >= 8192 only
   hipLaunchKernelGGL((spectro16h_kernel<L, FMT>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   return hipGetLastError();
 }

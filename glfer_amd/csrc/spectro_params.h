@@ -25,6 +25,7 @@ struct SpectroParams {
   /* real-input (N/2-point) form of a single taper, spectro16h.hip; NULL when not built for this plan */
   const float *htaps;      /* device: [8][N/32][4] window as (w[2n],w[2n+1]) pairs, sqrt(1/(4N)) folded */
   const float2 *htw;       /* device: [slots][N/32] inter-pass twiddles of the N/2-point transform      */
+  int htapers;             /* windows in htaps: 0/1 = periodogram; > 1 = multitaper via the real-input form, [htapers] tables */
   const float2 *hrot;      /* device: [N/32] (cos,sin)(2 pi t/N), the lane part of the post twiddle     */
   /* odd taper counts, spectro16x.hip: the last taper alone; NULL when not built for this plan */
   const float *xtaps;      /* device: [4][N/16][4] last taper, sqrt(1/(4N(1+sig))) folded               */
