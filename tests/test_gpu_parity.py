@@ -94,7 +94,11 @@ def test_baseline_configs_vs_oracle(lib, oracle, torch_cuda, cfg, seed):
     (512, 0.33, 6, 4.0, 0, 0, "s16", 150),      # 7 tapers, odd hop
     (256, 0.0, 2, 1.5, 0, 0, "f32", 97),        # smallest block: 16 frames per block
     (2048, 0.25, 4, 2.5, 0, 0, "f32", 40),      # N = 2048: xl only (x spills there)
-    (8192, 0.5, 4, 2.5, 1, 0, "f32", 9),        # N >= 8192: packed kernel
+    (8192, 0.5, 4, 2.5, 1, 0, "f32", 21),       # N >= 8192: the real-input kernel, taper by taper
+    (8192, 0.75, 7, 4.0, 0, 1, "s16", 23),      # ... 16-bit pairs, history zeroed in every frame
+    (8192, 0.33, 3, 2.5, 0, 0, "u8", 17),       # ... odd hop: integer pairs unaligned -> packed kernel
+    (16384, 0.5, 8, 4.5, 0, 0, "f32", 13),      # N = 16384, 9 tapers
+    (16384, 0.25, 1, 1.5, 1, 1, "u8", 12),      # two tapers, 8-bit pairs
     (4096, 0.75, 3, 2.5, 0, 0, "f32", 50),      # even taper count: packed kernel
 ])
 def test_multitaper_kernel_forms_vs_oracle(lib, oracle, torch_cuda, n, overlap, kmax, nw, sub_mean, history_mode, fmt, frames):
