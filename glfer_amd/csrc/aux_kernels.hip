@@ -114,6 +114,135 @@ __global__ __launch_bounds__(256) void floor_kernel(const float *__restrict__ ps
 }
 
 // ---------------------------------------------------------------------------
+// K6, rows of up to 64*EPL bins: ONE WAVEFRONT per row, the row in registers (lane l holds bins
+// l + 64 j), no LDS and no barriers.  The m-th smallest key is found bit by bit: with the prefix P
+// decided so far, T = P | bit; if fewer than m keys are below T the answer has that bit set.  A
+// step is EPL compare+add pairs per lane and one DPP sum over the wavefront; bits above the first
+// one in which the row's smallest and largest key differ are skipped.  (The histogram form above
+// serialises on LDS atomics -- a PSD row's keys share their leading digits, so a whole wavefront
+// adds to one bucket -- and needs ~34 workgroup barriers per row.)
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+// sum over the wavefront, returned in an SGPR: row_shr 1,2,4,8 leave each row's total in its lane 15,
+// row_bcast 15 / 31 carry the totals up to lane 63
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // same walk; lanes shifted in from outside read 0
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
+
+// c += (k0 < T) + (k1 < T) + (k2 < T) + (k3 < T): four compares into four SGPR pairs, then four
+// add-with-carry-in -- 2 VALU per key, and no wait states between a compare and its use (the compiler's
+// own form goes through VCC: v_cmp, s_nop 1, v_cndmask, v_add)
+__device__ __forceinline__ void count_below4(uint32_t &c, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t T) {
+  asm("v_cmp_gt_u32_e64 s[20:21], %5, %1\n\t"
+      "v_cmp_gt_u32_e64 s[22:23], %5, %2\n\t"
+      "v_cmp_gt_u32_e64 s[24:25], %5, %3\n\t"
+      "v_cmp_gt_u32_e64 s[26:27], %5, %4\n\t"
+      "v_addc_co_u32_e64 %0, s[28:29], 0, %0, s[20:21]\n\t"
+      "v_addc_co_u32_e64 %0, s[28:29], 0, %0, s[22:23]\n\t"
+      "v_addc_co_u32_e64 %0, s[28:29], 0, %0, s[24:25]\n\t"
+      "v_addc_co_u32_e64 %0, s[28:29], 0, %0, s[26:27]"
+      : "+v"(c)
+      : "v"(k0), "v"(k1), "v"(k2), "v"(k3), "v"(T)
+      : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29");
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict__ psd, long long nframes, int bins, int m,
+                                                         float *__restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nframes) return;                      // wavefront-uniform
+  const float *src = psd + (size_t)r * bins;
+  float v[EPL];
+  uint32_t key[EPL];
+  float best = 0.0f;
+  int besti = 0;
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+  for (int j = 0; j < EPL; j++) {
+    const int i = lane + 64 * j;
+    const bool in = i < bins;
+    v[j] = in ? src[i] : 0.0f;
+    key[j] = in ? fkey(v[j]) : 0xFFFFFFFFu;      // padding sorts last: never among the m <= bins smallest
+    if (in && v[j] > best) { best = v[j]; besti = i; }   // ascending i: the lane's lowest index of its maximum
+    if (in) {
+      kmin = key[j] < kmin ? key[j] : kmin;
+      kmax = key[j] > kmax ? key[j] : kmax;
+    }
+  }
+  // largest bin and its first index (strict > scan from 0.0, fft.c:284-291): bins are >= 0, so the
+  // float order is the order of the bit patterns
+  const uint32_t peak_bits = wave_max_u32(__float_as_uint(best > 0.0f ? best : 0.0f));
+  const float peak = __uint_as_float(peak_bits);
+  const uint32_t first = wave_min_u32((best == peak && peak > 0.0f) ? (uint32_t)besti : 0xFFFFFFFFu);
+  const int peak_i = peak > 0.0f ? (int)first : 0;
+
+  // key of the m-th smallest bin
+  kmin = wave_min_u32(kmin);
+  kmax = wave_max_u32(kmax);
+  const uint32_t diff = kmin ^ kmax;
+  uint32_t P = kmin, below = 0;                  // below = number of keys < P
+  if (diff) {
+    const int hb = 31 - __builtin_clz(diff);     // first bit in which the row's keys differ
+    P = (hb == 31) ? 0u : (kmin >> (hb + 1)) << (hb + 1);
+    uint32_t upper = (uint32_t)bins;             // number of keys below the end of the bucket [P, P + 2^(b+1)) under search
+    for (int b = hb; b >= 0; b--) {
+      const uint32_t T = P | (1u << b);
+      uint32_t c = 0, Tv;
+      asm("v_mov_b32 %0, %1" : "=v"(Tv) : "s"(T));          // compares against a VGPR: an SGPR operand halves the VALU rate (tools/pkbench3)
+      constexpr int G = EPL >= 5 ? (EPL / 4) * 4 : 0;
+#pragma unroll
+      for (int j = 0; j < G; j += 4) count_below4(c, key[j], key[j + 1], key[j + 2], key[j + 3], Tv);
+#pragma unroll
+      for (int j = G; j < EPL; j++) c += key[j] < Tv ? 1u : 0u;
+      c = wave_sum_u32(c);
+      if (c < (uint32_t)m) { P = T; below = c; } else upper = c;
+      if (upper - below == 1) {                  // one key left in the bucket: it is the smallest key >= P
+        uint32_t cand = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) cand = (key[j] >= P && key[j] < cand) ? key[j] : cand;
+        P = wave_min_u32(cand);
+        break;
+      }
+    }
+  }
+  const uint32_t ties = (uint32_t)m - below;     // copies of the m-th smallest that belong to the m smallest
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < EPL; j++) s += (double)(key[j] < P ? v[j] : 0.0f);
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    float fl = (float)(s + (double)ties * (double)fkey_inv(P));
+    fl = (float)(fl / 0.05);                     // fft.c:274 (float / double)
+    fl = fl / (float)bins;                       // fft.c:276
+    float *o = stats + (size_t)r * 4;
+    o[0] = peak;
+    o[1] = fl;
+    o[2] = (peak > 0.0f) ? peak : 0.0f;
+    o[3] = (float)peak_i;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K5a.  The sliding sum of avg.c:116-127 per bin, as the same double recurrence
 //   f <  depth : cum += psd[f]                      (shift register still filling)
 //   f >= depth : cum += psd[f] - psd[f-depth]       (avgarray[index][0] is the row f-depth)
@@ -251,8 +380,18 @@ using namespace glfer;
 extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int bins, int m, float *stats,
                                          hipStream_t st) {
   if (nframes == 0) return hipSuccess;
-  const size_t shmem = (size_t)bins * sizeof(float) + 256 * sizeof(uint32_t);
-  hipLaunchKernelGGL(floor_kernel, dim3((unsigned)nframes), dim3(256), shmem, st, psd, bins, m, stats);
+  if (m < 1 || m > bins) return hipErrorInvalidValue;
+  const unsigned wgrid = (unsigned)((nframes + 3) / 4);          // one wavefront per row, four rows per block
+  const long long nf = (long long)nframes;
+  if (bins <= 64 * 3) hipLaunchKernelGGL(floor_wave_kernel<3>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
+  else if (bins <= 64 * 5) hipLaunchKernelGGL(floor_wave_kernel<5>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
+  else if (bins <= 64 * 9) hipLaunchKernelGGL(floor_wave_kernel<9>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
+  else if (bins <= 64 * 17) hipLaunchKernelGGL(floor_wave_kernel<17>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
+  else if (bins <= 64 * 33) hipLaunchKernelGGL(floor_wave_kernel<33>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
+  else {                                         // longer rows: one workgroup per row, the row in LDS
+    const size_t shmem = (size_t)bins * sizeof(float) + 256 * sizeof(uint32_t);
+    hipLaunchKernelGGL(floor_kernel, dim3((unsigned)nframes), dim3(256), shmem, st, psd, bins, m, stats);
+  }
   return hipGetLastError();
 }
 

@@ -355,6 +355,41 @@ def test_floor_statistics(lib, oracle, torch_cuda):
     assert np.allclose(got[:, 1], want[:, 1], rtol=2e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("bins", [129, 257, 513, 1025, 2049, 4097, 8193, 100, 2048, 3000])
+def test_floor_statistics_row_shapes(lib, oracle, torch_cuda, bins):
+    # every row length the estimator produces (one wavefront per row up to 2049 bins, one workgroup
+    # per row above), lengths that do not fill the last lane group, and rows built to stress the
+    # selection: heavy ties around the 5 % quantile, few distinct values, one tiny outlier, a constant
+    # row, all zeros, sorted both ways, the maximum repeated (first index wins), denormals
+    rng = np.random.default_rng(bins)
+    rows = [(rng.random(bins) ** 5).astype(np.float32) for _ in range(6)]
+    q = np.round(rng.random(bins) * 7).astype(np.float32) / 8            # 8 distinct values
+    rows.append(q)
+    t = (rng.random(bins) ** 3).astype(np.float32)
+    t[rng.integers(0, bins, bins // 3)] = np.float32(0.001)              # a third of the row tied near the bottom
+    rows.append(t)
+    rows.append(np.full(bins, 0.3, np.float32))
+    rows.append(np.zeros(bins, np.float32))
+    rows.append(np.sort((rng.random(bins) ** 4).astype(np.float32)))
+    rows.append(np.sort((rng.random(bins) ** 4).astype(np.float32))[::-1].copy())
+    m = (rng.random(bins) * 0.5).astype(np.float32)
+    m[[bins // 3, bins // 2, bins - 1]] = 0.75                           # the largest bin three times
+    rows.append(m)
+    d = (rng.random(bins) * 1e-41).astype(np.float32)                    # denormals
+    d[bins // 2] = 1e-30
+    rows.append(d)
+    o = (rng.random(bins) + 1.0).astype(np.float32)                      # values in [1, 2): keys differ only in the mantissa
+    o[7 % bins] = 1e-20
+    rows.append(o)
+    psd = np.stack(rows).astype(np.float32)
+    got = lib.compute_floor(torch_cuda.from_numpy(psd).cuda()).cpu().numpy().astype(np.float64)
+    want = np.array([oracle.floor_stats(r) for r in psd], np.float64)
+    assert np.array_equal(got[:, [0, 2, 3]], want[:, [0, 2, 3]])
+    # the reference adds the m = 5 % smallest bins in float, in sorted order (fft.c:271-273); the kernels
+    # add them in double: up to m/2 ulp apart (m = 410 at 8193 bins), inside the 1e-5 of the PSD itself
+    assert np.allclose(got[:, 1], want[:, 1], rtol=TOL, atol=1e-44)
+
+
 @pytest.mark.parametrize("mode_name,mode_id", [("plain", 2), ("sumextreme", 3), ("sumavg", 1)])
 @pytest.mark.parametrize("max0", [0, 1])
 def test_moving_average(lib, torch_cuda, mode_name, mode_id, max0):
