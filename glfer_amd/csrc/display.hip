@@ -141,44 +141,84 @@ __global__ __launch_bounds__(256) void levels_fixed_kernel(long long nframes, fl
   }
 }
 
+// One bin of one column: the dB short and the 0..255 colour index (g_main.c:1186-1226).
+//   levbuf = (short)(10 log10 x)  [double log10, truncated]       colour = (uchar)((f - thr255) / one_m_thr)
+// Both truncate a double: the value only matters next to an integer.  So the logarithm is taken in
+// float (v_log_f32) and the quotient as a product with the reciprocal, and only a result within a
+// guard band of an integer -- 2e-3 for the float logarithm (its error is < 1e-4 over |y| <= 400),
+// 1e-9 for the product (a few double ulp of at most 255) -- is recomputed the reference's way:
+// the same integers as the all-double form, at a fraction of the instructions.
+template <typename SRC>
+__device__ __forceinline__ void map_bin(SRC s, int scale_log, float display_min, float span, double thr255,
+                                        double one_m_thr, double inv_one_m_thr, short &l, unsigned &v) {
+  const float sf = (float)s;                               // the linear scale maps (float)s, and logs that
+  const double sd = scale_log ? (double)s : (double)sf;
+  const float y = __builtin_amdgcn_logf(sf) * 3.010299956639812f;         // 10 log10 = log2 * 10 log10(2)
+  int li;
+  if (sf > 1e-30f && sf < 1e30f && __builtin_fabsf(y - __builtin_rintf(y)) > 2e-3f) li = (int)y;   // (a double source rounded to float moves y by 3e-7)
+  else li = x86_d2i(10.0 * log10(sd));
+  l = (short)li;
+  const float sig_level = scale_log ? (float)l : sf;
+  const float f = 255.0f * ((sig_level - display_min) / span);
+  if ((double)f < thr255) {
+    v = 0;
+  } else if (f > 255.0f) {
+    v = 255;
+  } else {
+    const double num = (double)f - thr255, q = num * inv_one_m_thr;
+    const int qi = (__builtin_fabs(q - __builtin_rint(q)) > 1e-9) ? (int)q : x86_d2i(num / one_m_thr);
+    v = (unsigned)qi & 0xffu;                              // (unsigned char) of the conversion
+  }
+}
+
+// One block per column.  A thread maps FOUR consecutive pixels: the 12 RGB bytes and the 4 shorts go
+// out as one 12-byte and one 8-byte store (byte-aligned: rows of 3n bytes start anywhere; gfx950 runs
+// with unaligned global access enabled and the compiler emits dwordx3/dwordx2 for it), instead of
+// twelve byte stores and four short stores; the palette sits in LDS as one dword per colour.
 template <typename SRC>
 __global__ __launch_bounds__(256) void map_kernel(const SRC *__restrict__ src, int n, int scale_log,
                                                   double thr255, double one_m_thr,
                                                   const float *__restrict__ levels,
                                                   const unsigned char *__restrict__ colortab,
                                                   unsigned char *__restrict__ rgb, short *__restrict__ lev) {
-  __shared__ unsigned char tab[768];
-  for (int i = threadIdx.x; i < 768; i += 256) tab[i] = colortab[i];
+  __shared__ unsigned tab[256];
+  {
+    const int c = threadIdx.x;
+    tab[c] = (unsigned)colortab[3 * c] | ((unsigned)colortab[3 * c + 1] << 8) | ((unsigned)colortab[3 * c + 2] << 16);
+  }
   __syncthreads();
   const size_t fr = blockIdx.x;
   const SRC *row = src + fr * (size_t)n;
   const float display_max = levels[fr * 4 + 0];
   const float display_min = levels[fr * 4 + 1];
   const float span = display_max - display_min;
+  const double inv = 1.0 / one_m_thr;
   unsigned char *orow = rgb + fr * (size_t)n * 3;
   short *lrow = lev ? lev + fr * (size_t)n : nullptr;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const SRC s = row[n - i - 1];
-    float sig_level;
-    short l;
-    if (scale_log) {
-      l = (short)x86_d2i(10.0 * log10((double)s));         // levbuf[..] = 10.0*log10(x)
-      sig_level = (float)l;                                // sig_level = (that short)
-    } else {
-      sig_level = (float)s;
-      l = (short)x86_d2i(10.0 * log10((double)sig_level));
+  const int n4 = n & ~3;
+  for (int i = 4 * (int)threadIdx.x; i < n4; i += 4 * 256) {         // pixels i..i+3 <- bins n-1-i .. n-4-i
+    SRC q[4];
+    __builtin_memcpy(q, row + (n - 4 - i), sizeof q);
+    short l[4];
+    unsigned c[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      unsigned v;
+      map_bin<SRC>(q[3 - u], scale_log, display_min, span, thr255, one_m_thr, inv, l[u], v);
+      c[u] = tab[v];
     }
-    const float f = 255.0f * ((sig_level - display_min) / span);
-    unsigned char v;
-    if ((double)f < thr255)
-      v = 0;
-    else if (f > 255.0f)
-      v = 255;
-    else
-      v = (unsigned char)x86_d2i(((double)f - thr255) / one_m_thr);
-    orow[3 * i] = tab[3 * v];
-    orow[3 * i + 1] = tab[3 * v + 1];
-    orow[3 * i + 2] = tab[3 * v + 2];
+    const unsigned w[3] = {c[0] | (c[1] << 24), (c[1] >> 8) | (c[2] << 16), (c[2] >> 16) | (c[3] << 8)};
+    __builtin_memcpy(orow + 3 * (size_t)i, w, 12);
+    if (lrow) __builtin_memcpy(lrow + i, l, 8);
+  }
+  for (int i = n4 + (int)threadIdx.x; i < n; i += 256) {              // the last n mod 4 pixels
+    short l;
+    unsigned v;
+    map_bin<SRC>(row[n - i - 1], scale_log, display_min, span, thr255, one_m_thr, inv, l, v);
+    const unsigned c = tab[v];
+    orow[3 * i] = (unsigned char)c;
+    orow[3 * i + 1] = (unsigned char)(c >> 8);
+    orow[3 * i + 2] = (unsigned char)(c >> 16);
     if (lrow) lrow[i] = l;
   }
 }

@@ -127,6 +127,40 @@ def test_state_carries_across_calls(lib, oracle, torch_cuda):
            (two.first_buffer, two.display_max_lvl, two.display_min_lvl)
 
 
+def test_whole_db_boundaries(lib, oracle, torch_cuda):
+    # levbuf truncates 10*log10(x) to a whole dB: the kernel takes the logarithm in float and falls
+    # back to the double form inside a guard band around every integer.  Rows packed with values ON and
+    # next to the boundaries 10^(k/10) -- the exact float, its neighbours 1, 2, 3, 1000 and 20000 ulp
+    # away (inside and just outside the band) -- over the whole float range, plus a log-uniform fill;
+    # row lengths 4k, 4k+1, 4k+3 exercise the four-pixel groups and their tail.
+    rng = np.random.default_rng(5)
+    ks = np.arange(-370, 381)
+    base = (10.0 ** (ks / 10.0)).astype(np.float32)
+    vals = [base]
+    for ulps in (1, 2, 3, 1000, 20000):
+        for sign in (1, -1):
+            vals.append((base.view(np.int32) + sign * ulps).view(np.float32))
+    edge = np.concatenate(vals)
+    edge = edge[np.isfinite(edge) & (edge > 0)]
+    for n in (2048, 2049, 1027):
+        rows = 24
+        psd = (10.0 ** rng.uniform(-30, 5, (rows, n))).astype(np.float32)
+        flat = psd.reshape(-1)
+        idx = rng.permutation(flat.size)[: edge.size]
+        flat[idx] = edge
+        stats = np.array([oracle.floor_stats(r) for r in psd], np.float32)
+        for scale_type, autoscale in ((2, 0), (2, 1), (0, 0)):
+            d = lib.Display(palette=2, scale_type=scale_type, autoscale=autoscale, max_level_db=-5.0, min_level_db=-120.0,
+                            thr_level=3.0)
+            rgb, lev, _ = lib.display(d, torch_cuda.from_numpy(psd).cuda(), torch_cuda.from_numpy(stats).cuda())
+            w_rgb, w_lev, _, _ = oracle.display(psd, stats, palette_id=2, scale_log=scale_type >= 2, autoscale=bool(autoscale),
+                                                max_level_db=-5.0, min_level_db=-120.0, thr_level=3.0)
+            # glibc's and the device's double log10 may still differ in the last bit exactly at a boundary:
+            # the bound is the test-wide one, the expectation is zero or a handful
+            _same(lev.cpu().numpy(), w_lev, "levbuf n=%d" % n)
+            _same(rgb.cpu().numpy().reshape(-1, 3).view(np.dtype("V3")), w_rgb.reshape(-1, 3).view(np.dtype("V3")), "rgb n=%d" % n)
+
+
 def test_special_values(lib, oracle, torch_cuda):
     # zero, denormal, huge, inf and NaN bins; equal max/min levels (division by zero -> NaN/inf)
     psd = np.array([[0.0, 1e-45, 1e-20, 1.0, 3e38, np.inf, np.nan, 0.5]], np.float32)
