@@ -373,6 +373,140 @@ __global__ __launch_bounds__(256) void avg_norm_kernel(const float *__restrict__
   }
 }
 
+// K5, fused: the sliding sums AND the per-frame normalisation in one pass.  avg_cum_kernel writes
+// the sums (8 B per bin) for avg_norm_kernel to read back, reduce and overwrite: 28 B of HBM traffic
+// per bin where the output alone is 8.  Here a block owns a chunk of AVG_CHUNK frames and the WHOLE
+// band: thread t keeps the double sums of bins minbin + t + 256 j in registers (same recurrence,
+// same restart from a direct sum as avg_cum_kernel: bit-identical sums), walks the frames in
+// order, and for each frame reduces its sums over the block (wavefront shuffles + four partials,
+// one barrier; the partials alternate between two LDS slots, so no second barrier), normalises and
+// stores the row: 4 B read (+4 B of the row leaving the window, an L2 hit for small depths) and
+// 8 B written per bin.  The next frame's samples are requested before the current one is reduced.
+template <int BPT>
+__global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict__ psd, long long nframes, int bins,
+                                                        int n_out, int depth, int minbin, int maxbin, int mode, int max0,
+                                                        double *__restrict__ avg, double *__restrict__ ret) {
+  __shared__ double p_sum[2][4], p_max[2][4], p_min[2][4], p_var[2][4];
+  __shared__ int p_idx[2][4], p_cnt[2][4];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const long long f0 = (long long)blockIdx.x * AVG_CHUNK;
+  const long long f1 = f0 + AVG_CHUNK < nframes ? f0 + AVG_CHUNK : nframes;
+  const int b0 = minbin + tid;
+  double cum[BPT];
+#pragma unroll
+  for (int j = 0; j < BPT; j++) cum[j] = 0.0;
+  for (long long g = f0 > depth ? f0 - depth : 0; g < f0; g++) {
+    const float *r = psd + (size_t)g * bins;
+#pragma unroll
+    for (int j = 0; j < BPT; j++)
+      if (b0 + 256 * j < maxbin) cum[j] += (double)r[b0 + 256 * j];
+  }
+  float v[BPT], old[BPT];
+  auto fetch = [&](long long f) {
+    const float *r = psd + (size_t)f * bins;
+    const float *ro = psd + (size_t)(f >= depth ? f - depth : 0) * bins;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) {
+      const bool in = b0 + 256 * j < maxbin;
+      v[j] = in ? r[b0 + 256 * j] : 0.0f;
+      old[j] = (in && f >= depth) ? ro[b0 + 256 * j] : 0.0f;
+    }
+  };
+  fetch(f0);
+  const double span = (double)(maxbin - minbin - 1);
+  for (long long f = f0; f < f1; f++) {
+    const int par = (int)(f & 1);
+    const int eff = (f + 1 < depth) ? (int)(f + 1) : depth;   // effdepth after this frame
+    const double init = (double)psd[(size_t)f * bins + minbin];
+    double s = 0.0, mx = -1.0e300, mn = 1.0e300;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) {
+      if (b0 + 256 * j < maxbin) {
+        if (f < depth) cum[j] += (double)v[j];
+        else cum[j] += (double)v[j] - (double)old[j];
+        const double c = cum[j];
+        s += c;
+        if (c > mx) { mx = c; mi = b0 + 256 * j; }
+        if (c < mn) mn = c;
+      }
+    }
+    if (f + 1 < f1) fetch(f + 1);                              // in flight under the reduction
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      s += __shfl_xor(s, o);
+      const double om = __shfl_xor(mx, o);
+      const int oi = __shfl_xor(mi, o);
+      if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+      const double on = __shfl_xor(mn, o);
+      if (on < mn) mn = on;
+    }
+    if ((tid & 63) == 0) { p_sum[par][wave] = s; p_max[par][wave] = mx; p_min[par][wave] = mn; p_idx[par][wave] = mi; }
+    __syncthreads();
+    double r_sum = p_sum[par][0], r_max = p_max[par][0], r_min = p_min[par][0];
+    int r_idx = p_idx[par][0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+      r_sum += p_sum[par][w];
+      if (p_max[par][w] > r_max || (p_max[par][w] == r_max && p_idx[par][w] < r_idx)) { r_max = p_max[par][w]; r_idx = p_idx[par][w]; }
+      if (p_min[par][w] < r_min) r_min = p_min[par][w];
+    }
+    // running max starts at psd[minbin] (avg.c:111,163,224) and only a strictly larger sum moves it
+    double top = init;
+    int peak = -1;
+    if (r_max > init) { top = r_max; peak = r_idx; }
+    const double low = (r_min < 1.0) ? r_min : 1.0;            // avg.c:165,192-193
+    double spec;
+    if (mode == 2) spec = (r_sum - top) / (span * (double)(eff + 1));   // avg.c:147
+    else spec = (r_sum - top) / span;                                    // avg.c:199,260
+
+    double *row = avg + (size_t)f * n_out;
+    double var = 0.0;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) {
+      const int b = b0 + 256 * j;
+      if (b < maxbin) {
+        const double c = cum[j];
+        double out;
+        if (mode == 2) {
+          out = c / (double)(eff + 1);                                    // avg.c:155
+        } else if (mode == 3) {
+          out = max0 ? (c - low) / (top - low) : c / spec;                // avg.c:209-212
+        } else {
+          if (c - spec > 0) {                                             // avg.c:272-284
+            out = max0 ? (c - spec) / (top - spec) : c / spec;
+            if (b != peak) { var += (c / spec) * (c / spec); cnt++; }
+          } else {
+            out = 1e-15;
+          }
+        }
+        row[b] = out;
+      }
+    }
+    for (int b = tid; b < n_out; b += 256)
+      if (b < minbin || b >= maxbin) row[b] = 1e-15;
+    if (mode == 1) {
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        var += __shfl_xor(var, o);
+        cnt += __shfl_xor(cnt, o);
+      }
+      if ((tid & 63) == 0) { p_var[par][wave] = var; p_cnt[par][wave] = cnt; }
+      __syncthreads();
+      var = (p_var[par][0] + p_var[par][1]) + (p_var[par][2] + p_var[par][3]);
+      cnt = (p_cnt[par][0] + p_cnt[par][1]) + (p_cnt[par][2] + p_cnt[par][3]);
+    }
+    if (tid == 0) {
+      double *o = ret + (size_t)f * 4;
+      o[0] = (mode == 2) ? spec : top / spec;                             // avg.c:158,218,297
+      o[1] = (double)peak;
+      o[2] = (mode == 1) ? var / (double)cnt : 0.0;                       // avg.c:294
+      o[3] = (double)eff;
+    }
+  }
+}
+
 }  // namespace glfer
 
 using namespace glfer;
@@ -400,11 +534,28 @@ extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframe
                                        double *ret, hipStream_t st) {
   if (nframes == 0) return hipSuccess;
   const int band = maxbin - minbin;
-  hipLaunchKernelGGL(avg_cum_kernel, dim3((unsigned)((band + 255) / 256), (unsigned)((nframes + AVG_CHUNK - 1) / AVG_CHUNK)), dim3(256), 0, st, psd,
-                     (long long)nframes, bins, n_out, depth, minbin, maxbin, avg);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(avg_norm_kernel, dim3((unsigned)nframes), dim3(256), 0, st, psd, bins, n_out, depth,
-                     minbin, maxbin, mode, max0, avg, ret);
+  if (band < 1 || minbin < 0 || maxbin > bins || maxbin > n_out || depth < 1) return hipErrorInvalidValue;
+  const unsigned chunks = (unsigned)((nframes + AVG_CHUNK - 1) / AVG_CHUNK);
+  const long long nf = (long long)nframes;
+#define GLFER_AVG_FUSED(B)                                                                                          \
+  hipLaunchKernelGGL(avg_fused_kernel<B>, dim3(chunks), dim3(256), 0, st, psd, nf, bins, n_out, depth, minbin, maxbin, \
+                     mode, max0, avg, ret)
+  const int bpt = (band + 255) / 256;
+  if (bpt <= 1) GLFER_AVG_FUSED(1);
+  else if (bpt <= 2) GLFER_AVG_FUSED(2);
+  else if (bpt <= 3) GLFER_AVG_FUSED(3);
+  else if (bpt <= 5) GLFER_AVG_FUSED(5);
+  else if (bpt <= 9) GLFER_AVG_FUSED(9);
+  else if (bpt <= 17) GLFER_AVG_FUSED(17);
+  else if (bpt <= 33) GLFER_AVG_FUSED(33);
+  else {                                             // wider than any block size of the estimator: the two-pass form
+    hipLaunchKernelGGL(avg_cum_kernel, dim3((unsigned)((band + 255) / 256), chunks), dim3(256), 0, st, psd, nf, bins, n_out,
+                       depth, minbin, maxbin, avg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(avg_norm_kernel, dim3((unsigned)nframes), dim3(256), 0, st, psd, bins, n_out, depth, minbin, maxbin,
+                       mode, max0, avg, ret);
+  }
+#undef GLFER_AVG_FUSED
   return hipGetLastError();
 }

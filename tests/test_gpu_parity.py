@@ -437,6 +437,33 @@ def test_moving_average_long_run(lib, oracle, torch_cuda, depth):
                 assert np.all(np.abs(avg[f] - want) <= bound + 1e-300), (f, depth)
 
 
+@pytest.mark.parametrize("bins,minbin,maxbin", [(129, 2, 120), (257, 0, 257), (513, 10, 500), (1025, 25, 1000),
+                                                (2049, 25, 2000), (4097, 1, 4097), (8193, 100, 8100)])
+@pytest.mark.parametrize("mode", ["plain", "sumextreme", "sumavg"])
+def test_moving_average_row_shapes(lib, oracle, torch_cuda, bins, minbin, maxbin, mode):
+    """Every row length of the estimator (1..33 bins per thread of the fused kernel), bands that do and
+    do not start at bin 0 / end at the last bin, both normalisations, 300 rows (two restarts of the
+    chunked recurrence) with depth 1 and 6, against the oracle's row-by-row averager."""
+    rng = np.random.default_rng(bins + len(mode))
+    frames = 300
+    p = (rng.random((frames, bins)) ** 3 + 0.05).astype(np.float32)
+    p[40, minbin + (maxbin - minbin) // 3] = 50.0                       # a clear peak in one row
+    mode_id = {"plain": lib.AVG_PLAIN, "sumextreme": lib.AVG_SUMEXTREME, "sumavg": lib.AVG_SUMAVG}[mode]
+    for depth, max0 in ((1, 0), (6, 1), (6, 0)):
+        avg, ret = lib.update_avg(mode_id, torch_cuda.from_numpy(p).cuda(), depth, minbin, maxbin, max0=max0)
+        avg, ret = avg.cpu().numpy(), ret.cpu().numpy()
+        a = oracle.Averager(bins, depth)
+        for f in range(frames):
+            r, want, peak, var = a.update(mode, p[f], minbin, maxbin, max0=max0, n=bins)
+            if mode == "plain":
+                assert np.array_equal(avg[f], want), (f, depth)
+            else:
+                assert np.allclose(avg[f], want, rtol=1e-11, atol=1e-300), (f, depth, max0)
+            assert np.isclose(ret[f, 0], r, rtol=1e-11) and ret[f, 1] == peak, (f, depth, max0)
+            if mode == "sumavg":
+                assert np.isclose(ret[f, 2], var, rtol=1e-10), (f, depth, max0)
+
+
 def test_shards_reproduce_the_full_run(lib, torch_cuda):
     """glfer_amd.shard: frame ranges computed from each rank's own sample window (hops + left
     halo, addressed through a virtual base pointer) give exactly the rows of the full run."""
