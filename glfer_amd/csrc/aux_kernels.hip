@@ -171,8 +171,7 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= nframes) return;                      // wavefront-uniform
   const float *src = psd + (size_t)r * bins;
-  float v[EPL];
-  uint32_t key[EPL];
+  uint32_t key[EPL];                             // the row as keys only: fkey_inv() gives the value back
   float best = 0.0f;
   int besti = 0;
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
@@ -180,9 +179,9 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
   for (int j = 0; j < EPL; j++) {
     const int i = lane + 64 * j;
     const bool in = i < bins;
-    v[j] = in ? src[i] : 0.0f;
-    key[j] = in ? fkey(v[j]) : 0xFFFFFFFFu;      // padding sorts last: never among the m <= bins smallest
-    if (in && v[j] > best) { best = v[j]; besti = i; }   // ascending i: the lane's lowest index of its maximum
+    const float v = in ? src[i] : 0.0f;
+    key[j] = in ? fkey(v) : 0xFFFFFFFFu;         // padding sorts last: never among the m <= bins smallest
+    if (in && v > best) { best = v; besti = i; }         // ascending i: the lane's lowest index of its maximum
     if (in) {
       kmin = key[j] < kmin ? key[j] : kmin;
       kmax = key[j] > kmax ? key[j] : kmax;
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
   const uint32_t ties = (uint32_t)m - below;     // copies of the m-th smallest that belong to the m smallest
   double s = 0.0;
 #pragma unroll
-  for (int j = 0; j < EPL; j++) s += (double)(key[j] < P ? v[j] : 0.0f);
+  for (int j = 0; j < EPL; j++) s += (double)(key[j] < P ? fkey_inv(key[j]) : 0.0f);
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
   if (lane == 0) {
@@ -522,7 +521,9 @@ extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int b
   else if (bins <= 64 * 9) hipLaunchKernelGGL(floor_wave_kernel<9>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
   else if (bins <= 64 * 17) hipLaunchKernelGGL(floor_wave_kernel<17>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
   else if (bins <= 64 * 33) hipLaunchKernelGGL(floor_wave_kernel<33>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
-  else {                                         // longer rows: one workgroup per row, the row in LDS
+  else if (bins <= 64 * 65) hipLaunchKernelGGL(floor_wave_kernel<65>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
+  else if (bins <= 64 * 129) hipLaunchKernelGGL(floor_wave_kernel<129>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
+  else {                                         // longer rows than any block size gives: one workgroup per row, the row in LDS
     const size_t shmem = (size_t)bins * sizeof(float) + 256 * sizeof(uint32_t);
     hipLaunchKernelGGL(floor_kernel, dim3((unsigned)nframes), dim3(256), shmem, st, psd, bins, m, stats);
   }
