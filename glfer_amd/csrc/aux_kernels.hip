@@ -382,14 +382,14 @@ __global__ __launch_bounds__(256) void avg_norm_kernel(const float *__restrict__
 // stores the row: 4 B read (+4 B of the row leaving the window, an L2 hit for small depths) and
 // 8 B written per bin.  The next frame's samples are requested before the current one is reduced.
 template <int BPT>
-__global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict__ psd, long long nframes, int bins,
+__global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict__ psd, long long nframes, int chunk, int bins,
                                                         int n_out, int depth, int minbin, int maxbin, int mode, int max0,
                                                         double *__restrict__ avg, double *__restrict__ ret) {
   __shared__ double p_sum[2][4], p_max[2][4], p_min[2][4], p_var[2][4];
   __shared__ int p_idx[2][4], p_cnt[2][4];
   const int tid = threadIdx.x, wave = tid >> 6;
-  const long long f0 = (long long)blockIdx.x * AVG_CHUNK;
-  const long long f1 = f0 + AVG_CHUNK < nframes ? f0 + AVG_CHUNK : nframes;
+  const long long f0 = (long long)blockIdx.x * chunk;
+  const long long f1 = f0 + chunk < nframes ? f0 + chunk : nframes;
   const int b0 = minbin + tid;
   double cum[BPT];
 #pragma unroll
@@ -536,20 +536,28 @@ extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframe
   if (nframes == 0) return hipSuccess;
   const int band = maxbin - minbin;
   if (band < 1 || minbin < 0 || maxbin > bins || maxbin > n_out || depth < 1) return hipErrorInvalidValue;
-  const unsigned chunks = (unsigned)((nframes + AVG_CHUNK - 1) / AVG_CHUNK);
   const long long nf = (long long)nframes;
-#define GLFER_AVG_FUSED(B)                                                                                          \
-  hipLaunchKernelGGL(avg_fused_kernel<B>, dim3(chunks), dim3(256), 0, st, psd, nf, bins, n_out, depth, minbin, maxbin, \
-                     mode, max0, avg, ret)
+  // A fused block walks `chunk` frames in order, so the launch has nframes/chunk blocks: 128-frame
+  // chunks for long batches, shorter ones (down to 8) to keep ~1000 blocks in flight for short ones.
+  // Every chunk restarts from the `depth` rows before it: once that costs more than the chunk itself
+  // the two-pass form (parallel over bins as well) is the better one.
+  int chunk = AVG_CHUNK;
+  while (chunk > 8 && nf / chunk < 1024) chunk /= 2;
   const int bpt = (band + 255) / 256;
-  if (bpt <= 1) GLFER_AVG_FUSED(1);
-  else if (bpt <= 2) GLFER_AVG_FUSED(2);
-  else if (bpt <= 3) GLFER_AVG_FUSED(3);
-  else if (bpt <= 5) GLFER_AVG_FUSED(5);
-  else if (bpt <= 9) GLFER_AVG_FUSED(9);
-  else if (bpt <= 17) GLFER_AVG_FUSED(17);
-  else if (bpt <= 33) GLFER_AVG_FUSED(33);
-  else {                                             // wider than any block size of the estimator: the two-pass form
+  if (bpt <= 33 && depth <= 2 * chunk) {
+    const unsigned blocks = (unsigned)((nf + chunk - 1) / chunk);
+#define GLFER_AVG_FUSED(B)                                                                                              \
+  hipLaunchKernelGGL(avg_fused_kernel<B>, dim3(blocks), dim3(256), 0, st, psd, nf, chunk, bins, n_out, depth, minbin, maxbin, \
+                     mode, max0, avg, ret)
+    if (bpt <= 1) GLFER_AVG_FUSED(1);
+    else if (bpt <= 2) GLFER_AVG_FUSED(2);
+    else if (bpt <= 3) GLFER_AVG_FUSED(3);
+    else if (bpt <= 5) GLFER_AVG_FUSED(5);
+    else if (bpt <= 9) GLFER_AVG_FUSED(9);
+    else if (bpt <= 17) GLFER_AVG_FUSED(17);
+    else GLFER_AVG_FUSED(33);
+  } else {
+    const unsigned chunks = (unsigned)((nframes + AVG_CHUNK - 1) / AVG_CHUNK);
     hipLaunchKernelGGL(avg_cum_kernel, dim3((unsigned)((band + 255) / 256), chunks), dim3(256), 0, st, psd, nf, bins, n_out,
                        depth, minbin, maxbin, avg);
     hipError_t e = hipGetLastError();
