@@ -10,11 +10,13 @@
 // The 1/N of fft.c:212-216 and the two halvings above are folded into the window: w*sqrt(1/(4N)).
 //
 // Layout: frames per block = 256/(N/32) (N=4096: two frames, two wavefronts each).  The window
-// is the same for every frame and stays in 32 VGPRs for the whole launch; the next frame's samples
-// are fetched (8-byte loads: y[2n], y[2n+1] are adjacent) right after pass 0 has handed its data
-// to LDS.  Mirror step: only the upper half of Z (k >= M/2) goes through LDS, lane t keeps its
-// own Z[k], k < M/2, in registers; the post twiddle W_N^(t + T*m) is the lane's W_N^t (two VGPRs)
-// times the compile-time constant W_32^m.
+// is the same for every frame (in LDS up to N = 4096, re-read per frame above: see VAR); the next
+// frame's samples are fetched -- one load per pair (y[2n], y[2n+1]) in every sample format, integer
+// pairs staying raw until the frame is formed -- right after pass 0 has handed its data to LDS.
+// Mirror step: only the upper half of Z (k >= M/2) goes through LDS, lane t keeps its own Z[k],
+// k < M/2, in registers; the post twiddle W_N^(t + T*m) is the lane's W_N^t (two VGPRs) times the
+// compile-time constant W_32^m.  MT = 1 runs several windows (the tapers of mtm_do, mtm.c:154-239)
+// over the frame in turn and sums the spectra: the multitaper path for N >= 8192.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "stockham16.hpp"
