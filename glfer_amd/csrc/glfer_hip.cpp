@@ -614,12 +614,16 @@ static void copy_wide(void *dst, const void *src, size_t bytes) {
   if (nt <= 1) { memcpy(dst, src, bytes); return; }
   std::vector<std::thread> th;
   const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
-  for (unsigned i = 0; i < nt; i++) {
-    const size_t off = (size_t)i * per;
-    if (off >= bytes) break;
-    const size_t len = std::min(per, bytes - off);
-    th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, len); });
+  size_t done = 0;                               // bytes handed to threads so far
+  try {
+    for (unsigned i = 0; i + 1 < nt && done + per < bytes; i++) {
+      const size_t off = done;
+      th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, per); });
+      done += per;
+    }
+  } catch (...) {                                // no more threads to be had: this one copies the rest
   }
+  memcpy((char *)dst + done, (const char *)src + done, bytes - done);
   for (auto &t : th) t.join();
 }
 
@@ -680,7 +684,13 @@ static int ingest_chunks(glfer_hip_plan *p, size_t frames, size_t chunk_frames,
     const size_t want = std::min(chunk_frames, frames - done - nf);
     nread = 0;
     std::thread fetch;
-    if (want) fetch = std::thread([&] { nread = reader(h_in[cur ^ 1], want); });
+    if (want) {
+      try {
+        fetch = std::thread([&] { nread = reader(h_in[cur ^ 1], want); });
+      } catch (...) {                            // no thread: fetch here, before the row copy
+        nread = reader(h_in[cur ^ 1], want);
+      }
+    }
     if (prev_nf) copy_wide(h_psd + prev_done * bins, h_out[cur ^ 1], prev_nf * bins * sizeof(float));
     if (fetch.joinable()) fetch.join();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
