@@ -312,6 +312,21 @@ def test_host_buffer_entry(lib, oracle, torch_cuda):
     assert max(max(rel_err(got[f], want[f])) for f in range(7)) < TOL
 
 
+def test_host_buffer_entry_many_chunks(lib, torch_cuda):
+    """The host entry streams through pinned buffers in 16 384-frame chunks (the next chunk's samples
+    and the previous chunk's rows are copied by host threads while the GPU works): 70 000 overlapped
+    frames, five chunks, must be the device entry's rows bit for bit -- the halo carried between
+    chunks, the frame-group alignment of the chunk cuts and the threaded copies all show here."""
+    n, overlap, frames = 512, 0.5, 70000
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=3, overlap=overlap, sample_format=lib.SAMPLES_S16))
+    rng = np.random.default_rng(3)
+    raw = (rng.standard_normal(frames * sp.hop + 17) * 5000).clip(-32768, 32767).astype(np.int16)
+    got = sp.run_host(raw)
+    want = sp.run(torch_cuda.from_numpy(raw).cuda()).cpu().numpy()
+    assert got.shape == want.shape == (frames, n // 2 + 1)
+    assert np.array_equal(got, want)
+
+
 def test_linearity_and_scaling_at_full_size(lib, torch_cuda):
     """Size-independent properties at BASELINE's batch scale (65536 frames of N=4096, MTM K=4):
     PSD is quadratic in amplitude, identical frames give identical rows, and Parseval holds."""
