@@ -82,7 +82,7 @@ static size_t tap_slot(int n, int pair, int i, int which) {
 
 extern "C" {
 
-const char *glfer_hip_version(void) { return "glfer_hip 0.3 (gfx950; 16 points/lane Stockham radix-16, LDS exchange; real-input periodogram, shared odd taper)"; }
+const char *glfer_hip_version(void) { return "glfer_hip 0.4 (gfx950; 16 points/lane Stockham radix-16, LDS exchange; real-input periodogram and large-block multitaper, shared odd taper; wavefront floor, fused average)"; }
 
 int glfer_hip_palette(int palette, unsigned char colortab[768]) {
   if (!colortab) return GLFER_E_ARG;
