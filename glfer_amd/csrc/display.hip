@@ -37,35 +37,53 @@ struct LevelsParams {
 // the true walk is ~1e-11, and it is not left to chance: levels_fixup_kernel compares every chunk's
 // warm-up end state with its predecessor's final state, bit for bit, and re-walks the chunk from
 // the true state where they differ.  131 072 columns: 10 M columns/s as one walk, ~16x that in chunks.
-constexpr int LEV_CHUNK = 4096, LEV_WARM = 4096;
+constexpr int LEV_CHUNK = 1024, LEV_WARM = 4096;   // a block walks WARM + CHUNK frames; more, shorter chunks = more blocks, less per block
 
 // Lanes 0 / 1 of a 64-lane block carry the max / min chains over frames [from, to); the other lanes
-// stage loads and stores through LDS.  Frames >= out_from get their levels written.
+// stage loads and stores through LDS.  Frames >= out_from get their levels written.  The chain is the
+// critical path (four dependent conversions/FMAs per frame), so nothing else may sit on it: a batch's
+// 64 inputs are in the chain lane's registers before it starts, and the next batch's statistics are
+// already on their way from memory.
 __device__ __forceinline__ void levels_walk(const float *__restrict__ stats, long long from, long long to,
                                             long long out_from, const LevelsParams &p, float overlap, float &lvl,
                                             bool &first, float *__restrict__ levels, float (&sx)[2][64],
                                             float (&sy)[2][64]) {
   const int lane = threadIdx.x;
+  float r0 = 0.0f, r1 = 0.0f;
+  if (from + lane < to) {
+    r0 = stats[(from + lane) * 4 + 0];
+    r1 = stats[(from + lane) * 4 + 1];
+  }
   for (long long base = from; base < to; base += 64) {
     const long long f = base + lane;
-    if (f < to) {
-      sx[0][lane] = stats[f * 4 + 0];
-      sx[1][lane] = stats[f * 4 + 1];
-    }
+    sx[0][lane] = r0;
+    sx[1][lane] = r1;
     __syncthreads();
+    if (f + 64 < to) {                                     // the next batch, in flight under this one's chain
+      r0 = stats[(f + 64) * 4 + 0];
+      r1 = stats[(f + 64) * 4 + 1];
+    }
     if (lane < 2) {
       const int cnt = (int)((to - base < 64) ? (to - base) : 64);
-      for (int j = 0; j < cnt; j++) {
-        float x = sx[lane][j];
-        if (first) {                                       // g_main.c:1112-1120
-          if (overlap > 0.0) x /= overlap;
-          lvl = x;
-          first = false;
-        } else {                                           // g_main.c:1122-1123
-          lvl = (float)((1.0 - 0.99) * (double)x + 0.99 * (double)lvl);
+      float x[64];
+#pragma unroll
+      for (int j = 0; j < 64; j++) x[j] = sx[lane][j];
+#pragma unroll
+      for (int j = 0; j < 64; j++) {
+        if (j < cnt) {
+          if (first) {                                     // g_main.c:1112-1120
+            float x0 = x[j];
+            if (overlap > 0.0) x0 /= overlap;
+            lvl = x0;
+            first = false;
+          } else {                                         // g_main.c:1122-1123
+            lvl = (float)((1.0 - 0.99) * (double)x[j] + 0.99 * (double)lvl);
+          }
         }
-        sy[lane][j] = lvl;
+        x[j] = lvl;
       }
+#pragma unroll
+      for (int j = 0; j < 64; j++) sy[lane][j] = x[j];
     }
     __syncthreads();
     if (f < to && f >= out_from) {
