@@ -721,6 +721,26 @@ int glfer_hip_spectrogram_host(glfer_hip_plan *p, const void *h_stream, size_t n
   if (!h_psd) return GLFER_E_ARG;
   const size_t esz = p->cfg.sample_format == GLFER_SAMPLES_F32 ? 4 : (p->cfg.sample_format == GLFER_SAMPLES_S16 ? 2 : 1);
   const size_t hop_bytes = (size_t)p->hop * esz;
+  if (frames * hop_bytes + frames * (size_t)p->bins * sizeof(float) < ((size_t)4 << 20)) {
+    // a few megabytes: one copy each way costs less than setting the pipeline up
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    const size_t used = frames * (size_t)p->hop;
+    void *d_in = nullptr;
+    float *d_out = nullptr;
+    int rc = GLFER_OK;
+    hipError_t e = hipMalloc(&d_in, used * esz);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, frames * (size_t)p->bins * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_in, h_stream, used * esz, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: staging");
+    if (rc == GLFER_OK) rc = run_device(p, d_in, used, 0, frames, d_out, nullptr, nullptr);
+    if (rc == GLFER_OK) {
+      e = hipMemcpy(h_psd, d_out, frames * (size_t)p->bins * sizeof(float), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: copy back");
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+  }
   size_t given = 0;
   auto reader = [&](unsigned char *dst, size_t want) {
     copy_wide(dst, (const unsigned char *)h_stream + given * hop_bytes, want * hop_bytes);
