@@ -164,9 +164,79 @@ __device__ __forceinline__ void count_below4(uint32_t &c, uint32_t k0, uint32_t 
       : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29");
 }
 
+// inclusive prefix sum over the wavefront (the same DPP walk, every lane keeps its value)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
+// number of keys below T, over the wavefront
+template <int NK>
+__device__ __forceinline__ uint32_t count_below(const uint32_t (&key)[NK], uint32_t T) {
+  uint32_t c = 0, Tv;
+  asm("v_mov_b32 %0, %1" : "=v"(Tv) : "s"(T));              // compares against a VGPR: an SGPR operand halves the VALU rate (tools/pkbench3)
+  constexpr int G = NK >= 4 ? (NK / 4) * 4 : 0;
+#pragma unroll
+  for (int j = 0; j < G; j += 4) count_below4(c, key[j], key[j + 1], key[j + 2], key[j + 3], Tv);
+#pragma unroll
+  for (int j = G; j < NK; j++) c += key[j] < Tv ? 1u : 0u;
+  return wave_sum_u32(c);
+}
+
+// P = the m-th smallest of the wavefront's `total` real keys (the arrays are padded with 0xFFFFFFFF),
+// below = number of keys < P.  kmin / kmax: smallest and largest real key.
+template <int NK>
+__device__ __forceinline__ void select_mth(const uint32_t (&key)[NK], uint32_t total, uint32_t m, uint32_t kmin, uint32_t kmax,
+                                           uint32_t &P, uint32_t &below) {
+  const uint32_t diff = kmin ^ kmax;
+  P = kmin;
+  below = 0;
+  if (!diff) return;
+  const int hb = 31 - __builtin_clz(diff);       // first bit in which the keys differ
+  P = (hb == 31) ? 0u : (kmin >> (hb + 1)) << (hb + 1);
+  uint32_t upper = total;                        // number of keys below the end of the bucket [P, P + 2^(b+1)) under search
+  for (int b = hb; b >= 0; b--) {
+    const uint32_t T = P | (1u << b);
+    const uint32_t c = count_below<NK>(key, T);
+    if (c < m) { P = T; below = c; } else upper = c;
+    if (upper - below == 1) {                    // one key left in the bucket: it is the smallest key >= P
+      uint32_t cand = 0xFFFFFFFFu;
+#pragma unroll
+      for (int j = 0; j < NK; j++) cand = (key[j] >= P && key[j] < cand) ? key[j] : cand;
+      P = wave_min_u32(cand);
+      return;
+    }
+  }
+}
+
+template <int NK>
+__device__ __forceinline__ double sum_below(const uint32_t (&key)[NK], uint32_t P) {
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < NK; j++) s += (double)(key[j] < P ? fkey_inv(key[j]) : 0.0f);
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+  return s;
+}
+
+// Rows of 577..2049 bins first shrink the problem: with c = ceil(m/64) <= 2, the largest of the lanes'
+// c-th smallest keys is a pivot with at least 64 c >= m keys at or below it -- the m smallest are all
+// among them -- and on a typical row only a few hundred keys are.  Those are compacted through a
+// wavefront-private LDS strip (a DPP prefix sum gives each lane its offset) into FLOOR_CAP keys per
+// lane, and the bitwise search runs on them: 8 compares per step instead of 33.  Rows on which the
+// pivot does not cut enough (many ties) take the search over the whole row.
+constexpr int FLOOR_CAP = 8;
+
 template <int EPL>
 __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict__ psd, long long nframes, int bins, int m,
                                                          float *__restrict__ stats) {
+  constexpr bool kCompact = EPL >= 17 && EPL <= 33;    // (at 9 keys per lane the detour costs what it saves)
+  __shared__ uint32_t strip[kCompact ? 4 : 1][kCompact ? 64 * FLOOR_CAP : 1];
   const int lane = threadIdx.x & 63;
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= nframes) return;                      // wavefront-uniform
@@ -174,7 +244,7 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
   uint32_t key[EPL];                             // the row as keys only: fkey_inv() gives the value back
   float best = 0.0f;
   int besti = 0;
-  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu;   // s1 <= s2: the lane's two smallest keys
 #pragma unroll
   for (int j = 0; j < EPL; j++) {
     const int i = lane + 64 * j;
@@ -182,11 +252,16 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
     const float v = in ? src[i] : 0.0f;
     key[j] = in ? fkey(v) : 0xFFFFFFFFu;         // padding sorts last: never among the m <= bins smallest
     if (in && v > best) { best = v; besti = i; }         // ascending i: the lane's lowest index of its maximum
-    if (in) {
-      kmin = key[j] < kmin ? key[j] : kmin;
-      kmax = key[j] > kmax ? key[j] : kmax;
+    if (in) kmax = key[j] > kmax ? key[j] : kmax;
+    if constexpr (kCompact) {
+      const uint32_t hi = key[j] > s1 ? key[j] : s1;
+      s1 = key[j] < s1 ? key[j] : s1;
+      s2 = hi < s2 ? hi : s2;
+    } else {
+      kmin = key[j] < kmin ? key[j] : kmin;      // (padding is the largest key)
     }
   }
+  if constexpr (kCompact) kmin = s1;
   // largest bin and its first index (strict > scan from 0.0, fft.c:284-291): bins are >= 0, so the
   // float order is the order of the bit patterns
   const uint32_t peak_bits = wave_max_u32(__float_as_uint(best > 0.0f ? best : 0.0f));
@@ -194,41 +269,46 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
   const uint32_t first = wave_min_u32((best == peak && peak > 0.0f) ? (uint32_t)besti : 0xFFFFFFFFu);
   const int peak_i = peak > 0.0f ? (int)first : 0;
 
-  // key of the m-th smallest bin
+  // key of the m-th smallest bin, the number of keys below it, the sum of those
   kmin = wave_min_u32(kmin);
   kmax = wave_max_u32(kmax);
-  const uint32_t diff = kmin ^ kmax;
-  uint32_t P = kmin, below = 0;                  // below = number of keys < P
-  if (diff) {
-    const int hb = 31 - __builtin_clz(diff);     // first bit in which the row's keys differ
-    P = (hb == 31) ? 0u : (kmin >> (hb + 1)) << (hb + 1);
-    uint32_t upper = (uint32_t)bins;             // number of keys below the end of the bucket [P, P + 2^(b+1)) under search
-    for (int b = hb; b >= 0; b--) {
-      const uint32_t T = P | (1u << b);
-      uint32_t c = 0, Tv;
-      asm("v_mov_b32 %0, %1" : "=v"(Tv) : "s"(T));          // compares against a VGPR: an SGPR operand halves the VALU rate (tools/pkbench3)
-      constexpr int G = EPL >= 5 ? (EPL / 4) * 4 : 0;
+  uint32_t P = 0, below = 0;
+  double s = 0.0;
+  bool done = false;
+  if constexpr (kCompact) {
+    const int cth = (m + 63) >> 6;               // every lane's cth smallest: 64*cth >= m keys at or below the pivot
+    const uint32_t pivot = cth <= 2 ? wave_max_u32(cth == 1 ? s1 : s2) : 0xFFFFFFFFu;
+    if (pivot != 0xFFFFFFFFu) {
+      uint32_t n = 0;
 #pragma unroll
-      for (int j = 0; j < G; j += 4) count_below4(c, key[j], key[j + 1], key[j + 2], key[j + 3], Tv);
+      for (int j = 0; j < EPL; j++) n += key[j] <= pivot ? 1u : 0u;
+      const uint32_t incl = wave_scan_u32(n);
+      const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      if (C <= 64u * FLOOR_CAP) {                // wavefront-uniform
+        uint32_t *mine = strip[threadIdx.x >> 6];
+        uint32_t off = incl - n;
 #pragma unroll
-      for (int j = G; j < EPL; j++) c += key[j] < Tv ? 1u : 0u;
-      c = wave_sum_u32(c);
-      if (c < (uint32_t)m) { P = T; below = c; } else upper = c;
-      if (upper - below == 1) {                  // one key left in the bucket: it is the smallest key >= P
-        uint32_t cand = 0xFFFFFFFFu;
+        for (int j = 0; j < EPL; j++) {
+          const bool is = key[j] <= pivot;
+          if (is) mine[off] = key[j];
+          off += is ? 1u : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t cand[FLOOR_CAP];
 #pragma unroll
-        for (int j = 0; j < EPL; j++) cand = (key[j] >= P && key[j] < cand) ? key[j] : cand;
-        P = wave_min_u32(cand);
-        break;
+        for (int q = 0; q < FLOOR_CAP; q++) cand[q] = (uint32_t)(lane + 64 * q) < C ? mine[lane + 64 * q] : 0xFFFFFFFFu;
+        select_mth<FLOOR_CAP>(cand, C, (uint32_t)m, kmin, pivot, P, below);
+        s = sum_below<FLOOR_CAP>(cand, P);
+        done = true;
       }
     }
   }
+  if (!done) {
+    select_mth<EPL>(key, (uint32_t)bins, (uint32_t)m, kmin, kmax, P, below);
+    s = sum_below<EPL>(key, P);
+  }
   const uint32_t ties = (uint32_t)m - below;     // copies of the m-th smallest that belong to the m smallest
-  double s = 0.0;
-#pragma unroll
-  for (int j = 0; j < EPL; j++) s += (double)(key[j] < P ? fkey_inv(key[j]) : 0.0f);
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
   if (lane == 0) {
     float fl = (float)(s + (double)ties * (double)fkey_inv(P));
     fl = (float)(fl / 0.05);                     // fft.c:274 (float / double)
