@@ -8,11 +8,17 @@ this rank's batch of frames.  Frames are independent, so N GPUs = N disjoint fra
 data-path collective (weak scaling: frames per GPU fixed); torch.distributed (RCCL) is used only
 for the barrier and the max-over-ranks of the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--workload mtm|fft]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--workload mtm|fft|mtm16k|hparma]
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (one child process per GPU, started before anything in this process touches the GPU) and
+prints rank 0's line; under `python -m torch.distributed.run` it is one of the ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,6 +27,22 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TOPS = 78.6        # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-instructions/s
+
+# workload -> (name, n, overlap, nw, kmax, default frames per GPU per step, frames of the CPU sample stream)
+WORKLOADS = {
+    "mtm": ("C3: multitaper N=4096 NW=2.5 mtm_k=4 (5 tapers), overlap 0, 48 kHz mono f32", 4096, 0.0, 2.5, 4, 262144, 16384),
+    "fft": ("C2: periodogram Hanning N=4096, overlap 75%, 48 kHz mono f32", 4096, 0.75, 0.0, 0, 1048576, 131072),
+    "mtm16k": ("C4: multitaper N=16384 NW=4.5 mtm_k=8 (9 tapers), overlap 0, 48 kHz mono f32", 16384, 0.0, 4.5, 8, 65536, 1024),
+    "hparma": ("C5: HP-ARMA t=128 p_e=32 N=4096, overlap 0, 48 kHz mono f32 (compute/latency bound, not HBM)", 4096, 0.0, 0.0, 0, 16384, 4096),
+}
+METRICS = {"mtm": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4",
+           "fft": "spectrogram frames/sec + achieved HBM GB/s, N=4096 periodogram",
+           "mtm16k": "spectrogram frames/sec + achieved HBM GB/s, N=16384 MTM K=8",
+           "hparma": "spectrogram frames/sec, HP-ARMA t=128 p_e=32 N=4096"}
+# the kernel that takes the body of the launch (glfer_hip.cpp launch_by_n) and its committed PMC summary
+KERNELS = {"mtm": ("spectro16y_kernel", "hbm_traffic.json"), "fft": ("spectro16h_kernel<12>", "hbm_traffic_fft.json"),
+           "mtm16k": ("spectro16h_kernel<14> (multitaper form)", "hbm_traffic_mtm16k.json"),
+           "hparma": ("hparma_kernel", None)}
 
 
 def synth_on_device(torch, nsamples, device, seed, fs=48000.0):
@@ -40,31 +62,103 @@ def synth_on_device(torch, nsamples, device, seed, fs=48000.0):
 
 def cpu_baseline(workload, n, overlap, nw, kmax, frames):
     """The oracle (CPU restatement of fft_do+fft_psd / mtm_do, pinned to the reference's
-    fft_radix2.c) timed on one host core on a bounded prefix of the same workload."""
-    import numpy as np
+    fft_radix2.c) timed on the host on a bounded prefix of the same workload: (i) one thread, the
+    shape of the reference (source.c:130-170 is single-threaded); (ii) one independent estimator
+    instance per thread over the host cores this process may use."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _signals import synth
     hop = O.hop(n, overlap)
     x = synth(frames * hop, seed=0)
-    # the same `frames`-frame stream is processed repeatedly until >= 12 s of CPU work is timed
+
+    def one_pass(stream):
+        if workload in ("mtm", "mtm16k"):
+            O.spectrogram_mtm(stream, n, overlap, nw, kmax)
+        elif workload == "hparma":
+            O.spectrogram_hparma(stream, n, overlap, 128, 32)
+        else:
+            O.spectrogram_fft(stream, n, overlap, O.WINDOWS["hanning"])
+
+    # (i) the same `frames`-frame stream is processed repeatedly until >= 10 s of CPU work is timed
     # (memory stays bounded; every pass is the full per-frame work of the reference path)
     done, dt = 0, 0.0
-    while dt < 12.0:
+    while dt < 10.0:
         t0 = time.perf_counter()
-        if workload == "mtm":
-            O.spectrogram_mtm(x, n, overlap, nw, kmax)
-        elif workload == "hparma":
-            O.spectrogram_hparma(x, n, overlap, 128, 32)
-        else:
-            O.spectrogram_fft(x, n, overlap, O.WINDOWS["hanning"])
+        one_pass(x)
         dt += time.perf_counter() - t0
         done += frames
-    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+    rate1 = done / dt
+    # (ii) every thread runs its own instance over a prefix sized for ~6 s at the one-thread rate
+    # (ctypes releases the GIL; the oracle keeps no global state).  A 1-GPU box gives one job
+    # 16 of the host's cores, so the pool is capped there.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    per_thread = max(1, min(frames, int(rate1 * 6.0)))
+    part = x[:per_thread * hop + (n - hop)]
+    per_thread = int(O.num_frames(part.size, n, overlap))
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        t0 = time.perf_counter()
+        list(pool.map(one_pass, [part] * cores))
+        dtn = time.perf_counter() - t0
+    return {"value": rate1, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d frames of the same workload (a %d-frame stream, repeated), single thread, "
                       "oracle/glfer_oracle.c (gcc -O2, radix-2 recurrence FFT as fft_radix2.c), %.1f s"
                       % (done, frames, dt),
+            "all_cores": {"value": cores * per_thread / dtn, "unit": "frames/s", "cores": cores, "kind": "port",
+                          "sample": "%d threads x %d frames, one estimator instance per thread, %.1f s"
+                                    % (cores, per_thread, dtn)},
             "host_cores_available": os.cpu_count()}
+
+
+def self_launch(args, argv):
+    """Start one rank per GPU as child processes and relay rank 0's JSON line.  Nothing here
+    imports torch or touches HIP: the children are started before any GPU call of this process
+    (a process that has initialised the GPU must never be replaced or forked)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()                                   # this exact child, by PID
+            p.wait()
+        rc = rc or p.returncode
+    for ln in out.decode(errors="replace").splitlines():       # the JSON line on stdout, anything else on stderr
+        print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    return rc
+
+
+def dry_run(args, world, rank):
+    """--dry-run: the launch path only (rendezvous, barrier, max-over-ranks, rank 0 prints), on
+    gloo, no GPU.  tests/test_bench_contract.py uses it to exercise `--gpus 2` as typed."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": t.item(), "steps": args.steps,
+                          "warmup": args.warmup, "workload": args.workload}))
 
 
 def main():
@@ -72,45 +166,52 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=262144, help="frames per GPU per step")
-    ap.add_argument("--workload", default="mtm", choices=["mtm", "fft", "hparma"])
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's default)")
+    ap.add_argument("--workload", default="mtm", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    import torch
-    import glfer_amd as G
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
+    import torch
+    import glfer_amd as G
+
+    # GLFER_BENCH_REHEARSE=1: every rank on cuda:0 with gloo for the barrier and the max -- lets a
+    # one-GPU box run the N > 1 path end to end (same sharding, same launches); never a measurement
+    rehearse = os.environ.get("GLFER_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    if args.workload == "mtm":
-        n, overlap, nw, kmax = 4096, 0.0, 2.5, 4
+    name, n, overlap, nw, kmax, default_frames, cpu_frames = WORKLOADS[args.workload]
+    if args.workload in ("mtm", "mtm16k"):
         params = G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax)
-        name = "C3: multitaper N=4096 NW=2.5 mtm_k=4 (5 tapers), overlap 0, 48 kHz mono f32"
     elif args.workload == "hparma":
-        n, overlap, nw, kmax = 4096, 0.0, 0.0, 0
         params = G.HparmaParams(n=n, overlap=overlap, t=128, p_e=32)
-        name = "C5: HP-ARMA t=128 p_e=32 N=4096, overlap 0, 48 kHz mono f32 (compute/latency bound, not HBM)"
-        if args.frames == 262144:
-            args.frames = 16384
     else:
-        n, overlap, nw, kmax = 4096, 0.75, 0.0, 0
         params = G.FftParams(n=n, window_type=G.WINDOWS["hanning"], overlap=overlap)
-        name = "C2: periodogram Hanning N=4096, overlap 75%, 48 kHz mono f32"
-        if args.frames == 262144:
-            args.frames = 1048576                     # a 2^30-sample stream per GPU
+    frames = args.frames or default_frames          # a 2^30-sample stream per GPU
     sp = G.Spectrogram(params, device=local)
     hop, bins = sp.hop, sp.bins
-    frames = args.frames
     # Weak scaling: the job is world*frames frames of one long stream; this rank owns the
     # contiguous frame range frame_range() gives it and holds only the samples of its window
     # (its hops + the N-H history halo on the left; the stream starts with zero history).
@@ -132,6 +233,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # events on the stream the kernels are launched on (run_shard hands torch's current stream
+    # to the C-ABI, and torch.cuda.Event records on that same stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in ev:
@@ -141,7 +244,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
@@ -152,49 +255,53 @@ def main():
         b_alg = 4 * hop + 4 * bins                      # compulsory read of H new samples + P bins out
         achieved = frames * b_alg / (kernel_ms * 1e-3) / 1e9
         ntap = sp.ntapers
+        kernel, pmc_name = KERNELS[args.workload]
         # measured HBM bytes per frame of this kernel, from the committed rocprofv3 PMC passes
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is) -- see profiles/
-        traffic = None
-        try:
-            pname = {"mtm": "r01_hbm_traffic.json", "fft": "r01_hbm_traffic_fft.json"}[args.workload]
-            prof = json.load(open(os.path.join(ROOT, "profiles", pname)))
-            traffic = prof["hbm_traffic_bytes_per_frame_corrected"] * frames
-        except Exception:
-            pass
+        traffic, traffic_src = None, None
+        for rnd in ("r02_", "r01_"):
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", rnd + pmc_name)))
+                traffic = prof["hbm_traffic_bytes_per_frame_corrected"] * frames
+                traffic_src = "profiles/" + rnd + pmc_name
+                break
+            except Exception:
+                pass
         line = {
-            "metric": {"mtm": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4",
-                       "fft": "spectrogram frames/sec + achieved HBM GB/s, N=4096 periodogram",
-                       "hparma": "spectrogram frames/sec, HP-ARMA t=128 p_e=32 N=4096"}[args.workload],
+            "metric": METRICS[args.workload],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU)" if rehearse else ""),
             "config": {"workload": name, "frames_per_gpu_per_step": frames, "n": n, "hop": hop,
                        "tapers": ntap, "sharding": "frame ranges, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch, rocprofv3 PMC (profiles/r01_hbm_traffic*.json)",
+                         "traffic_unit": "bytes per launch, rocprofv3 PMC (%s)" % traffic_src,
                          "algorithmic_bytes_per_launch": frames * b_alg,
-                         "kernel": {"hparma": "hparma_kernel", "fft": "spectro16h_kernel<12>", "mtm": "spectro16y_kernel"}[args.workload],
+                         "kernel": kernel,
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_frame": b_alg,
                          "note": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac"},
             "hbm_gbs_aggregate": fps * b_alg / 1e9,
         }
         # FP32 VALU view of the same launch: butterflies 3*M*log2(M) per complex M-point transform
-        # + inter-pass twiddles, taper multiply and |Z|^2.  MTM: one N-point transform per taper
-        # PAIR, the odd taper shared by two frames (ntap/2 transforms per frame); periodogram: one
-        # N/2-point transform per frame + the real-input split (8 ops per bin)
+        # + inter-pass twiddles, taper multiply and |Z|^2.  MTM at N <= 4096: one N-point transform
+        # per taper PAIR, the odd taper shared by two frames (ntap/2 transforms per frame);
+        # periodogram and MTM at N >= 8192: one N/2-point transform per taper + the real-input
+        # split (8 ops per bin)
         import math
+        m = n // 2
+        real_input = 3 * m * math.log2(m) + 4 * (m - m // 64) + 2 * m + 8 * m
         if args.workload == "fft":
-            m = n // 2
-            lane_ops = 3 * m * math.log2(m) + 4 * (m - m // 64) + 2 * m + 8 * m
+            lane_ops = real_input
+        elif args.workload == "mtm16k":
+            lane_ops = ntap * real_input
         else:
             lane_ops = (ntap / 2.0) * (3 * n * math.log2(n) + 4 * (n - n // 64) + 2 * n + 2 * n)
         line["valu"] = {"lane_ops_per_frame": lane_ops, "achieved_Tops": frames * lane_ops / (kernel_ms * 1e-3) / 1e12,
                         "peak_Tops": VALU_PEAK_TOPS,
                         "frac": frames * lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}
         if world == 1 and not args.no_cpu_baseline:
-            cpu_frames = {"mtm": 16384, "fft": 131072, "hparma": 4096}[args.workload]
             line["cpu_baseline"] = cpu_baseline(args.workload, n, overlap, nw, kmax, cpu_frames)
         print(json.dumps(line))
     if world > 1:

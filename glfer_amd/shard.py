@@ -2,7 +2,7 @@
 
 Frame f depends only on samples [f*H - (N-H), f*H + H) (fft.c:98-113), so the frame index
 range is cut into contiguous blocks, one per rank, each rank reading its hops plus a left halo
-of N-H samples (zeros for rank 0, as fft.c:103-108).  There is no exchange step: no collective
+of the N-H history samples, rounded up to whole hops (zeros for rank 0, as fft.c:103-108).  There is no exchange step: no collective
 on the data path, only the outputs' row ranges are disjoint.
 """
 
@@ -24,13 +24,22 @@ def frame_range(total_frames, rank, world, align=FRAME_ALIGN):
     return first, last - first
 
 
-def sample_window(first, count, hop, n, history_mode=0):
-    """[begin, end) of the stream samples the frames [first, first+count) read.
+def halo_samples(hop, n, history_mode=0):
+    """Samples a rank needs to the left of its first hop: the N-H history rounded UP to whole
+    hops.  Whole hops because per-hop mean removal (cfg.sub_mean, fft.c:86-96) corrects every
+    history sample by the mean of the hop it arrived in, so the engine reads ceil((N-H)/H) complete
+    hops back (glfer_hip.cpp run_device) -- the same rule the chunked ingest uses between chunks.
     history_mode 1 (history zeroed in every frame) needs no halo."""
+    if history_mode:
+        return 0
+    return -(-(n - hop) // hop) * hop
+
+
+def sample_window(first, count, hop, n, history_mode=0):
+    """[begin, end) of the stream samples the frames [first, first+count) read."""
     if count == 0:
         return 0, 0
-    halo = 0 if history_mode else n - hop
-    begin = max(0, first * hop - halo)
+    begin = max(0, first * hop - halo_samples(hop, n, history_mode))
     return begin, (first + count) * hop
 
 

@@ -937,8 +937,8 @@ void go_pcm_s16_to_float(const short *in, size_t n, float *out)
 }
 
 /* ------------------------------------------------------------------ */
-/* One frame per full hop of H samples (wav_fmt.c:119 delivers whole blocks;
- * a trailing partial block is dropped here). */
+/* One frame per full hop of H samples.  (A file source also hands over a trailing partial
+ * block, wav_fmt.c:102-119: that is go_wav_spectrogram, below.) */
 size_t go_num_frames(size_t nsamples, int n, float overlap)
 {
   int h = go_hop(n, overlap);
@@ -987,6 +987,290 @@ void go_spectrogram_mtm(const float *stream, size_t nsamples, int n,
     go_mtm_frame(&st, tapers, sig, kmax, hop, first, psd_out + f * nb);
   }
   free(hop);
+  free(tapers);
+  free(sig);
+  go_fft_state_free(&st);
+}
+
+/* ------------------------------------------------------------------ */
+/* wav_fmt.c:81-121 wav_read(): one read() of out_len samples per call into a buffer that is
+ * allocated (zeroed) on the first call and never cleared afterwards.  A short last read
+ * converts only the samples it delivered -- n_read for 8 bit, n_read/2 for 16 bit (an odd
+ * trailing byte is dropped) -- and still reports one block (*n_out = n_read == 0 ? 0 : 1), so
+ * the estimator sees the new samples over the STALE tail of the previous block; that tail is
+ * whatever the estimator left there (prepare_audio removes the hop's mean in place,
+ * fft.c:93-95).  The PCM bytes are handed over in memory instead of through a descriptor. */
+void go_wav_open(go_wav *w, const unsigned char *pcm, size_t nbytes, int bits, int out_len)
+{
+  w->pcm = pcm;
+  w->nbytes = nbytes;
+  w->pos = 0;
+  w->bits = bits;
+  w->out_len = out_len;
+  w->buff = (float *)calloc((size_t)out_len, sizeof(float));       /* wav_fmt.c:99 */
+}
+
+void go_wav_close(go_wav *w)
+{
+  free(w->buff);
+  w->buff = NULL;
+}
+
+int go_wav_read(go_wav *w, float **buf_out)
+{
+  const size_t s_bufsize = (size_t)w->out_len * w->bits / 8;       /* wav_fmt.c:87 */
+  size_t n_read = w->nbytes - w->pos;                              /* read(): what is left, at most s_bufsize */
+  if (n_read > s_bufsize)
+    n_read = s_bufsize;
+  const unsigned char *buf = w->pcm + w->pos;
+  w->pos += n_read;
+  if (w->bits == 8) {                                              /* wav_fmt.c:104-108 */
+    for (size_t i = 0; i < n_read; i++)
+      w->buff[i] = ((float)buf[i] - 128) / 128;
+  } else if (w->bits == 16) {                                      /* wav_fmt.c:109-116 */
+    for (size_t i = 0; i < n_read / 2; i++) {
+      short v;
+      memcpy(&v, buf + 2 * i, 2);
+      w->buff[i] = (float)v / 32768;
+    }
+  }
+  *buf_out = w->buff;
+  return n_read == 0 ? 0 : 1;                                      /* wav_fmt.c:119 */
+}
+
+/* source.c:118-165 over a whole WAV data chunk: wav_read() until it reports no block, one
+ * estimator call per block ON THE READER'S OWN BUFFER (audio_buf = buff, source.c:143-148).
+ * mode 0: fft_do + fft_psd; mode 1: mtm_do.  Returns the number of rows written (at most
+ * max_frames). */
+size_t go_wav_spectrogram(const unsigned char *pcm, size_t nbytes, int bits, int mode, int n,
+                          float overlap, int window_type, float a, int limiter, int sub_mean,
+                          int history_mode, double nw, int kmax, size_t max_frames, float *psd_out)
+{
+  go_fft_state st;
+  go_fft_state_init(&st, n, overlap, mode == 1 ? GO_WIN_RECTANGULAR : window_type, mode == 1 ? 0.0f : a,
+                    mode == 1 ? 0 : limiter, sub_mean);
+  double *tapers = NULL, *sig = NULL;
+  if (mode == 1) {
+    tapers = (double *)malloc((size_t)(kmax + 1) * n * sizeof(double));
+    sig = (double *)malloc((size_t)(kmax + 1) * sizeof(double));
+    go_dpss(n, kmax, nw, tapers, sig);
+  }
+  const size_t nb = (size_t)n / 2 + 1;
+  go_wav w;
+  go_wav_open(&w, pcm, nbytes, bits, go_hop(n, overlap));
+  size_t f = 0;
+  float *hop;
+  while (f < max_frames && go_wav_read(&w, &hop)) {
+    int first = (history_mode == 1) ? 1 : (f == 0);
+    if (mode == 1)
+      go_mtm_frame(&st, tapers, sig, kmax, hop, first, psd_out + f * nb);
+    else
+      go_fft_frame(&st, hop, first, psd_out + f * nb);
+    f++;
+  }
+  go_wav_close(&w);
+  free(tapers);
+  free(sig);
+  go_fft_state_free(&st);
+  return f;
+}
+
+/* ------------------------------------------------------------------ */
+/* lmp.c:59-99 lmp_init, lmp.c:101-181 lmp_do.  The ring of nl periodograms starts zeroed
+ * (lmp.c:87-93) and is written round-robin (j_l, lmp.c:176-178); mean and variance per bin are
+ * taken over the ring in SLOT order, in double.  prepare_audio's output is overwritten by the
+ * raw assembled frame (lmp.c:114-116), so window, a and limiter have no effect (the window is
+ * rectangular anyway, source.c:395). */
+void go_lmp_init(go_lmp_state *st, int n, float overlap, int nl, int sub_mean)
+{
+  go_fft_state_init(&st->fft, n, overlap, GO_WIN_RECTANGULAR, 0.0f, 0, sub_mean);
+  st->nl = nl;
+  st->j_l = 0;
+  st->ring = (float *)calloc((size_t)nl * n, sizeof(float));       /* matrix(0,nl-1,0,n-1), cleared */
+  st->my = (double *)calloc((size_t)n, sizeof(double));
+  st->sy = (double *)calloc((size_t)n, sizeof(double));
+}
+
+void go_lmp_free(go_lmp_state *st)
+{
+  go_fft_state_free(&st->fft);
+  free(st->ring);
+  free(st->my);
+  free(st->sy);
+  st->ring = NULL;
+  st->my = st->sy = NULL;
+}
+
+void go_lmp_frame(go_lmp_state *st, float *hop, int first_buffer, float *psd_buf)
+{
+  const int n_fft = st->fft.n, nl = st->nl;
+  double *my = st->my, *sy = st->sy;
+  double v_hat;
+
+  go_prepare(&st->fft, hop, first_buffer);                         /* lmp.c:110 */
+  for (int i = 0; i < n_fft; i++)                                  /* lmp.c:114-116 */
+    st->fft.inbuf_fft[i] = st->fft.inbuf_audio[i];
+  go_rfft_halfcomplex(st->fft.inbuf_fft, (size_t)n_fft);           /* lmp.c:121 */
+  go_psd(st->fft.inbuf_fft, n_fft, st->ring + (size_t)st->j_l * n_fft);   /* lmp.c:125 */
+
+  for (int i = 0; i < n_fft / 2 + 1; i++) {                        /* lmp.c:134-140 */
+    my[i] = 0.0;
+    for (int j = 0; j < nl; j++)
+      my[i] += st->ring[(size_t)j * n_fft + i];
+    my[i] /= nl;
+  }
+  for (int i = 0; i < n_fft / 2 + 1; i++) {                        /* lmp.c:143-149 */
+    sy[i] = 0.0;
+    for (int j = 0; j < nl; j++)
+      sy[i] += (st->ring[(size_t)j * n_fft + i] - my[i]) * (st->ring[(size_t)j * n_fft + i] - my[i]);
+    sy[i] /= (nl - 1);
+  }
+  for (int i = 0; i < n_fft / 2 + 1; i++) {                        /* lmp.c:151-159 */
+    v_hat = my[i] * my[i] - sy[i];
+    if (v_hat < 0.0) v_hat = 0.0;
+    v_hat = 0.5 * (my[i] - sqrt(v_hat));
+    psd_buf[i] = -sqrt(nl / 2.0) + (nl * my[i]) / (2.0 * sqrt(2.0 * nl) * v_hat);
+    if (psd_buf[i] <= 1.0e-3) psd_buf[i] = 1e-3;
+  }
+  psd_buf[0] = 1e-3;                                               /* lmp.c:160 */
+
+  st->j_l++;                                                       /* lmp.c:176-178 */
+  if (st->j_l == nl)
+    st->j_l = 0;
+}
+
+/* source.c:130-158 over a whole stream, LMP mode */
+void go_spectrogram_lmp(const float *stream, size_t nsamples, int n, float overlap, int nl,
+                        int sub_mean, int history_mode, float *out)
+{
+  go_lmp_state st;
+  go_lmp_init(&st, n, overlap, nl, sub_mean);
+  const int h = go_hop(n, overlap);
+  const size_t frames = go_num_frames(nsamples, n, overlap);
+  const size_t nb = (size_t)n / 2 + 1;
+  float *hop = (float *)malloc((size_t)h * sizeof(float));
+  for (size_t f = 0; f < frames; f++) {
+    memcpy(hop, stream + f * h, (size_t)h * sizeof(float));
+    int first = (history_mode == 1) ? 1 : (f == 0);
+    go_lmp_frame(&st, hop, first, out + f * nb);
+  }
+  free(hop);
+  go_lmp_free(&st);
+}
+
+/* ------------------------------------------------------------------ */
+/* The harmonic F-test side computation of mtm.c.  Tables: mtm.c:76-83 (U0), mtm.c:124-136
+ * (sum_U0_sqr and hn, both accumulated in float).  Per frame: mtm.c:165-174 (mu = transform of
+ * the hn-windowed frame), mtm.c:203-210 (denominator: sum over tapers of |y_j - mu U0_j|^2, DC
+ * and 0 < i < n/2 only: the Nyquist bin's stays 0), mtm.c:222-233 (numerator / denominator).
+ * In the reference build that fft_radix2.c serves, the transform at mtm.c:173 runs in place on
+ * inbuf_fft and `mu` is never written: mu_live = 0 restates that (mu all zeros, so ftest is 0,
+ * or NaN where the denominator is 0); mu_live = 1 is the evident intent (what the FFTW build
+ * computes: rfftw_one(plan, inbuf_fft, mu), mtm.c:171). */
+void go_ftest_tables(int n, int kmax, const double *tapers, double *U0, float *hn, float *sum_U0_sqr_out)
+{
+  float sum_U0_sqr;
+  for (int j = 0; j <= kmax; j++) {                                /* mtm.c:76-83 */
+    U0[j] = 0.0;
+    for (int i = 0; i < n; i++)
+      U0[j] += tapers[(size_t)j * n + i];
+  }
+  sum_U0_sqr = 0.0;                                                /* mtm.c:125-128 */
+  for (int j = 0; j <= kmax; j++)
+    sum_U0_sqr += U0[j] * U0[j];
+  for (int i = 0; i < n; i++) {                                    /* mtm.c:130-136 */
+    hn[i] = 0.0;
+    for (int j = 0; j <= kmax; j++)
+      hn[i] += U0[j] * tapers[(size_t)j * n + i];
+    hn[i] /= sum_U0_sqr;
+  }
+  *sum_U0_sqr_out = sum_U0_sqr;
+}
+
+void go_mtm_ftest_frame(go_fft_state *st, const double *tapers, const double *sig, int kmax,
+                        const double *U0, const float *hn, float sum_U0_sqr, int mu_live,
+                        float *hop, int first_buffer, float *psd_buf, float *ftest)
+{
+  const int n_fft = st->n, k = kmax;
+  double tmpr, tmpi, num_ftest;
+  float *mu = (float *)calloc((size_t)n_fft, sizeof(float));       /* mtm.c:108 */
+  float *psdbuftmp = (float *)malloc(((size_t)n_fft / 2 + 1) * sizeof(float));
+  float *outbuf = st->inbuf_fft;                                   /* mtm.c:106 */
+
+  go_prepare(st, hop, first_buffer);                               /* mtm.c:162 */
+  for (int i = 0; i < n_fft; i++)                                  /* mtm.c:165-168 */
+    st->inbuf_fft[i] = st->inbuf_audio[i] * hn[i];
+  go_rfft_halfcomplex(st->inbuf_fft, (size_t)n_fft);               /* mtm.c:173 */
+  if (mu_live)
+    memcpy(mu, st->inbuf_fft, (size_t)n_fft * sizeof(float));      /* mtm.c:171 (FFTW build) */
+
+  for (int i = 0; i < (n_fft + 1) / 2; i++) {                      /* mtm.c:179-186 */
+    psd_buf[i] = 0.0;
+    ftest[i] = 0.0;
+  }
+  if (n_fft % 2 == 0) {
+    psd_buf[n_fft / 2] = 0.0;
+    ftest[n_fft / 2] = 0.0;
+  }
+  for (int j = 0; j <= k; j++) {                                   /* mtm.c:189-220 */
+    for (int i = 0; i < n_fft; i++)
+      st->inbuf_fft[i] = tapers[(size_t)j * n_fft + i] * st->inbuf_audio[i];
+    go_rfft_halfcomplex(st->inbuf_fft, (size_t)n_fft);
+    tmpr = outbuf[0] - mu[0] * U0[j];
+    ftest[0] += tmpr * tmpr;
+    for (int i = 1; i < (n_fft + 1) / 2; i++) {
+      tmpr = outbuf[i] - mu[i] * U0[j];
+      tmpi = outbuf[n_fft - i] - mu[n_fft - i] * U0[j];
+      ftest[i] += tmpr * tmpr + tmpi * tmpi;
+    }
+    go_psd(st->inbuf_fft, n_fft, psdbuftmp);
+    for (int i = 0; i < (n_fft + 1) / 2; i++)
+      psd_buf[i] += psdbuftmp[i] / (1.0 + sig[j]);
+    if (n_fft % 2 == 0)
+      psd_buf[n_fft / 2] += psdbuftmp[n_fft / 2] / (1.0 + sig[j]);
+  }
+  num_ftest = k * (mu[0] * mu[0]) * sum_U0_sqr;                    /* mtm.c:222-233 */
+  ftest[0] = num_ftest / ftest[0];
+  for (int i = 1; i < (n_fft + 1) / 2; i++) {
+    num_ftest = k * (mu[i] * mu[i] + mu[n_fft - i] * mu[n_fft - i]) * sum_U0_sqr;
+    ftest[i] = num_ftest / ftest[i];
+  }
+  if (n_fft % 2 == 0) {
+    int i = n_fft / 2;
+    num_ftest = k * (mu[i] * mu[i] + mu[n_fft - i] * mu[n_fft - i]) * sum_U0_sqr;
+    ftest[i] = num_ftest / ftest[i];
+  }
+  free(mu);
+  free(psdbuftmp);
+}
+
+/* source.c:130-148 over a whole stream, MTM mode, with the F statistic of every frame */
+void go_spectrogram_mtm_ftest(const float *stream, size_t nsamples, int n, float overlap, double nw,
+                              int kmax, int sub_mean, int history_mode, int mu_live, float *psd_out,
+                              float *ftest_out)
+{
+  go_fft_state st;
+  go_fft_state_init(&st, n, overlap, GO_WIN_RECTANGULAR, 0.0f, 0, sub_mean);
+  double *tapers = (double *)malloc((size_t)(kmax + 1) * n * sizeof(double));
+  double *sig = (double *)malloc((size_t)(kmax + 1) * sizeof(double));
+  double *U0 = (double *)malloc((size_t)(kmax + 1) * sizeof(double));
+  float *hn = (float *)malloc((size_t)n * sizeof(float));
+  float sum_U0_sqr;
+  go_dpss(n, kmax, nw, tapers, sig);
+  go_ftest_tables(n, kmax, tapers, U0, hn, &sum_U0_sqr);
+  const int h = go_hop(n, overlap);
+  const size_t frames = go_num_frames(nsamples, n, overlap);
+  const size_t nb = (size_t)n / 2 + 1;
+  float *hop = (float *)malloc((size_t)h * sizeof(float));
+  for (size_t f = 0; f < frames; f++) {
+    memcpy(hop, stream + f * h, (size_t)h * sizeof(float));
+    int first = (history_mode == 1) ? 1 : (f == 0);
+    go_mtm_ftest_frame(&st, tapers, sig, kmax, U0, hn, sum_U0_sqr, mu_live, hop, first,
+                       psd_out + f * nb, ftest_out + f * nb);
+  }
+  free(hop);
+  free(hn);
+  free(U0);
   free(tapers);
   free(sig);
   go_fft_state_free(&st);

@@ -9,10 +9,10 @@
  * order, so that on one compiler/flag set the results are bit-identical to
  * the reference objects built by oracle/Makefile into oracle/_ref/.
  *
- * Pinning status (see oracle/README.md):
- *   - go_rfft_halfcomplex, go_dpss, go_avg_*, go_bessel_i0, go_svd are checked
- *     BIT-EXACT against the reference's own fft_radix2.c, g-l_dpss.c, avg.c and
- *     util.c compiled unmodified (tests/test_oracle_vs_ref.py).
+ * Pinning status:
+ *   - go_rfft_halfcomplex, go_dpss, go_avg_*, go_bessel_i0, go_svd, go_wav_read are
+ *     checked BIT-EXACT against the reference's own fft_radix2.c, g-l_dpss.c, avg.c,
+ *     util.c and wav_fmt.c compiled unmodified (tests/test_oracle_pinning.py).
  *   - go_window, go_prepare, go_psd, go_mtm_frame, go_floor restate fft.c/mtm.c,
  *     which cannot be compiled here (glfer.h needs <gtk/gtk.h>, absent from
  *     this image); they are pinned by independent known answers (numpy rfft
@@ -165,6 +165,45 @@ void go_spectrogram_fft(const float *stream, size_t nsamples, int n,
 void go_spectrogram_mtm(const float *stream, size_t nsamples, int n,
                         float overlap, double nw, int kmax, int sub_mean,
                         int history_mode, float *psd_out);
+
+/* ---- file source: wav_fmt.c:81-121 wav_read() + the loop of source.c:118-165 ---- */
+typedef struct {
+  const unsigned char *pcm;   /* the bytes after the WAV header                             */
+  size_t nbytes, pos;
+  int bits;                   /* wavhd.bit_p_spl: 8 or 16                                   */
+  int out_len;                /* samples per block = the hop (open_wav_file's n)            */
+  float *buff;                /* the reader's float block, handed to the estimator as is    */
+} go_wav;
+void go_wav_open(go_wav *w, const unsigned char *pcm, size_t nbytes, int bits, int out_len);
+int go_wav_read(go_wav *w, float **buf_out);       /* returns *n_out: 0 at end of data, else 1 */
+void go_wav_close(go_wav *w);
+/* mode 0 = FFT (fft_do + fft_psd), 1 = MTM (mtm_do); returns the rows written */
+size_t go_wav_spectrogram(const unsigned char *pcm, size_t nbytes, int bits, int mode, int n,
+                          float overlap, int window_type, float a, int limiter, int sub_mean,
+                          int history_mode, double nw, int kmax, size_t max_frames, float *psd_out);
+
+/* ---- LMP estimator: lmp.c:59-99 lmp_init, lmp.c:101-181 lmp_do ---- */
+typedef struct {
+  go_fft_state fft;
+  int nl;              /* params->avg = opt.lmp_av (source.c:397)                           */
+  int j_l;             /* ring slot the next periodogram goes to (lmp.c:104 static)         */
+  float *ring;         /* [nl][n] psdbufl                                                   */
+  double *my, *sy;     /* [n] per-bin mean and variance over the ring                       */
+} go_lmp_state;
+void go_lmp_init(go_lmp_state *st, int n, float overlap, int nl, int sub_mean);
+void go_lmp_free(go_lmp_state *st);
+void go_lmp_frame(go_lmp_state *st, float *hop, int first_buffer, float *psd_buf);
+void go_spectrogram_lmp(const float *stream, size_t nsamples, int n, float overlap, int nl,
+                        int sub_mean, int history_mode, float *out);
+
+/* ---- MTM harmonic F-test: mtm.c:76-83,124-136 (tables), mtm.c:165-174,203-233 (per frame) ---- */
+void go_ftest_tables(int n, int kmax, const double *tapers, double *U0, float *hn, float *sum_U0_sqr_out);
+void go_mtm_ftest_frame(go_fft_state *st, const double *tapers, const double *sig, int kmax,
+                        const double *U0, const float *hn, float sum_U0_sqr, int mu_live,
+                        float *hop, int first_buffer, float *psd_buf, float *ftest);
+void go_spectrogram_mtm_ftest(const float *stream, size_t nsamples, int n, float overlap, double nw,
+                              int kmax, int sub_mean, int history_mode, int mu_live, float *psd_out,
+                              float *ftest_out);
 
 #ifdef __cplusplus
 }

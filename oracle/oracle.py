@@ -56,6 +56,14 @@ def _load():
     lib.go_fft_state_free.argtypes = [C.c_void_p]
     lib.go_svd.restype = C.c_int
     lib.go_svd.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p]
+    lib.go_wav_spectrogram.restype = C.c_size_t
+    lib.go_wav_spectrogram.argtypes = [np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.c_size_t, C.c_int,
+                                       C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                       C.c_double, C.c_int, C.c_size_t, _f32p]
+    lib.go_spectrogram_lmp.argtypes = [_f32p, C.c_size_t, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _f32p]
+    lib.go_spectrogram_mtm_ftest.argtypes = [_f32p, C.c_size_t, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, _f32p, _f32p]
+    lib.go_ftest_tables.argtypes = [C.c_int, C.c_int, _f64p, _f64p, _f32p, C.POINTER(C.c_float)]
     lib.go_pcm_u8_to_float.argtypes = [np.ctypeslib.ndpointer(np.uint8), C.c_size_t, _f32p]
     lib.go_pcm_s16_to_float.argtypes = [np.ctypeslib.ndpointer(np.int16), C.c_size_t, _f32p]
     return lib
@@ -156,6 +164,80 @@ def spectrogram_hparma(stream, n, overlap, t, p_e, sub_mean=0, history_mode=0):
     out = np.empty((frames, n // 2 + 1), np.float32)
     _lib.go_spectrogram_hparma(stream, stream.size, n, C.c_float(overlap), int(t), int(p_e),
                                int(sub_mean), int(history_mode), out)
+    return out
+
+
+def spectrogram_lmp(stream, n, overlap, nl, sub_mean=0, history_mode=0):
+    """lmp_do (lmp.c:101-181) once per hop: the detection statistic of every frame."""
+    stream = np.ascontiguousarray(stream, np.float32)
+    frames = num_frames(stream.size, n, overlap)
+    out = np.empty((frames, n // 2 + 1), np.float32)
+    _lib.go_spectrogram_lmp(stream, stream.size, n, C.c_float(overlap), int(nl), int(sub_mean),
+                            int(history_mode), out)
+    return out
+
+
+def spectrogram_mtm_ftest(stream, n, overlap, nw, kmax, sub_mean=0, history_mode=0, mu_live=1):
+    """mtm_do with its harmonic F-test side computation (mtm.c:165-174, 203-233): (psd, ftest).
+    mu_live=0 restates the reference build without FFTW, where `mu` is never written."""
+    stream = np.ascontiguousarray(stream, np.float32)
+    frames = num_frames(stream.size, n, overlap)
+    psd = np.empty((frames, n // 2 + 1), np.float32)
+    ft = np.empty((frames, n // 2 + 1), np.float32)
+    _lib.go_spectrogram_mtm_ftest(stream, stream.size, n, C.c_float(overlap), float(nw), int(kmax),
+                                  int(sub_mean), int(history_mode), int(mu_live), psd, ft)
+    return psd, ft
+
+
+def ftest_tables(n, kmax, tapers):
+    """mtm.c:76-83, 124-136: (U0[kmax+1] float64, hn[n] float32, sum_U0_sqr float32)."""
+    U0 = np.empty(kmax + 1, np.float64)
+    hn = np.empty(n, np.float32)
+    s = C.c_float(0.0)
+    _lib.go_ftest_tables(n, kmax, np.ascontiguousarray(tapers, np.float64), U0, hn, C.byref(s))
+    return U0, hn, np.float32(s.value)
+
+
+def wav_spectrogram(pcm, bits, mode, n, overlap, window_type=0, a=0.0, limiter=0, sub_mean=0,
+                    history_mode=0, nw=0.0, kmax=0, max_frames=None):
+    """The file source: wav_read() blocks (wav_fmt.c:81-121, incl. the trailing partial block over
+    the stale tail of the previous one) through fft_do+fft_psd (mode "fft") or mtm_do ("mtm")."""
+    raw = np.ascontiguousarray(pcm).view(np.uint8).reshape(-1)
+    h = hop(n, overlap)
+    bsz = h * bits // 8
+    frames = -(-raw.size // bsz)
+    if max_frames is not None:
+        frames = min(frames, max_frames)
+    out = np.empty((frames, n // 2 + 1), np.float32)
+    got = _lib.go_wav_spectrogram(raw, raw.size, bits, 1 if mode == "mtm" else 0, n, C.c_float(overlap),
+                                  int(window_type), C.c_float(a), int(limiter), int(sub_mean),
+                                  int(history_mode), float(nw), int(kmax), frames, out)
+    assert got == frames, (got, frames)
+    return out
+
+
+class _GoWav(C.Structure):
+    _fields_ = [("pcm", C.c_void_p), ("nbytes", C.c_size_t), ("pos", C.c_size_t), ("bits", C.c_int),
+                ("out_len", C.c_int), ("buff", C.POINTER(C.c_float))]
+
+
+def wav_blocks(pcm, bits, hop_len, mutate=None):
+    """Every block wav_read() hands out for these PCM bytes (copies).  mutate(block) stands for
+    what the estimator does to the reader's buffer between reads (mean removal, fft.c:93-95)."""
+    raw = np.ascontiguousarray(pcm).view(np.uint8).reshape(-1)
+    _lib.go_wav_open.argtypes = [C.POINTER(_GoWav), C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    _lib.go_wav_read.argtypes = [C.POINTER(_GoWav), C.POINTER(C.POINTER(C.c_float))]
+    _lib.go_wav_close.argtypes = [C.POINTER(_GoWav)]
+    w = _GoWav()
+    _lib.go_wav_open(C.byref(w), raw.ctypes.data, raw.size, bits, hop_len)
+    out = []
+    buf = C.POINTER(C.c_float)()
+    while _lib.go_wav_read(C.byref(w), C.byref(buf)):
+        blk = np.ctypeslib.as_array(buf, shape=(hop_len,))
+        out.append(blk.copy())
+        if mutate is not None:
+            mutate(blk)
+    _lib.go_wav_close(C.byref(w))
     return out
 
 
@@ -338,7 +420,31 @@ class Ref:
                                             C.c_int, C.c_int, C.POINTER(C.c_int)]
         r.update_avg_sumavg.argtypes = [C.POINTER(_RefAvg), C.c_int, _f32p, C.c_int, C.c_int,
                                         C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        if hasattr(r, "wav_read"):               # wav_fmt.c, when the prebuilt _ref/ has it
+            r.open_wav_file.restype = C.c_int
+            r.open_wav_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+            r.wav_read.argtypes = [C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
+            r.close_wav_file.argtypes = []
         self.r = r
+
+    def wav_blocks(self, path, hop_len, mutate=None):
+        """open_wav_file + wav_read until n == 0 (wav_fmt.c:45-121, source.c:118-124): copies of
+        every block handed out, and the sample rate the header parse reported."""
+        speed = C.c_int(0)
+        self.r.open_wav_file(os.fsencode(path), hop_len, C.byref(speed))
+        out = []
+        buf = C.POINTER(C.c_float)()
+        n = C.c_int(0)
+        while True:
+            self.r.wav_read(C.byref(buf), C.byref(n))
+            if n.value == 0:
+                break
+            blk = np.ctypeslib.as_array(buf, shape=(hop_len,))
+            out.append(blk.copy())
+            if mutate is not None:
+                mutate(blk)
+        self.r.close_wav_file()
+        return out, speed.value
 
     def rfft_halfcomplex(self, x):
         d = np.ascontiguousarray(x, np.float32).copy()

@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz -- golden input/output vectors for the hot path.
 
 The reference ships no fixtures.  These vectors come from the CPU oracle
-(oracle/glfer_oracle.c), run in the build container right after tests/test_oracle_vs_ref.py
+(oracle/glfer_oracle.c), run in the build container right after tests/test_oracle_pinning.py
 has shown it bit-identical to the reference's own fft_radix2.c / g-l_dpss.c / avg.c / util.c
 objects (oracle/_ref/).  Each file holds data only: parameters, the input samples and the
 expected outputs.
@@ -109,7 +109,36 @@ def main():
     disp["avg_log_auto_otd_rgb"], disp["avg_log_auto_otd_lev"], disp["avg_log_auto_otd_levels"] = rgb, lev, levels
     save("display_fft1024", psd=psd[:, :513], stats=fl.astype(np.float32), avg=avg_out["plain_max0_avg"],
          palettes=np.array([O.palette(i) for i in range(8)]), **disp)
+    round2()
+
+
+def round2():
+    """Round-2 rows: LMP (l_*), MTM harmonic F-test (f_*), WAV files with a trailing partial block (w_*)."""
+    x = synth(14 * 512, fs=8000.0, seed=7)
+    save("l_lmp1024_av4_ovl50", n=1024, overlap=np.float32(0.5), nl=4, sub_mean=0, x=x,
+         out=O.spectrogram_lmp(x, 1024, 0.5, 4))
+    x = synth(9 * 2048, fs=48000.0, seed=8)
+    save("l_lmp2048_av3_submean", n=2048, overlap=np.float32(0.0), nl=3, sub_mean=1, x=x,
+         out=O.spectrogram_lmp(x, 2048, 0.0, 3, sub_mean=1))
+    for live in (1, 0):
+        x = synth(5 * 1024, fs=8000.0, seed=9)
+        psd, ft = O.spectrogram_mtm_ftest(x, 1024, 0.0, 2.5, 4, mu_live=live)
+        save("f_mtm1024_nw25_k4_mu%d" % live, n=1024, overlap=np.float32(0.0), nw=2.5, kmax=4, mu_live=live, x=x,
+             psd=psd, ftest=ft)
+    x = synth(4 * 1024, fs=48000.0, seed=10)
+    psd, ft = O.spectrogram_mtm_ftest(x, 4096, 0.75, 4.0, 7, mu_live=1)
+    save("f_mtm4096_nw4_k7_ovl75_mu1", n=4096, overlap=np.float32(0.75), nw=4.0, kmax=7, mu_live=1, x=x, psd=psd, ftest=ft)
+    x = synth(9 * 512 + 200, fs=8000.0, seed=11)
+    pcm = np.round(x * 30000).astype(np.int16)
+    save("w_s16_fft1024_kaiser_ovl50_submean_tail200", bits=16, mode="fft", n=1024, overlap=np.float32(0.5), window=7,
+         sub_mean=1, nw=0.0, kmax=0, pcm=pcm, psd=O.wav_spectrogram(pcm, 16, "fft", 1024, 0.5, 7, sub_mean=1))
+    pcm8 = np.clip(np.round(x[:5 * 1024 + 333] * 120 + 128), 0, 255).astype(np.uint8)
+    save("w_u8_mtm1024_nw25_k4_tail333", bits=8, mode="mtm", n=1024, overlap=np.float32(0.0), window=5, sub_mean=0,
+         nw=2.5, kmax=4, pcm=pcm8, psd=O.wav_spectrogram(pcm8, 8, "mtm", 1024, 0.0, nw=2.5, kmax=4))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        round2()
+    else:
+        main()

@@ -35,3 +35,36 @@ def test_committed_bench_line_has_the_contract_keys(name):
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     # whole-job throughput: frames of all steps / wall time
     assert abs(line["value"] - line["config"]["frames_per_gpu_per_step"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as typed (no torch.distributed.run around it): the parent starts
+    one child per rank before touching any GPU, rank 0's line comes back on stdout, exit code 0.
+    --dry-run keeps the launch path (rendezvous on 127.0.0.1, barrier, max over ranks) and skips
+    the GPU work, so this runs on the CPU with gloo."""
+    r = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                                   # ONE JSON line, nothing else on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["max_over_ranks"] == 2.0 and line["steps"] == 3 and line["warmup"] == 1
+
+
+def test_bench_under_a_launcher_is_one_rank():
+    """Under torch.distributed.run the environment carries WORLD_SIZE: no self-launch, and a
+    --gpus that disagrees with it is refused instead of asserting half-way."""
+    r = _run_bench("--gpus", "1", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 0 and json.loads(r.stdout.strip())["n_gpus"] == 1
+    r = _run_bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a gpurun_out/prof[_<workload>]/ tree (rocprofv3 --kernel-trace --stats and --pmc
 passes over bench.py) into the small summaries kept under profiles/.
-usage: summarize_prof.py <round-tag> [mtm|fft]"""
+usage: summarize_prof.py <round-tag> [mtm|fft|mtm16k]"""
 import collections
 import csv
 import glob
@@ -46,7 +46,11 @@ for r in csv.DictReader(open(one("sq/*/*_counter_collection.csv"))):
     if r["Kernel_Name"] == KNAME:
         sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
 sq = {n: sum(v) / len(v) for n, v in sq.items()}
-frames, hop, bins = (262144, 4096, 2049) if workload == "mtm" else (1048576, 1024, 2049)
+frames, hop, bins, wname = {
+    "mtm": (262144, 4096, 2049, "C3 MTM N=4096 NW=2.5 mtm_k=4 overlap 0, %d frames per launch"),
+    "fft": (1048576, 1024, 2049, "C2 periodogram Hanning N=4096 overlap 75 %%, %d frames per launch"),
+    "mtm16k": (65536, 16384, 8193, "C4 MTM N=16384 NW=4.5 mtm_k=8 (9 tapers) overlap 0, %d frames per launch"),
+}[workload]
 alg = frames * (4 * hop + 4 * bins)
 # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports exactly half
 # the bytes of a coalesced streaming read -> doubled here; WRITE_SIZE reads the bytes exactly.
@@ -54,9 +58,8 @@ traffic = (2 * fetch + write) * 1024
 summary = {
     "command": "rocprofv3 --kernel-trace {--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*} "
                "-- python3 bench.py --steps K --warmup 1 --no-cpu-baseline%s   (separate passes)"
-               % ("" if workload == "mtm" else " --workload " + workload),
-    "workload": ("C3 MTM N=4096 NW=2.5 mtm_k=4 overlap 0, %d frames per launch" if workload == "mtm" else
-                 "C2 periodogram Hanning N=4096 overlap 75 %%, %d frames per launch") % frames,
+               % (" --workload " + workload),
+    "workload": wname % frames,
     "kernel": k["Name"], "kernel_avg_ns_profiled": float(k["AverageNs"]), "kernel_calls": int(k["Calls"]),
     "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
     "hbm_traffic_bytes_per_launch_corrected": traffic,
