@@ -17,7 +17,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libglfer_hip.so")
 
-MODE_FFT, MODE_MTM, MODE_HPARMA = 0, 1, 2
+MODE_FFT, MODE_MTM, MODE_HPARMA, MODE_LMP = 0, 1, 2, 3
+WAV_PARTIAL_TAIL = 1
 WINDOWS = {"hanning": 0, "blackman": 1, "gaussian": 2, "welch": 3,
            "bartlett": 4, "rectangular": 5, "hamming": 6, "kaiser": 7}
 SAMPLES_F32, SAMPLES_S16, SAMPLES_U8 = 0, 1, 2
@@ -33,6 +34,9 @@ EXPORTS = [
     "glfer_hip_spectrogram_wav", "glfer_hip_submean_device",
     "glfer_hip_floor_device",
     "glfer_hip_avg_device", "glfer_hip_palette", "glfer_hip_display_device", "glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version",
+    "glfer_hip_frame_range", "glfer_hip_prepare_device", "glfer_hip_mtm_ftest_device", "glfer_hip_host_alloc",
+    "glfer_hip_host_free", "glfer_hip_spectrogram_host_multi", "glfer_hip_spectrogram_wav_ex",
+    "glfer_hip_avg_cum_device", "glfer_hip_waterfall_host",
 ]
 
 
@@ -46,7 +50,7 @@ class Config(C.Structure):
                 ("window_type", C.c_int), ("limiter_a", C.c_float), ("enable_limiter", C.c_int),
                 ("sub_mean", C.c_int), ("history_mode", C.c_int), ("mtm_w", C.c_float),
                 ("mtm_k", C.c_int), ("sample_format", C.c_int), ("device", C.c_int),
-                ("hparma_t", C.c_int), ("hparma_p_e", C.c_int)]
+                ("hparma_t", C.c_int), ("hparma_p_e", C.c_int), ("lmp_av", C.c_int)]
 
 
 class Display(C.Structure):
@@ -70,7 +74,8 @@ PALETTES = {"hsv": 0, "thresh": 1, "cool": 2, "hot": 3, "bw": 4, "bone": 5, "cop
 class WavInfo(C.Structure):
     """glfer_wav_info (include/glfer_hip.h): the header fields of wav_fmt.h:34-52 that are used."""
     _fields_ = [("format", C.c_int), ("channels", C.c_int), ("sample_rate", C.c_int),
-                ("bits_per_sample", C.c_int), ("data_offset", C.c_size_t), ("nsamples", C.c_size_t)]
+                ("bits_per_sample", C.c_int), ("data_offset", C.c_size_t), ("nsamples", C.c_size_t),
+                ("data_bytes", C.c_size_t)]
 
 
 _lib = None
@@ -115,6 +120,18 @@ def lib():
     L.glfer_hip_display_device.argtypes = [C.POINTER(Display), vp, vp, vp, sz, C.c_int, vp, vp, vp, vp]
     L.glfer_hip_avg_device.argtypes = [C.c_int, vp, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, vp, vp, vp]
+    L.glfer_hip_frame_range.argtypes = [sz, C.c_uint, C.c_uint, C.POINTER(sz), C.POINTER(sz)]
+    L.glfer_hip_frame_range.restype = None
+    L.glfer_hip_prepare_device.argtypes = [vp, vp, sz, sz, sz, vp, vp]
+    L.glfer_hip_mtm_ftest_device.argtypes = [vp, vp, sz, sz, sz, vp, C.c_int, vp]
+    L.glfer_hip_host_alloc.argtypes = [sz]
+    L.glfer_hip_host_alloc.restype = vp
+    L.glfer_hip_host_free.argtypes = [vp]
+    L.glfer_hip_host_free.restype = None
+    L.glfer_hip_spectrogram_host_multi.argtypes = [C.POINTER(Config), C.c_uint, vp, sz, vp, C.POINTER(sz)]
+    L.glfer_hip_spectrogram_wav_ex.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz), sz, C.c_uint]
+    L.glfer_hip_avg_cum_device.argtypes = [vp, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.glfer_hip_waterfall_host.argtypes = [vp, C.POINTER(Display), vp, sz, vp, vp, C.POINTER(sz)]
     for f in ("glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version"):
         getattr(L, f).restype = C.c_char_p
     L.glfer_hip_strerror.argtypes = [C.c_int]
@@ -185,6 +202,20 @@ class HparmaParams:
         self.w, self.kmax = 0.0, 0
 
 
+class LmpParams:
+    """What source.c:390-398 sets before lmp_init(): fft.{n,overlap}, avg = opt.lmp_av (window
+    rectangular; a and the limiter act on a buffer lmp_do overwrites, lmp.c:114-116)."""
+
+    def __init__(self, n=1024, overlap=0.0, avg=4, sub_mean=0, history_mode=HISTORY_ZERO_FIRST,
+                 sample_format=SAMPLES_F32):
+        self.mode = MODE_LMP
+        self.n, self.overlap, self.avg = n, overlap, avg
+        self.window_type = WINDOWS["rectangular"]       # source.c:395
+        self.a, self.limiter, self.sub_mean = 0.0, 0, sub_mean
+        self.history_mode, self.sample_format = history_mode, sample_format
+        self.w, self.kmax = 0.0, 0
+
+
 _TORCH_DTYPES = None
 
 
@@ -193,13 +224,18 @@ def _torch():
     return torch
 
 
+def make_config(params, device=0):
+    return Config(params.mode, params.n, params.overlap, params.window_type, params.a,
+                  params.limiter, params.sub_mean, params.history_mode, params.w, params.kmax,
+                  params.sample_format, device, getattr(params, "t", 0), getattr(params, "p_e", 0),
+                  getattr(params, "avg", 0))
+
+
 class Spectrogram:
     """A plan (fft_init / mtm_init) bound to one GPU, plus the batched hot path."""
 
     def __init__(self, params, device=0):
-        cfg = Config(params.mode, params.n, params.overlap, params.window_type, params.a,
-                     params.limiter, params.sub_mean, params.history_mode, params.w, params.kmax,
-                     params.sample_format, device, getattr(params, "t", 0), getattr(params, "p_e", 0))
+        cfg = make_config(params, device)
         self._h = C.c_void_p()
         _check(lib().glfer_hip_plan_create(C.byref(cfg), C.byref(self._h)), "glfer_hip_plan_create")
         self.params, self.device = params, device
@@ -259,17 +295,61 @@ class Spectrogram:
                "glfer_hip_spectrogram_device")
         return out
 
-    def run_wav(self, path, chunk_frames=0, max_frames=None):
-        """Whole WAV file -> numpy psd [frames][bins], streamed through pinned buffers."""
+    def run_wav(self, path, chunk_frames=0, max_frames=None, partial_tail=False):
+        """Whole WAV file -> numpy psd [frames][bins], streamed through pinned buffers.
+        partial_tail: also the reference's extra frame for a trailing partial block
+        (wav_fmt.c:102-119; GLFER_WAV_PARTIAL_TAIL)."""
         info = wav_probe(path)
-        frames = info.nsamples // self.hop
+        frames = info.nsamples // self.hop + (1 if partial_tail else 0)
         if max_frames is not None:
             frames = min(frames, max_frames)
         out = np.empty((frames, self.bins), np.float32)
         nf = C.c_size_t(0)
-        _check(lib().glfer_hip_spectrogram_wav(self._h, os.fsencode(path), out.ctypes.data, frames,
-                                               C.byref(nf), chunk_frames), "glfer_hip_spectrogram_wav")
+        _check(lib().glfer_hip_spectrogram_wav_ex(self._h, os.fsencode(path), out.ctypes.data, frames,
+                                                  C.byref(nf), chunk_frames, WAV_PARTIAL_TAIL if partial_tail else 0),
+               "glfer_hip_spectrogram_wav_ex")
         return out[:nf.value]
+
+    def ftest(self, stream, first_frame=0, nframes=None, mu_live=True):
+        """The harmonic F statistic of mtm_do (mtm.c:165-174, 203-233) for every frame: a float
+        tensor [nframes][bins].  mu_live=False restates the reference build without FFTW."""
+        torch = _torch()
+        assert stream.is_cuda and stream.dim() == 1 and stream.is_contiguous()
+        assert stream.dtype == self._sample_dtype()
+        if nframes is None:
+            nframes = self.num_frames(stream.numel()) - first_frame
+        out = torch.empty((nframes, self.bins), dtype=torch.float32, device=stream.device)
+        st = C.c_void_p(torch.cuda.current_stream(stream.device).cuda_stream)
+        _check(lib().glfer_hip_mtm_ftest_device(self._h, stream.data_ptr(), stream.numel(), first_frame, nframes,
+                                                out.data_ptr(), 1 if mu_live else 0, st), "glfer_hip_mtm_ftest_device")
+        return out
+
+    def prepare(self, stream, first_frame=0, nframes=None):
+        """prepare_audio's inbuf_fft (fft.c:66-165) for every frame: float tensor [nframes][n]."""
+        torch = _torch()
+        assert stream.is_cuda and stream.dim() == 1 and stream.is_contiguous()
+        assert stream.dtype == self._sample_dtype()
+        if nframes is None:
+            nframes = self.num_frames(stream.numel()) - first_frame
+        out = torch.empty((nframes, self.n), dtype=torch.float32, device=stream.device)
+        st = C.c_void_p(torch.cuda.current_stream(stream.device).cuda_stream)
+        _check(lib().glfer_hip_prepare_device(self._h, stream.data_ptr(), stream.numel(), first_frame, nframes,
+                                              out.data_ptr(), st), "glfer_hip_prepare_device")
+        return out
+
+    def waterfall_host(self, samples, disp, want_lev=True):
+        """Host samples -> (rgb uint8 [frames][bins][3], lev int16 [frames][bins] | None) through the
+        chunked ring, mapping done on the device (glfer_hip_waterfall_host)."""
+        want = {SAMPLES_F32: np.float32, SAMPLES_S16: np.int16, SAMPLES_U8: np.uint8}[self.params.sample_format]
+        samples = np.ascontiguousarray(samples, want)
+        frames = self.num_frames(samples.size)
+        rgb = np.empty((frames, self.bins, 3), np.uint8)
+        lev = np.empty((frames, self.bins), np.int16) if want_lev else None
+        nf = C.c_size_t(0)
+        _check(lib().glfer_hip_waterfall_host(self._h, C.byref(disp), samples.ctypes.data, samples.size, rgb.ctypes.data,
+                                              lev.ctypes.data if want_lev else None, C.byref(nf)), "glfer_hip_waterfall_host")
+        assert nf.value == frames
+        return rgb, lev
 
     def run_host(self, samples):
         """samples: numpy array on the host; returns numpy psd [frames][bins]."""
@@ -284,6 +364,50 @@ class Spectrogram:
                "glfer_hip_spectrogram_host")
         assert nf.value == frames
         return out
+
+
+def frame_range(total_frames, rank, world):
+    """glfer_hip_frame_range: (first, count) of a rank's contiguous frame block."""
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    lib().glfer_hip_frame_range(total_frames, rank, world, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def spectrogram_host_multi(params, samples, devices, out=None):
+    """glfer_hip_spectrogram_host_multi: one stream on the host, its frames dealt out over
+    `devices` (a list of HIP device ordinals), numpy psd [frames][bins] back."""
+    want = {SAMPLES_F32: np.float32, SAMPLES_S16: np.int16, SAMPLES_U8: np.uint8}[params.sample_format]
+    samples = np.ascontiguousarray(samples, want)
+    cfg = make_config(params, 0)
+    hop = int(params.n * (1.0 - float(np.float32(params.overlap))))
+    frames = samples.size // hop
+    if out is None:
+        out = np.empty((frames, params.n // 2 + 1), np.float32)
+    mask = 0
+    for d in devices:
+        mask |= 1 << d
+    nf = C.c_size_t(0)
+    _check(lib().glfer_hip_spectrogram_host_multi(C.byref(cfg), mask, samples.ctypes.data, samples.size,
+                                                  out.ctypes.data, C.byref(nf)), "glfer_hip_spectrogram_host_multi")
+    return out[:nf.value]
+
+
+class PinnedArray:
+    """A numpy view of pinned host memory from glfer_hip_host_alloc (rows land in it by DMA)."""
+
+    def __init__(self, shape, dtype):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib().glfer_hip_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise GlferHipError("glfer_hip_host_alloc(%d) failed" % self.nbytes)
+        buf = (C.c_ubyte * self.nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().glfer_hip_host_free(self.ptr)
+            self.ptr = None
 
 
 def wav_probe(path):
@@ -336,6 +460,19 @@ def display(disp, src, stats, want_lev=True, want_levels=True):
         C.c_void_p(rgb.data_ptr()), C.c_void_p(lev.data_ptr()) if want_lev else None,
         C.c_void_p(levels.data_ptr()) if want_levels else None, st), "glfer_hip_display_device")
     return rgb, lev, levels
+
+
+def avg_cum(psd, depth, minbin, maxbin, n_out=None):
+    """avgdata->cum after each frame (avg.c:114-127): float64 [frames][n_out], zeros out of band."""
+    torch = _torch()
+    assert psd.is_cuda and psd.dtype == torch.float32 and psd.is_contiguous() and psd.dim() == 2
+    frames, bins = psd.shape
+    n_out = bins if n_out is None else n_out
+    cum = torch.zeros((frames, n_out), dtype=torch.float64, device=psd.device)
+    st = C.c_void_p(torch.cuda.current_stream(psd.device).cuda_stream)
+    _check(lib().glfer_hip_avg_cum_device(psd.data_ptr(), frames, bins, n_out, depth, minbin, maxbin, cum.data_ptr(), st),
+           "glfer_hip_avg_cum_device")
+    return cum
 
 
 def update_avg(mode, psd, depth, minbin, maxbin, max0=0, n_out=None):

@@ -605,6 +605,12 @@ extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int b
   else if (bins <= 64 * 129) hipLaunchKernelGGL(floor_wave_kernel<129>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
   else {                                         // longer rows than any block size gives: one workgroup per row, the row in LDS
     const size_t shmem = (size_t)bins * sizeof(float) + 256 * sizeof(uint32_t);
+    static size_t allowed = 0;               // raised once per process and size class, not per launch
+    if (shmem > allowed) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(floor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return e;
+      allowed = shmem;
+    }
     hipLaunchKernelGGL(floor_kernel, dim3((unsigned)nframes), dim3(256), shmem, st, psd, bins, m, stats);
   }
   return hipGetLastError();
@@ -646,5 +652,17 @@ extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframe
                        mode, max0, avg, ret);
   }
 #undef GLFER_AVG_FUSED
+  return hipGetLastError();
+}
+
+// avgdata->cum alone (the shims hand it back to the caller's avg_data_t)
+extern "C" hipError_t glfer_launch_avg_cum(const float *psd, size_t nframes, int bins, int n_out, int depth,
+                                           int minbin, int maxbin, double *cum, hipStream_t st) {
+  if (nframes == 0) return hipSuccess;
+  const int band = maxbin - minbin;
+  if (band < 1 || minbin < 0 || maxbin > bins || maxbin > n_out || depth < 1) return hipErrorInvalidValue;
+  const unsigned chunks = (unsigned)((nframes + AVG_CHUNK - 1) / AVG_CHUNK);
+  hipLaunchKernelGGL(avg_cum_kernel, dim3((unsigned)((band + 255) / 256), chunks), dim3(256), 0, st, psd, (long long)nframes,
+                     bins, n_out, depth, minbin, maxbin, cum);
   return hipGetLastError();
 }

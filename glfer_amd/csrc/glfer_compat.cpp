@@ -19,10 +19,14 @@
 #include <vector>
 
 extern "C" {
+// glfer's own globals (glfer.c:56-57), referenced weakly: present when this library is linked into
+// glfer (or any program that defines them), absent -- address 0 -- for a stand-alone user
+extern opt_t opt __attribute__((weak));
+extern glfer_t glfer __attribute__((weak));
 int glfer_compat_autoscale = 1;        // opt.autoscale default, glfer.c:275
 int glfer_compat_first_buffer = 1;     // glfer.first_buffer = TRUE at start-up, g_main.c:990
-__attribute__((weak)) int glfer_compat_get_autoscale(void) { return glfer_compat_autoscale; }
-__attribute__((weak)) int glfer_compat_get_first_buffer(void) { return glfer_compat_first_buffer; }
+int glfer_compat_get_autoscale(void) { return &opt ? opt.autoscale : glfer_compat_autoscale; }
+int glfer_compat_get_first_buffer(void) { return &glfer ? glfer.first_buffer : glfer_compat_first_buffer; }
 }
 
 namespace {
@@ -130,9 +134,15 @@ void fft_init(fft_params_t *p) {                                   // fft.c:168-
 }
 
 void prepare_audio(float *audio_buf, fft_params_t *p) {            // fft.c:66-165
-  // history/mean handling; the non-linearity, window and limiter are applied by the kernel,
-  // so inbuf_fft is only defined after fft_do()
+  // history / mean handling here, then RA9MB, window and limiter on the device into inbuf_fft
+  // (what lmp.c:101-120 and the scope, g_scope.c:194-197, read after this call)
+  Engine &e = engine_for(p);
   assemble(audio_buf, p);
+  if (!e.d_spec) hipck(hipMalloc((void **)&e.d_spec, (size_t)p->n * sizeof(float)), "hipMalloc prepared frame");
+  hipck(hipMemcpy(e.d_frame, p->inbuf_audio, (size_t)p->n * sizeof(float), hipMemcpyHostToDevice), "H2D frame");
+  int rc = glfer_hip_prepare_device(e.plan, e.d_frame, (size_t)p->n, 0, 1, e.d_spec, nullptr);
+  if (rc) die("prepare_audio", rc);
+  hipck(hipMemcpy(p->inbuf_fft, e.d_spec, (size_t)p->n * sizeof(float), hipMemcpyDeviceToHost), "D2H prepared frame");
 }
 
 void fft_do(float *audio_buf, fft_params_t *p) {                   // fft.c:190-200
@@ -165,15 +175,19 @@ void fft_close(fft_params_t *p) {                                  // fft.c:297-
 }
 
 void compute_floor(float *psd_buf, int n, float *sig, float *floor_pwr, float *peak, unsigned int *peak_bin) {
-  float *d_psd = nullptr, *d_st = nullptr, st[4];                  // fft.c:240-294
-  hipck(hipMalloc((void **)&d_psd, (size_t)n * sizeof(float)), "hipMalloc");
-  hipck(hipMalloc((void **)&d_st, 4 * sizeof(float)), "hipMalloc");
+  static float *d_psd = nullptr, *d_st = nullptr;                  // fft.c:240-294; one row of scratch, kept
+  static int cap = 0;
+  float st[4];
+  if (n > cap) {
+    if (d_psd) (void)hipFree(d_psd);
+    hipck(hipMalloc((void **)&d_psd, (size_t)n * sizeof(float)), "hipMalloc");
+    if (!d_st) hipck(hipMalloc((void **)&d_st, 4 * sizeof(float)), "hipMalloc");
+    cap = n;
+  }
   hipck(hipMemcpy(d_psd, psd_buf, (size_t)n * sizeof(float), hipMemcpyHostToDevice), "H2D psd");
   int rc = glfer_hip_floor_device(d_psd, 1, n, d_st, nullptr);
   if (rc) die("compute_floor", rc);
   hipck(hipMemcpy(st, d_st, sizeof st, hipMemcpyDeviceToHost), "D2H stats");
-  (void)hipFree(d_psd);
-  (void)hipFree(d_st);
   *sig = st[0];
   *floor_pwr = st[1];
   *peak = st[2];
@@ -264,6 +278,69 @@ void hparma_close(hparma_params_t *p) {                            // hparma.c:1
   p->fft.outbuf = nullptr;
 }
 
+// ---- lmp.h ------------------------------------------------------------------------------
+namespace {
+struct LmpDev {
+  float *d_hist = nullptr;      // the last frames, oldest first: 2*nl slots of n samples
+  size_t frames = 0;            // frames seen since lmp_init (the ring slot is frames % nl, lmp.c:104)
+  int held = 0;                 // frames in d_hist
+};
+std::map<const void *, LmpDev> g_lmp;
+}  // namespace
+
+void lmp_init(lmp_params_t *p) {                                   // lmp.c:59-99
+  const int n = p->fft.n;
+  p->fft.inbuf_audio = (float *)calloc(n, sizeof(float));
+  p->fft.inbuf_fft = (float *)calloc(n, sizeof(float));
+  p->fft.outbuf = p->fft.inbuf_fft;
+  p->fft.sub_mean = glfer_compat_get_autoscale();                  // lmp.c:82
+  glfer_hip_config cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.mode = GLFER_MODE_LMP;
+  cfg.n = n;
+  cfg.overlap = 0.0f;                    // frames arrive assembled: one block per call
+  cfg.lmp_av = p->avg;                                             // nl = params->avg, lmp.c:85
+  engine_open(p, cfg, false);
+  LmpDev d;
+  hipck(hipMalloc((void **)&d.d_hist, (size_t)2 * p->avg * n * sizeof(float)), "hipMalloc lmp history");
+  g_lmp[p] = d;
+}
+
+void lmp_do(float *audio_buf, float *psd_buf, float *phase_buf, lmp_params_t *p) {   // lmp.c:101-181
+  (void)phase_buf;
+  Engine &e = engine_for(p);
+  LmpDev &d = g_lmp[p];
+  const int n = p->fft.n, nl = p->avg;
+  assemble(audio_buf, &p->fft);
+  // the engine recomputes the periodograms the ring still holds from the frames themselves, so
+  // the last nl assembled frames stay on the device, in time order
+  if (d.held == 2 * nl) {
+    hipck(hipMemcpy(d.d_hist, d.d_hist + (size_t)(nl + 1) * n, (size_t)(nl - 1) * n * sizeof(float), hipMemcpyDeviceToDevice),
+          "slide frames");
+    d.held = nl - 1;
+  }
+  hipck(hipMemcpy(d.d_hist + (size_t)d.held * n, p->fft.inbuf_audio, (size_t)n * sizeof(float), hipMemcpyHostToDevice), "H2D frame");
+  d.held++;
+  // frame index d.frames of a stream whose sample 0 sits (d.frames + 1 - held) frames before d_hist
+  const float *vbase = d.d_hist - ((ptrdiff_t)d.frames + 1 - d.held) * n;
+  int rc = glfer_hip_spectrogram_device(e.plan, vbase, (d.frames + 1) * (size_t)n, d.frames, 1, e.d_psd, nullptr);
+  if (rc) die("lmp_do", rc);
+  hipck(hipMemcpy(psd_buf, e.d_psd, e.psd.size() * sizeof(float), hipMemcpyDeviceToHost), "D2H psd");
+  d.frames++;
+}
+
+void lmp_close(lmp_params_t *p) {                                  // lmp.c:184-194
+  auto it = g_lmp.find(p);
+  if (it != g_lmp.end()) {
+    (void)hipFree(it->second.d_hist);
+    g_lmp.erase(it);
+  }
+  engine_close(p);
+  free(p->fft.inbuf_audio); p->fft.inbuf_audio = nullptr;
+  free(p->fft.inbuf_fft); p->fft.inbuf_fft = nullptr;
+  p->fft.outbuf = nullptr;
+}
+
 // ---- avg.h ------------------------------------------------------------------------------
 namespace {
 struct AvgDev {
@@ -282,7 +359,10 @@ void alloc_avg(avg_data_t *a, int width, int depth) {              // avg.c:38-6
   a->effdepth = 0;
   a->avg = (double *)calloc(width, sizeof(double));
   a->cum = (double *)calloc(width, sizeof(double));
-  a->avgarray = nullptr;        // the shift registers live on the device
+  // avgarray[bin][0..depth-1]: the last `depth` values of the bin, oldest first (avg.c:47-52); kept
+  // in step below by plain data movement -- the sums themselves come from the device
+  a->avgarray = (double **)calloc(width, sizeof(double *));
+  for (int i = 0; i < width; i++) a->avgarray[i] = (double *)calloc(depth, sizeof(double));
   AvgDev d;
   hipck(hipMalloc((void **)&d.d_rows, (size_t)2 * (depth + 1) * width * sizeof(float)), "hipMalloc avg rows");
   hipck(hipMemset(d.d_rows, 0, (size_t)2 * (depth + 1) * width * sizeof(float)), "hipMemset avg rows");
@@ -299,7 +379,16 @@ void delete_avg(avg_data_t *a) {                                   // avg.c:62-7
     (void)hipFree(it->second.d_ret);
     g_avg.erase(it);
   }
-  if (a->avgwidth) { free(a->avg); free(a->cum); }
+  if (a->avgwidth) {
+    free(a->avg);
+    free(a->cum);
+    if (a->avgarray) {
+      for (int i = 0; i < a->avgwidth; i++) free(a->avgarray[i]);
+      free(a->avgarray);
+    }
+  }
+  a->avg = a->cum = nullptr;
+  a->avgarray = nullptr;
   a->avgwidth = a->avgdepth = a->effdepth = 0;
 }
 
@@ -329,6 +418,16 @@ static double avg_step(int mode, avg_data_t *a, int N, float *psd, int max0, int
   if (rc) die("update_avg", rc);
   double ret[4];
   hipck(hipMemcpy(a->avg, d.d_avg + (size_t)(nrows - 1) * width, (size_t)N * sizeof(double), hipMemcpyDeviceToHost), "D2H avg");
+  // avgdata->cum: the sliding sums of the band (avg.c:114-127), from the device as well (d_avg is reused)
+  rc = glfer_hip_avg_cum_device(d.d_rows + (size_t)first * width, (size_t)nrows, width, width, depth, minbin, maxbin, d.d_avg,
+                                nullptr);
+  if (rc) die("update_avg (sums)", rc);
+  hipck(hipMemcpy(a->cum + minbin, d.d_avg + (size_t)(nrows - 1) * width + minbin, (size_t)(maxbin - minbin) * sizeof(double),
+                  hipMemcpyDeviceToHost), "D2H cum");
+  for (int i = minbin; i < maxbin; i++) {                          // the shift registers: data movement only (avg.c:124-126)
+    memmove(a->avgarray[i], a->avgarray[i] + 1, (size_t)(depth - 1) * sizeof(double));
+    a->avgarray[i][depth - 1] = psd[i];
+  }
   hipck(hipMemcpy(ret, d.d_ret + (size_t)(nrows - 1) * 4, sizeof ret, hipMemcpyDeviceToHost), "D2H ret");
   if (a->effdepth < depth) a->effdepth++;                          // avg.c:138-139
   if (ret[1] >= 0) *peakbin = (int)ret[1];                         // left untouched when nothing exceeds psd[minbin]

@@ -6,21 +6,14 @@
 // (mtm.c:214-219) and the 1/2 of the re/im packing folded in, so the kernel's epilogue is
 // a single add.  No CPU fallback exists: every compute entry fails with GLFER_E_HIP when
 // HIP cannot run it.
-#include "../../include/glfer_hip.h"
-
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "plan.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
-#include <functional>
 #include <new>
-#include <string>
-#include <thread>
-#include <vector>
 
 #include "host_tables.h"
 #include "spectro_params.h"
@@ -32,42 +25,48 @@ extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int b
 extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframes, int bins, int n_out,
                                        int depth, int minbin, int maxbin, int max0, double *avg,
                                        double *ret, hipStream_t st);
+extern "C" hipError_t glfer_launch_avg_cum(const float *psd, size_t nframes, int bins, int n_out, int depth,
+                                           int minbin, int maxbin, double *cum, hipStream_t st);
+extern "C" hipError_t glfer_launch_lmp(const float *rows, long long row0, long long first, size_t nframes, int bins,
+                                       int nl, float *out, hipStream_t st);
+extern "C" hipError_t glfer_launch_ftest(const float *spec, size_t nframes, int n, int ntap, const double *U0,
+                                         float sum_U0_sqr, int mu_live, float *ftest, hipStream_t st);
+extern "C" hipError_t glfer_launch_submean_tail(const void *raw_last, const float *prev, float *out, int H, int fresh,
+                                                int fmt, hipStream_t st);
+extern "C" hipError_t glfer_launch_prepare(const SpectroParams *p, int n, const float *window, float *out,
+                                           hipStream_t st);
 
 static thread_local std::string g_hip_err;
 
-static int hip_fail(hipError_t e, const char *what) {
+namespace glfer {
+int hip_fail(hipError_t e, const char *what) {
   char buf[256];
   snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
   g_hip_err = buf;
   return GLFER_E_HIP;
 }
-#define HIP_TRY(call)                                   \
-  do {                                                  \
-    hipError_t e_ = (call);                             \
-    if (e_ != hipSuccess) return hip_fail(e_, #call);   \
-  } while (0)
 
-struct glfer_hip_plan {
-  glfer_hip_config cfg;
-  int n, hop, keep, bins, ntapers, npairs, lanes;
-  std::vector<float> window;        // [n] as the reference stores it (unit power)
-  std::vector<double> tapers;       // [ntapers][n]
-  std::vector<double> sig;          // [ntapers]
-  float *d_taps = nullptr;          // [npairs][8][n/16][4] scaled tables (tap_slot)
-  float2 *d_tw = nullptr;           // [64][lanes]
-  float *d_htaps = nullptr;         // real-input form (spectro16h.hip): window pairs, [htapers][8][n/32][4]
-  int htapers = 0;                  // 1: periodogram window; > 1: the tapers of the multitaper form (n >= 8192)
-  float2 *d_htw = nullptr;          //   twiddles of the n/2-point transform
-  float2 *d_hrot = nullptr;         //   (cos,sin)(2 pi t/n), t < n/32
-  float *d_xtaps = nullptr;         // odd taper counts (spectro16x.hip): the last taper alone, [4][n/16][4]
-  float *d_ltaps = nullptr;         // odd taper counts, LDS-resident half tables (spectro16xl.hip)
-  uint16_t *d_lagmap = nullptr;     // HP-ARMA: [t][p_e+1] lag held by each matrix cell
-  float2 *d_unit = nullptr;         // HP-ARMA: [n/2+1] exp(-2 pi i k/n)
-  float *d_scratch = nullptr;       // sub_mean copy of the hops of one call
-  size_t scratch_floats = 0;
-  float spec_unscale = 1.0f;
-  bool nonlin = false;
-};
+std::string error_text() { return g_hip_err; }
+void set_error_text(const std::string &text) { g_hip_err = text; }
+
+int device_of(const void *d_ptr) {
+  hipPointerAttribute_t at;
+  if (!d_ptr || hipPointerGetAttributes(&at, d_ptr) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged ? at.device : -1;
+}
+}  // namespace glfer
+using glfer::DeviceGuard;
+using glfer::hip_fail;
+
+// the device the data of a plan-less entry lives on: the pointer's, else the current one
+static int data_device(const void *d_ptr) {
+  int dev = glfer::device_of(d_ptr);
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return dev;
+}
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
@@ -98,25 +97,25 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
   if (d->scale_type < GLFER_SCALE_LIN || d->scale_type > GLFER_SCALE_LOG_MAX0) return GLFER_E_ARG;
   if (nframes == 0) return GLFER_OK;
   hipStream_t st = (hipStream_t)hip_stream;
+  DeviceGuard guard(data_device(d_rgb));
+  HIP_TRY(guard.error());
   const int scale_log = d->scale_type == GLFER_SCALE_LOG || d->scale_type == GLFER_SCALE_LOG_MAX0;
 
-  float *levels = d_levels;
-  float *scratch = nullptr;
-  unsigned char *d_tab = nullptr;
-  // one allocation: the levels rows (when the caller does not want them) + the chunk states of the
-  // autoscale walk
-  const size_t lev_floats = levels ? 0 : nframes * 4, st_floats = d->autoscale ? glfer_levels_scratch_floats(nframes) : 0;
-  if (lev_floats + st_floats) HIP_TRY(hipMalloc(&scratch, (lev_floats + st_floats) * sizeof(float)));
-  if (!levels) levels = scratch;
-  float *chunk_state = scratch ? scratch + lev_floats : nullptr;
+  // one stream-ordered allocation: the palette, the levels rows (when the caller does not want
+  // them) and the chunk states of the autoscale walk
+  const size_t lev_floats = d_levels ? 0 : nframes * 4, st_floats = d->autoscale ? glfer_levels_scratch_floats(nframes) : 0;
+  unsigned char *scratch = nullptr;
+  HIP_TRY(hipMallocAsync((void **)&scratch, 768 + (lev_floats + st_floats) * sizeof(float), st));
+  unsigned char *d_tab = scratch;
+  float *fs = reinterpret_cast<float *>(scratch + 768);
+  float *levels = d_levels ? d_levels : fs;
+  float *chunk_state = st_floats ? fs + lev_floats : nullptr;
   int rc = GLFER_OK;
   auto fail = [&](hipError_t err) { rc = hip_fail(err, "glfer_hip_display_device"); };
-  hipError_t e = hipMalloc(&d_tab, 768);
-  if (e != hipSuccess) { fail(e); (void)hipFree(scratch); return rc; }
   unsigned char tab[768];
   glfer::make_palette(d->palette, tab);
   // pageable source: hipMemcpyAsync stages it before returning, so `tab` may go out of scope
-  e = hipMemcpyAsync(d_tab, tab, 768, hipMemcpyHostToDevice, st);
+  hipError_t e = hipMemcpyAsync(d_tab, tab, 768, hipMemcpyHostToDevice, st);
   if (e != hipSuccess) fail(e);
 
   if (rc == GLFER_OK) {
@@ -142,13 +141,11 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
   float last[4] = {0, 0, 0, 0};
   if (rc == GLFER_OK) {
     e = hipMemcpyAsync(last, levels + (nframes - 1) * 4, sizeof last, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) fail(e);
-  } else {
-    (void)hipStreamSynchronize(st);
   }
-  (void)hipFree(d_tab);
-  (void)hipFree(scratch);
+  (void)hipFreeAsync(scratch, st);
+  e = hipStreamSynchronize(st);              // the carried state comes back to the host
+  if (e != hipSuccess && rc == GLFER_OK) fail(e);
   if (rc == GLFER_OK) {
     d->display_max_lvl = last[2];
     d->display_min_lvl = last[3];
@@ -176,7 +173,10 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   const int n = cfg->n;
   if (!is_pow2(n) || n < 256 || n > 16384) return GLFER_E_ARG;
   if (!(cfg->overlap >= 0.0f) || !(cfg->overlap < 1.0f)) return GLFER_E_ARG;   // g_options.c:1030
-  if (cfg->mode != GLFER_MODE_FFT && cfg->mode != GLFER_MODE_MTM && cfg->mode != GLFER_MODE_HPARMA) return GLFER_E_ARG;
+  if (cfg->mode != GLFER_MODE_FFT && cfg->mode != GLFER_MODE_MTM && cfg->mode != GLFER_MODE_HPARMA &&
+      cfg->mode != GLFER_MODE_LMP)
+    return GLFER_E_ARG;
+  if (cfg->mode == GLFER_MODE_LMP && (cfg->lmp_av < 1 || cfg->lmp_av > 4096)) return GLFER_E_ARG;
   if (cfg->mode == GLFER_MODE_HPARMA) {
     const int t = cfg->hparma_t, ncol = cfg->hparma_p_e + 1;
     if (t < 2 || ncol < 2 || ncol > t || t > n || ncol > 256 || t > 65535) return GLFER_E_ARG;   // p_e+1 <= t (hparma.c:107)
@@ -201,17 +201,27 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   // --- host tables
   p->window.assign(n, 1.0f);
   std::vector<float> taps;
-  if (cfg->mode == GLFER_MODE_FFT) {
+  // LMP (lmp.c:101-181): the periodogram of the raw assembled frame -- lmp.c:114-116 overwrites what
+  // prepare_audio left in inbuf_fft, so window (rectangular anyway, source.c:395), a and limiter
+  // have no effect -- followed by the per-bin statistic over the last lmp_av periodograms
+  const bool lmp = cfg->mode == GLFER_MODE_LMP;
+  if (lmp) {
+    p->cfg.window_type = GLFER_WIN_RECTANGULAR;
+    p->cfg.limiter_a = 0.0f;
+    p->cfg.enable_limiter = 0;
+    p->lmp_av = cfg->lmp_av;
+  }
+  if (cfg->mode == GLFER_MODE_FFT || lmp) {
     p->ntapers = 1;
     p->npairs = 1;
-    glfer::make_window(cfg->window_type, n, p->window.data());
-    p->nonlin = (cfg->limiter_a > 0.0f) || (cfg->enable_limiter == 1);
+    glfer::make_window(p->cfg.window_type, n, p->window.data());
+    p->nonlin = (p->cfg.limiter_a > 0.0f) || (p->cfg.enable_limiter == 1);
     // psd = |X|^2/N (fft.c:212-216); the pair packing contributes |Z_k|^2+|Z_{N-k}|^2 = 2|X_k|^2
     const double scale = std::sqrt(1.0 / (2.0 * n));
     p->spec_unscale = (float)scale;
     // device layout: taps[pair][i] = (taper 2*pair, taper 2*pair+1)[i], interleaved
     taps.assign((size_t)2 * n, 0.0f);
-    const bool rect = (cfg->window_type == GLFER_WIN_RECTANGULAR);
+    const bool rect = (p->cfg.window_type == GLFER_WIN_RECTANGULAR);
     for (int i = 0; i < n; i++) {
       const double w = rect ? 1.0 : (double)p->window[i];          // fft.c:132,139: no multiply when rectangular
       taps[tap_slot(n, 0, i, 0)] = p->nonlin ? (float)w : (float)(w * scale);
@@ -251,12 +261,12 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   // registers: the packed N-point form would need the whole N-point exchange buffer (139 KB at
   // N = 16384: one workgroup per CU), the real-input form half of it.  Each taper carries its weight:
   // sqrt(1 / (4N (1 + sig_j))).
-  const bool h_periodogram = cfg->mode == GLFER_MODE_FFT && !p->nonlin && n >= 512;
+  const bool h_periodogram = (cfg->mode == GLFER_MODE_FFT || lmp) && !p->nonlin && n >= 512;
   const bool h_multitaper = cfg->mode == GLFER_MODE_MTM && n >= 8192;
   if (h_periodogram || h_multitaper) {
     const int th = n / 32;
     const int nwin = h_multitaper ? p->ntapers : 1;
-    const bool rect = h_periodogram && (cfg->window_type == GLFER_WIN_RECTANGULAR);
+    const bool rect = h_periodogram && (p->cfg.window_type == GLFER_WIN_RECTANGULAR);
     htaps.resize((size_t)nwin * n);
     for (int j = 0; j < nwin; j++) {
       const double scale = std::sqrt(1.0 / (4.0 * n * (h_multitaper ? 1.0 + p->sig[j] : 1.0)));
@@ -349,8 +359,13 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   }
 
   // --- device tables
-  hipError_t e = hipSetDevice(cfg->device);
+  DeviceGuard guard(cfg->device);
+  hipError_t e = guard.error();
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_taps, taps.size() * sizeof(float));
+  if (e == hipSuccess && cfg->mode == GLFER_MODE_FFT && cfg->window_type != GLFER_WIN_RECTANGULAR) {
+    e = hipMalloc((void **)&p->d_window, (size_t)n * sizeof(float));            // prepare_audio's multiply, fft.c:139-146
+    if (e == hipSuccess) e = hipMemcpy(p->d_window, p->window.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_tw, tw.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(p->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -387,14 +402,17 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
 
 void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (!p) return;
+  DeviceGuard guard(p->cfg.device);
   if (p->d_taps) (void)hipFree(p->d_taps);
+  if (p->d_window) (void)hipFree(p->d_window);
+  if (p->d_ftaps) (void)hipFree(p->d_ftaps);
+  if (p->d_U0) (void)hipFree(p->d_U0);
   if (p->d_tw) (void)hipFree(p->d_tw);
   if (p->d_htaps) (void)hipFree(p->d_htaps);
   if (p->d_htw) (void)hipFree(p->d_htw);
   if (p->d_hrot) (void)hipFree(p->d_hrot);
   if (p->d_xtaps) (void)hipFree(p->d_xtaps);
   if (p->d_ltaps) (void)hipFree(p->d_ltaps);
-  if (p->d_scratch) (void)hipFree(p->d_scratch);
   if (p->d_lagmap) (void)hipFree(p->d_lagmap);
   if (p->d_unit) (void)hipFree(p->d_unit);
   delete p;
@@ -527,21 +545,11 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   return real_input ? launch_real_input(body, n, st) : launch_shared_odd(body, n, st);
 }
 
-static int run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first,
-                      size_t nframes, float *d_psd, float *d_spec, void *hip_stream) {
-  if (!p || !d_stream || (!d_psd && nframes)) return GLFER_E_ARG;
-  if (nframes == 0) return GLFER_OK;
-  if ((first + nframes) > nsamples / (size_t)p->hop) return GLFER_E_ARG;   // frame past the stream
-  if (nframes > 0x7fffffffu) return GLFER_E_ARG;
-  if (d_spec && p->cfg.mode != GLFER_MODE_FFT) return GLFER_E_ARG;
-  hipStream_t st = (hipStream_t)hip_stream;
-  HIP_TRY(hipSetDevice(p->cfg.device));
+}  // extern "C"
 
-  SpectroParams sp;
+// Fills the kernel argument block from a plan.
+static void fill_params(const glfer_hip_plan *p, SpectroParams &sp) {
   memset(&sp, 0, sizeof sp);
-  sp.stream = d_stream;
-  sp.frame0 = (long long)first;
-  sp.nframes = (int)nframes;
   sp.H = p->hop;
   sp.R = p->keep;
   sp.npairs = p->npairs;
@@ -560,249 +568,233 @@ static int run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, 
   sp.hrot = p->d_hrot;
   sp.xtaps = p->d_xtaps;
   sp.ltaps = p->d_ltaps;
-  sp.psd = d_psd;
-  sp.spec = d_spec;
+}
 
-  if (p->cfg.sub_mean) {
-    // K0 (fft.c:86-96): the mean of each hop's NEW samples is removed before the hop enters
-    // the frame history, so every sample is corrected by the mean of the hop it arrived in.
-    // ZERO_ALWAYS frames see only their own hop; otherwise a frame reaches back ceil(R/H) hops
-    const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop);
-    size_t hop_lo = first;
-    if (!sp.history_mode) hop_lo = (first > hops_back) ? first - hops_back : 0;
-    const size_t nhops = first + nframes - hop_lo;
-    const size_t need = nhops * (size_t)p->hop;
-    if (need > p->scratch_floats) {
-      if (p->d_scratch) HIP_TRY(hipFree(p->d_scratch));
-      p->d_scratch = nullptr;
-      p->scratch_floats = 0;
-      HIP_TRY(hipMalloc((void **)&p->d_scratch, need * sizeof(float)));
-      p->scratch_floats = need;
-    }
-    const size_t esz = sp.fmt == GLFER_FMT_F32 ? 4 : (sp.fmt == GLFER_FMT_S16 ? 2 : 1);
-    const char *src = (const char *)d_stream + hop_lo * (size_t)p->hop * esz;
-    HIP_TRY(glfer_launch_submean(src, p->d_scratch, p->hop, (long long)nhops, sp.fmt, st));
-    sp.stream = p->d_scratch;
-    sp.fmt = GLFER_FMT_F32;
-    sp.frame0 = (long long)(first - hop_lo);
+// K0 (fft.c:86-96) for the hops that frames [first, first+nframes) touch: the mean of each hop's
+// NEW samples is removed before the hop enters the frame history, so every sample is corrected by
+// the mean of the hop it arrived in.  ZERO_ALWAYS frames see only their own hop; otherwise a frame
+// reaches back ceil(R/H) whole hops -- which is why a shard's or a chunk's halo is whole hops
+// (glfer_hip.h, "Cutting a stream").  The corrected float copy lives in stream-ordered scratch
+// (hipMallocAsync on `st`: nothing is shared between calls, the call stays asynchronous) and the
+// kernels get its VIRTUAL base, so frame indices stay global and the frame groups of the
+// shared-odd-taper kernels stay aligned to the stream, not to the launch.
+//
+// tail_fresh >= 0: the last hop is the file source's trailing partial block.  The caller has laid
+// its fresh samples over a copy of the previous hop's RAW samples; what the reference's buffer
+// holds there is the previous hop AFTER its mean removal (wav_fmt.c:102-119 over fft.c:93-95), so
+// the last hop is rebuilt from the corrected previous hop before its own mean is taken.
+static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t first, size_t nframes, hipStream_t st,
+                           float **scratch_out, long tail_fresh = -1) {
+  const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop);
+  size_t hop_lo = first;
+  if (!sp.history_mode) hop_lo = (first > hops_back) ? first - hops_back : 0;
+  const size_t last = first + nframes - 1;
+  if (tail_fresh >= 0 && last > 0 && hop_lo > last - 1) hop_lo = last - 1;   // the stale part needs the hop before
+  const size_t nhops = first + nframes - hop_lo;
+  float *scratch = nullptr;
+  HIP_TRY(hipMallocAsync((void **)&scratch, nhops * (size_t)p->hop * sizeof(float), st));
+  const size_t esz = sp.fmt == GLFER_FMT_F32 ? 4 : (sp.fmt == GLFER_FMT_S16 ? 2 : 1);
+  const char *src = (const char *)sp.stream + hop_lo * (size_t)p->hop * esz;
+  hipError_t e = glfer_launch_submean(src, scratch, p->hop, (long long)nhops, sp.fmt, st);
+  if (e == hipSuccess && tail_fresh >= 0)
+    e = glfer_launch_submean_tail(src + (nhops - 1) * (size_t)p->hop * esz, nhops > 1 ? scratch + (nhops - 2) * (size_t)p->hop : nullptr,
+                                  scratch + (nhops - 1) * (size_t)p->hop, p->hop, (int)tail_fresh, sp.fmt, st);
+  if (e != hipSuccess) {
+    (void)hipFreeAsync(scratch, st);
+    return hip_fail(e, "glfer_launch_submean");
   }
-  if (p->cfg.mode == GLFER_MODE_HPARMA)
-    HIP_TRY(glfer_launch_hparma(&sp, p->n, p->cfg.hparma_t, p->cfg.hparma_p_e + 1, p->d_lagmap, p->d_unit, st));
-  else
-    HIP_TRY(launch_by_n(sp, p->n, st));
+  sp.stream = reinterpret_cast<const char *>(scratch) - hop_lo * (size_t)p->hop * sizeof(float);
+  sp.fmt = GLFER_FMT_F32;
+  *scratch_out = scratch;
   return GLFER_OK;
 }
 
+int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first, size_t nframes,
+                     float *d_psd, float *d_spec, hipStream_t st, long tail_fresh) {
+  if (!p || !d_stream || (!d_psd && nframes)) return GLFER_E_ARG;
+  if (nframes == 0) return GLFER_OK;
+  if ((first + nframes) > nsamples / (size_t)p->hop) return GLFER_E_ARG;   // frame past the stream
+  if (nframes > 0x7fffffffu) return GLFER_E_ARG;
+  if (d_spec && p->cfg.mode != GLFER_MODE_FFT) return GLFER_E_ARG;
+  DeviceGuard guard(p->cfg.device);
+  HIP_TRY(guard.error());
+
+  SpectroParams sp;
+  fill_params(p, sp);
+  sp.stream = d_stream;
+  sp.frame0 = (long long)first;
+  sp.nframes = (int)nframes;
+  sp.psd = d_psd;
+  sp.spec = d_spec;
+
+  float *scratch = nullptr, *rows = nullptr;
+  int rc = GLFER_OK;
+  if (tail_fresh >= 0 && (tail_fresh >= (long)p->hop || p->cfg.mode == GLFER_MODE_LMP)) return GLFER_E_ARG;
+  if (p->cfg.sub_mean) rc = submean_scratch(p, sp, first, nframes, st, &scratch, tail_fresh);
+  if (rc == GLFER_OK && p->cfg.mode == GLFER_MODE_LMP) {
+    // lmp.c:101-181: periodograms of the frames the ring holds when frame first+nframes-1 is done
+    // (lmp_av - 1 frames before `first`, recomputed rather than carried), then the statistic
+    const size_t back = std::min<size_t>((size_t)p->lmp_av - 1, first);
+    const size_t nrows = nframes + back;
+    hipError_t e = hipMallocAsync((void **)&rows, nrows * (size_t)p->bins * sizeof(float), st);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMallocAsync(lmp rows)");
+    if (rc == GLFER_OK && back && p->cfg.sub_mean) {
+      // the extra frames reach further back than the hops corrected above
+      (void)hipFreeAsync(scratch, st);
+      scratch = nullptr;
+      sp.stream = d_stream;
+      sp.fmt = p->cfg.sample_format;
+      rc = submean_scratch(p, sp, first - back, nrows, st, &scratch);
+    }
+    if (rc == GLFER_OK) {
+      sp.frame0 = (long long)(first - back);
+      sp.nframes = (int)nrows;
+      sp.psd = rows;
+      e = launch_by_n(sp, p->n, st);
+      if (e == hipSuccess)
+        e = glfer_launch_lmp(rows, (long long)(first - back), (long long)first, nframes, p->bins, p->lmp_av, d_psd, st);
+      if (e != hipSuccess) rc = hip_fail(e, "lmp launch");
+    }
+  } else if (rc == GLFER_OK) {
+    hipError_t e = p->cfg.mode == GLFER_MODE_HPARMA
+                       ? glfer_launch_hparma(&sp, p->n, p->cfg.hparma_t, p->cfg.hparma_p_e + 1, p->d_lagmap, p->d_unit, st)
+                       : launch_by_n(sp, p->n, st);
+    if (e != hipSuccess) rc = hip_fail(e, "estimator launch");
+  }
+  if (rows) (void)hipFreeAsync(rows, st);
+  if (scratch) (void)hipFreeAsync(scratch, st);
+  return rc;
+}
+
+extern "C" {
+
 int glfer_hip_spectrogram_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first,
                                  size_t nframes, float *d_psd, void *hip_stream) {
-  return run_device(p, d_stream, nsamples, first, nframes, d_psd, nullptr, hip_stream);
+  return glfer_run_device(p, d_stream, nsamples, first, nframes, d_psd, nullptr, (hipStream_t)hip_stream);
 }
 
 int glfer_hip_spectrum_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first,
                               size_t nframes, float *d_psd, float *d_spec, void *hip_stream) {
   if (!d_spec) return GLFER_E_ARG;
-  return run_device(p, d_stream, nsamples, first, nframes, d_psd, d_spec, hip_stream);
+  return glfer_run_device(p, d_stream, nsamples, first, nframes, d_psd, d_spec, (hipStream_t)hip_stream);
 }
 
-// memcpy spread over a few threads: the destination is usually fresh pageable memory, where the
-// page faults, not the copy, set the pace
-static void copy_wide(void *dst, const void *src, size_t bytes) {
-  const size_t kMin = (size_t)8 << 20;
-  unsigned nt = bytes < 2 * kMin ? 1u : (unsigned)std::min<size_t>(8, bytes / kMin);
-  const unsigned hw = std::thread::hardware_concurrency();
-  if (hw && nt > hw) nt = hw;
-  if (nt <= 1) { memcpy(dst, src, bytes); return; }
-  std::vector<std::thread> th;
-  const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
-  size_t done = 0;                               // bytes handed to threads so far
-  try {
-    for (unsigned i = 0; i + 1 < nt && done + per < bytes; i++) {
-      const size_t off = done;
-      th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, per); });
-      done += per;
-    }
-  } catch (...) {                                // no more threads to be had: this one copies the rest
+// prepare_audio (fft.c:66-165) for a batch of frames: what it leaves in params->inbuf_fft
+// (lmp.c:101-120 and g_scope.c:194-197 read it).  d_frames: [nframes][N] floats.
+int glfer_hip_prepare_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first,
+                             size_t nframes, float *d_frames, void *hip_stream) {
+  if (!p || !d_stream || (!d_frames && nframes)) return GLFER_E_ARG;
+  if (nframes == 0) return GLFER_OK;
+  if ((first + nframes) > nsamples / (size_t)p->hop || nframes > 0x7fffffffu) return GLFER_E_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  DeviceGuard guard(p->cfg.device);
+  HIP_TRY(guard.error());
+  SpectroParams sp;
+  fill_params(p, sp);
+  sp.stream = d_stream;
+  sp.frame0 = (long long)first;
+  sp.nframes = (int)nframes;
+  float *scratch = nullptr;
+  int rc = GLFER_OK;
+  if (p->cfg.sub_mean) rc = submean_scratch(p, sp, first, nframes, st, &scratch);
+  if (rc == GLFER_OK) {
+    // MTM / HP-ARMA / LMP run prepare_audio with a rectangular window (source.c:344,369,395); a and
+    // the limiter still act on inbuf_fft there, but those estimators overwrite it, so the shims ask
+    // for this only in FFT mode
+    hipError_t e = glfer_launch_prepare(&sp, p->n, p->d_window, d_frames, st);
+    if (e != hipSuccess) rc = hip_fail(e, "glfer_launch_prepare");
   }
-  memcpy((char *)dst + done, (const char *)src + done, bytes - done);
-  for (auto &t : th) t.join();
-}
-
-// Host samples -> host PSD rows, in chunks of whole frames through pinned buffers.  Per chunk:
-// H2D, the estimator, D2H on one stream; while the GPU works on chunk c the host fetches chunk c+1's
-// samples (reader) and moves chunk c-1's rows from their pinned buffer to the caller's memory.  Each
-// device buffer starts with the N-H samples carried over from the previous chunk, and the kernel is
-// given a virtual stream base so that frame indices -- and the zero history of the very first
-// frames -- come out as in a one-shot run.  reader(dst, nframes) fills dst with nframes*hop samples
-// and returns the number of whole frames it delivered.
-static int ingest_chunks(glfer_hip_plan *p, size_t frames, size_t chunk_frames,
-                         const std::function<size_t(unsigned char *, size_t)> &reader, float *h_psd, size_t *nframes_out) {
-  const size_t esz = p->cfg.sample_format == GLFER_SAMPLES_F32 ? 4 : (p->cfg.sample_format == GLFER_SAMPLES_S16 ? 2 : 1);
-  const size_t hop = (size_t)p->hop, bins = (size_t)p->bins;
-  // history kept on the device between chunks: whole hops covering the N-H overlap
-  const size_t halo = (size_t)((p->keep + p->hop - 1) / p->hop) * hop;
-  if (chunk_frames == 0) {                                     // default: 16384 frames, at most 256 MiB of samples
-    chunk_frames = 16384;
-    const size_t cap = ((size_t)256 << 20) / (hop * esz);
-    if (chunk_frames > cap) chunk_frames = cap;
-  }
-  if (chunk_frames < 2 * (halo / hop)) chunk_frames = 2 * (halo / hop);     // halo copy must not overlap itself
-  if (chunk_frames < 1) chunk_frames = 1;
-  chunk_frames = (chunk_frames + GLFER_FRAME_ALIGN - 1) / GLFER_FRAME_ALIGN * GLFER_FRAME_ALIGN;   // see launch_by_n
-  if (chunk_frames > frames) chunk_frames = frames;
-  HIP_TRY(hipSetDevice(p->cfg.device));
-  unsigned char *h_in[2] = {nullptr, nullptr};
-  float *h_out[2] = {nullptr, nullptr}, *d_out = nullptr;
-  unsigned char *d_in = nullptr;
-  hipStream_t st = nullptr;
-  const size_t chunk_bytes = chunk_frames * hop * esz, out_bytes = chunk_frames * bins * sizeof(float);
-  hipError_t e = hipStreamCreate(&st);
-  for (int b = 0; b < 2 && e == hipSuccess; b++) {
-    e = hipHostMalloc((void **)&h_in[b], chunk_bytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&h_out[b], out_bytes, hipHostMallocDefault);
-  }
-  if (e == hipSuccess) e = hipMalloc((void **)&d_in, (halo + chunk_frames * hop) * esz);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_out, out_bytes);
-  int rc = (e == hipSuccess) ? GLFER_OK : hip_fail(e, "ingest: allocate");
-  size_t done = 0, nread = 0, prev_nf = 0, prev_done = 0;
-  int cur = 0;
-  if (rc == GLFER_OK) nread = reader(h_in[0], std::min(chunk_frames, frames));
-  while (rc == GLFER_OK && done < frames && nread > 0) {
-    const size_t nf = nread;
-    // chunk samples land behind the halo; sample 0 of the stream sits at d_in + halo - done*hop
-    e = hipMemcpyAsync(d_in + halo * esz, h_in[cur], nf * hop * esz, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
-    const unsigned char *vbase = d_in + halo * esz - done * hop * esz;   // virtual address of stream sample 0
-    rc = run_device(p, vbase, (done + nf) * hop, done, nf, d_out, nullptr, st);
-    if (rc) break;
-    e = hipMemcpyAsync(h_out[cur], d_out, nf * bins * sizeof(float), hipMemcpyDeviceToHost, st);
-    // keep the last `halo` samples of this chunk in front of the next one (only a full chunk is
-    // ever followed by another, and a full chunk is at least one halo long)
-    if (e == hipSuccess && halo && done + nf < frames)
-      e = hipMemcpyAsync(d_in, d_in + nf * hop * esz, halo * esz, hipMemcpyDeviceToDevice, st);
-    // while the GPU works: fetch the next chunk's samples, hand the previous chunk's rows over
-    // (side by side: both are host memory copies)
-    const size_t want = std::min(chunk_frames, frames - done - nf);
-    nread = 0;
-    std::thread fetch;
-    if (want) {
-      try {
-        fetch = std::thread([&] { nread = reader(h_in[cur ^ 1], want); });
-      } catch (...) {                            // no thread: fetch here, before the row copy
-        nread = reader(h_in[cur ^ 1], want);
-      }
-    }
-    if (prev_nf) copy_wide(h_psd + prev_done * bins, h_out[cur ^ 1], prev_nf * bins * sizeof(float));
-    if (fetch.joinable()) fetch.join();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { rc = hip_fail(e, "ingest: chunk"); break; }
-    prev_nf = nf;
-    prev_done = done;
-    done += nf;
-    cur ^= 1;
-  }
-  if (rc == GLFER_OK && prev_nf) copy_wide(h_psd + prev_done * bins, h_out[cur ^ 1], prev_nf * bins * sizeof(float));
-  *nframes_out = done;
-  for (int b = 0; b < 2; b++) {
-    if (h_in[b]) (void)hipHostFree(h_in[b]);
-    if (h_out[b]) (void)hipHostFree(h_out[b]);
-  }
-  if (d_in) (void)hipFree(d_in);
-  if (d_out) (void)hipFree(d_out);
-  if (st) (void)hipStreamDestroy(st);
+  if (scratch) (void)hipFreeAsync(scratch, st);
   return rc;
 }
 
-int glfer_hip_spectrogram_host(glfer_hip_plan *p, const void *h_stream, size_t nsamples, float *h_psd,
-                               size_t *nframes_out) {
-  if (!p || !h_stream || !nframes_out) return GLFER_E_ARG;
-  const size_t frames = nsamples / (size_t)p->hop;
-  *nframes_out = frames;
-  if (frames == 0) return GLFER_OK;
-  if (!h_psd) return GLFER_E_ARG;
-  const size_t esz = p->cfg.sample_format == GLFER_SAMPLES_F32 ? 4 : (p->cfg.sample_format == GLFER_SAMPLES_S16 ? 2 : 1);
-  const size_t hop_bytes = (size_t)p->hop * esz;
-  if (frames * hop_bytes + frames * (size_t)p->bins * sizeof(float) < ((size_t)4 << 20)) {
-    // a few megabytes: one copy each way costs less than setting the pipeline up
-    HIP_TRY(hipSetDevice(p->cfg.device));
-    const size_t used = frames * (size_t)p->hop;
-    void *d_in = nullptr;
-    float *d_out = nullptr;
-    int rc = GLFER_OK;
-    hipError_t e = hipMalloc(&d_in, used * esz);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, frames * (size_t)p->bins * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(d_in, h_stream, used * esz, hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: staging");
-    if (rc == GLFER_OK) rc = run_device(p, d_in, used, 0, frames, d_out, nullptr, nullptr);
-    if (rc == GLFER_OK) {
-      e = hipMemcpy(h_psd, d_out, frames * (size_t)p->bins * sizeof(float), hipMemcpyDeviceToHost);
-      if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: copy back");
+// The harmonic F-test of mtm_do (mtm.c:165-174, 203-233) as an optional output of the multitaper
+// path.  The tapered spectra y_j(f) and mu(f) come from the estimator's own spectrum output (one
+// single-taper launch of spectro16_kernel per taper and one for hn), the statistic from a per-bin
+// epilogue (stats_kernels.hip).  Frames are processed in groups that keep the spectra scratch
+// under ~256 MiB.
+int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first,
+                               size_t nframes, float *d_ftest, int mu_live, void *hip_stream) {
+  if (!p || !d_stream || (!d_ftest && nframes) || p->cfg.mode != GLFER_MODE_MTM) return GLFER_E_ARG;
+  if (nframes == 0) return GLFER_OK;
+  if ((first + nframes) > nsamples / (size_t)p->hop || nframes > 0x7fffffffu) return GLFER_E_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  DeviceGuard guard(p->cfg.device);
+  HIP_TRY(guard.error());
+  const int n = p->n, T = p->ntapers;
+  if (!p->d_ftaps) {                     // tables of mtm.c:76-83, 124-136, once per plan
+    p->U0.resize(T);
+    p->hn.resize(n);
+    glfer::make_ftest_tables(n, T - 1, p->tapers.data(), p->U0.data(), p->hn.data(), &p->sum_U0_sqr);
+    std::vector<float> taps((size_t)(T + 1) * 2 * n, 0.0f);
+    for (int j = 0; j <= T; j++)
+      for (int i = 0; i < n; i++)
+        taps[(size_t)j * 2 * n + tap_slot(n, 0, i, 0)] = j < T ? (float)p->tapers[(size_t)j * n + i] : p->hn[i];
+    float *d = nullptr;
+    double *du = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, taps.size() * sizeof(float)));
+    hipError_t e = hipMalloc((void **)&du, (size_t)T * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(du, p->U0.data(), (size_t)T * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(d);
+      (void)hipFree(du);
+      return hip_fail(e, "ftest tables");
     }
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    return rc;
+    p->d_ftaps = d;
+    p->d_U0 = du;
   }
-  size_t given = 0;
-  auto reader = [&](unsigned char *dst, size_t want) {
-    copy_wide(dst, (const unsigned char *)h_stream + given * hop_bytes, want * hop_bytes);
-    given += want;
-    return want;
-  };
-  return ingest_chunks(p, frames, 0, reader, h_psd, nframes_out);
-}
-
-// ---- ingest (wav_fmt.c:45-121, source.c:118-128) ------------------------------------------
-static unsigned rd_u16(const unsigned char *b) { return b[0] | (b[1] << 8); }
-static unsigned rd_u32(const unsigned char *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24); }
-
-int glfer_hip_wav_probe(const char *path, glfer_wav_info *info) {
-  if (!path || !info) return GLFER_E_ARG;
-  FILE *f = fopen(path, "rb");
-  if (!f) return GLFER_E_ARG;                                    // wav_fmt.c:53-56 exits; we report
-  unsigned char hd[44];
-  const size_t got = fread(hd, 1, sizeof hd, f);
-  long end = 0;
-  if (fseek(f, 0, SEEK_END) == 0) end = ftell(f);
-  fclose(f);
-  if (got < sizeof hd) return GLFER_E_ARG;                       // "input file less than 20 bytes long", wav_fmt.c:61-62
-  if (memcmp(hd, "RIFF", 4) != 0) return GLFER_E_ARG;            // "input file not in WAV format", wav_fmt.c:63-64
-  info->format = (int)rd_u16(hd + 20);                           // wav_fmt.h:42
-  info->channels = (int)rd_u16(hd + 22);                         // wav_fmt.h:43
-  info->sample_rate = (int)rd_u32(hd + 24);                      // wav_fmt.h:44  -> *speed, wav_fmt.c:70
-  info->bits_per_sample = (int)rd_u16(hd + 34);                  // wav_fmt.h:47  -> bits, wav_fmt.c:71
-  info->data_offset = 44;
-  if (info->format != 1) return GLFER_E_ARG;                     // "input is not a PCM WAV file", wav_fmt.c:68-69
-  if (info->bits_per_sample != 8 && info->bits_per_sample != 16) return GLFER_E_ARG;   // wav_fmt.c:87-96 handles only these
-  const size_t avail = end > 44 ? (size_t)(end - 44) : 0;
-  info->nsamples = avail / (size_t)(info->bits_per_sample / 8);  // the reference reads until read() returns 0
-  return GLFER_OK;
-}
-
-int glfer_hip_spectrogram_wav(glfer_hip_plan *p, const char *path, float *h_psd, size_t max_frames,
-                              size_t *nframes_out, size_t chunk_frames) {
-  if (!p || !path || !nframes_out) return GLFER_E_ARG;
-  glfer_wav_info wi;
-  int rc = glfer_hip_wav_probe(path, &wi);
-  if (rc) return rc;
-  const int fmt = wi.bits_per_sample == 8 ? GLFER_SAMPLES_U8 : GLFER_SAMPLES_S16;
-  if (p->cfg.sample_format != fmt) return GLFER_E_ARG;
-  const size_t esz = (size_t)wi.bits_per_sample / 8, hop = (size_t)p->hop;
-  size_t frames = wi.nsamples / hop;                             // whole blocks only, wav_fmt.c:119
-  if (frames > max_frames) frames = max_frames;
-  *nframes_out = frames;
-  if (frames == 0) return GLFER_OK;
-  if (!h_psd) return GLFER_E_ARG;
-  FILE *f = fopen(path, "rb");
-  if (!f) return GLFER_E_ARG;
-  if (fseek(f, (long)wi.data_offset, SEEK_SET) != 0) { fclose(f); return GLFER_E_ARG; }
-  auto reader = [&](unsigned char *dst, size_t want) { return fread(dst, 1, want * hop * esz, f) / (hop * esz); };
-  rc = ingest_chunks(p, frames, chunk_frames, reader, h_psd, nframes_out);
-  fclose(f);
+  SpectroParams sp;
+  fill_params(p, sp);
+  sp.stream = d_stream;
+  sp.npairs = 1;
+  sp.nonlin = 0;
+  sp.post_scale = sp.spec_unscale = 1.0f;
+  sp.htaps = nullptr;                    // the packed kernel: it is the one with the spectrum output
+  sp.xtaps = sp.ltaps = nullptr;
+  float *scratch = nullptr;
+  int rc = GLFER_OK;
+  if (p->cfg.sub_mean) {
+    sp.frame0 = (long long)first;
+    rc = submean_scratch(p, sp, first, nframes, st, &scratch);
+  }
+  size_t group = ((size_t)256 << 20) / ((size_t)(T + 1) * n * sizeof(float));
+  group = std::max<size_t>(1, std::min<size_t>(group, 32768));
+  float *spec = nullptr, *dummy = nullptr;
+  if (rc == GLFER_OK) {
+    const size_t g = std::min(group, nframes);
+    hipError_t e = hipMallocAsync((void **)&spec, (size_t)(T + 1) * g * n * sizeof(float), st);
+    if (e == hipSuccess) e = hipMallocAsync((void **)&dummy, g * (size_t)p->bins * sizeof(float), st);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMallocAsync(ftest spectra)");
+  }
+  for (size_t done = 0; rc == GLFER_OK && done < nframes; done += group) {
+    const size_t g = std::min(group, nframes - done);
+    hipError_t e = hipSuccess;
+    for (int j = 0; j <= T && e == hipSuccess; j++) {
+      if (j == T && !mu_live) break;     // mu is never written in the reference build (mtm.c:173)
+      SpectroParams q = sp;
+      q.frame0 = (long long)(first + done);
+      q.nframes = (int)g;
+      q.taps = p->d_ftaps + (size_t)j * 2 * n;
+      q.psd = dummy;
+      q.spec = spec + (size_t)j * g * n;
+      e = launch_packed(q, n, st);
+    }
+    if (e == hipSuccess)
+      e = glfer_launch_ftest(spec, g, n, T, p->d_U0, p->sum_U0_sqr, mu_live ? 1 : 0, d_ftest + done * (size_t)p->bins, st);
+    if (e != hipSuccess) rc = hip_fail(e, "ftest launch");
+  }
+  if (spec) (void)hipFreeAsync(spec, st);
+  if (dummy) (void)hipFreeAsync(dummy, st);
+  if (scratch) (void)hipFreeAsync(scratch, st);
   return rc;
 }
 
 int glfer_hip_submean_device(const void *d_in, float *d_out, int hop, size_t nhops, int sample_format,
                              void *hip_stream) {
   if (!d_in || !d_out || hop < 1 || sample_format < 0 || sample_format > 2) return GLFER_E_ARG;
+  DeviceGuard guard(data_device(d_out));
+  HIP_TRY(guard.error());
   HIP_TRY(glfer_launch_submean(d_in, d_out, hop, (long long)nhops, sample_format, (hipStream_t)hip_stream));
   return GLFER_OK;
 }
@@ -810,6 +802,8 @@ int glfer_hip_submean_device(const void *d_in, float *d_out, int hop, size_t nho
 int glfer_hip_floor_device(const float *d_psd, size_t nframes, int bins, float *d_stats, void *hip_stream) {
   if (!d_psd || !d_stats || bins < 1 || bins > 32769) return GLFER_E_ARG;
   const int m = bins - (int)(bins * 0.95);                       // fft.c:271: i = N2*0.95 .. N2-1
+  DeviceGuard guard(data_device(d_psd));
+  HIP_TRY(guard.error());
   HIP_TRY(glfer_launch_floor(d_psd, nframes, bins, m, d_stats, (hipStream_t)hip_stream));
   return GLFER_OK;
 }
@@ -820,8 +814,22 @@ int glfer_hip_avg_device(int avg_mode, const float *d_psd, size_t nframes, int b
   if (avg_mode < GLFER_AVG_SUMAVG || avg_mode > GLFER_AVG_SUMEXTREME) return GLFER_E_ARG;
   if (depth < 1 || minbin < 0 || maxbin <= minbin || maxbin > bins || maxbin > n_out || n_out < 1)
     return GLFER_E_ARG;
+  DeviceGuard guard(data_device(d_psd));
+  HIP_TRY(guard.error());
   HIP_TRY(glfer_launch_avg(avg_mode, d_psd, nframes, bins, n_out, depth, minbin, maxbin, max0 ? 1 : 0, d_avg,
                            d_ret, (hipStream_t)hip_stream));
+  return GLFER_OK;
+}
+
+// the sliding sums alone (avgdata->cum after each frame, avg.c:114-127); bins outside
+// [minbin, maxbin) are left untouched
+int glfer_hip_avg_cum_device(const float *d_psd, size_t nframes, int bins, int n_out, int depth, int minbin,
+                             int maxbin, double *d_cum, void *hip_stream) {
+  if (!d_psd || !d_cum) return GLFER_E_ARG;
+  if (depth < 1 || minbin < 0 || maxbin <= minbin || maxbin > bins || maxbin > n_out || n_out < 1) return GLFER_E_ARG;
+  DeviceGuard guard(data_device(d_psd));
+  HIP_TRY(guard.error());
+  HIP_TRY(glfer_launch_avg_cum(d_psd, nframes, bins, n_out, depth, minbin, maxbin, d_cum, (hipStream_t)hip_stream));
   return GLFER_OK;
 }
 

@@ -273,4 +273,23 @@ void make_palette(int palette, unsigned char tab[768]) {
   }
 }
 
+// Tables of the harmonic F-test as mtm_init builds them: U0[j] = sum_i v_j[i] in double
+// (mtm.c:76-83), sum_U0_sqr and hn[i] = sum_j U0[j] v_j[i] / sum_U0_sqr with FLOAT accumulators
+// (mtm.c:56-60 declares them float, mtm.c:124-136).  tapers: [kmax+1][n].
+void make_ftest_tables(int n, int kmax, const double *tapers, double *U0, float *hn, float *sum_U0_sqr) {
+  for (int j = 0; j <= kmax; j++) {
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += tapers[(size_t)j * n + i];
+    U0[j] = s;
+  }
+  float total = 0.0f;
+  for (int j = 0; j <= kmax; j++) total += U0[j] * U0[j];            // float += double
+  for (int i = 0; i < n; i++) {
+    float h = 0.0f;
+    for (int j = 0; j <= kmax; j++) h += U0[j] * tapers[(size_t)j * n + i];
+    hn[i] = h / total;
+  }
+  *sum_U0_sqr = total;
+}
+
 }  // namespace glfer

@@ -1,0 +1,497 @@
+// ingest.cpp -- host samples in, host rows out: the file / buffer source of source.c:118-158 in
+// front of the batch estimator, and the multi-GPU entry.
+//
+// A job covers a contiguous frame range of one stream on one GPU.  It runs in chunks of whole frames
+// through a two-deep ring: two pinned sample buffers, two device sample buffers, two device row
+// buffers, two pinned row buffers and TWO STREAMS, chunk c on stream c mod 2, so chunk c+1's
+// upload runs while chunk c computes and downloads.  Every chunk's sample buffer starts with the
+// history it needs (the N-H overlap rounded up to whole hops, plus lmp_av-1 hops in LMP mode),
+// taken from the tail of the previous chunk's pinned buffer, and the kernels are handed the
+// stream's VIRTUAL base address, so frame indices -- and the zero history of the very first frames
+// -- come out as in a one-shot run.  Rows go straight into the caller's memory when it is pinned
+// (glfer_hip_host_alloc), otherwise through the pinned row buffers and a host copy.
+#include "plan.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+using glfer::DeviceGuard;
+using glfer::hip_fail;
+
+namespace {
+
+size_t sample_bytes(int fmt) { return fmt == GLFER_SAMPLES_F32 ? 4 : (fmt == GLFER_SAMPLES_S16 ? 2 : 1); }
+
+// memcpy spread over a few threads: the destination is usually fresh pageable memory, where the
+// page faults, not the copy, set the pace
+void copy_wide(void *dst, const void *src, size_t bytes) {
+  const size_t kMin = (size_t)8 << 20;
+  unsigned nt = bytes < 2 * kMin ? 1u : (unsigned)std::min<size_t>(8, bytes / kMin);
+  const unsigned hw = std::thread::hardware_concurrency();
+  if (hw && nt > hw) nt = hw;
+  if (nt <= 1) { memcpy(dst, src, bytes); return; }
+  std::vector<std::thread> th;
+  const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+  size_t done = 0;                               // bytes handed to threads so far
+  try {
+    for (unsigned i = 0; i + 1 < nt && done + per < bytes; i++) {
+      const size_t off = done;
+      th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, per); });
+      done += per;
+    }
+  } catch (...) {                                // no more threads to be had: this one copies the rest
+  }
+  memcpy((char *)dst + done, (const char *)src + done, bytes - done);
+  for (auto &t : th) t.join();
+}
+
+bool is_pinned_host(const void *p) {
+  hipPointerAttribute_t at;
+  if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+// What a job writes per frame.  PSD: bins floats.  Waterfall: the display mapping of
+// main_window_draw (g_main.c:1099-1236) applied on the device -- bins*3 RGB bytes (+ bins shorts of
+// levbuf) -- so 3-5 bytes per bin cross PCIe instead of 4, and the caller gets pixels.
+struct Sink {
+  float *h_psd = nullptr;
+  glfer_hip_display *disp = nullptr;     // waterfall mode when set
+  unsigned char *h_rgb = nullptr;
+  short *h_lev = nullptr;
+};
+
+struct Job {
+  glfer_hip_plan *p = nullptr;
+  size_t frame_lo = 0, frames = 0;       // global frame range [frame_lo, frame_lo + frames)
+  long tail_fresh = -1;                  // >= 0: the last frame is the file's trailing partial block with this many fresh samples
+  size_t chunk_frames = 0;               // 0 = default
+  // fills dst with whole hops [hop_index, hop_index + nhops) of the stream, raw sample format;
+  // returns the hops delivered (fewer only at the end of a file)
+  std::function<size_t(unsigned char *dst, size_t hop_index, size_t nhops)> read;
+  Sink sink;                             // rows of frame f go to index f - frame_lo
+};
+
+int run_job(const Job &job, size_t *frames_done) {
+  glfer_hip_plan *p = job.p;
+  *frames_done = 0;
+  if (job.frames == 0) return GLFER_OK;
+  const size_t esz = sample_bytes(p->cfg.sample_format);
+  const size_t hop = (size_t)p->hop, bins = (size_t)p->bins;
+  // history in front of every chunk: whole hops covering the N-H overlap (per-hop means need
+  // complete hops), plus the frames the LMP ring reaches back
+  const size_t halo_hops = (size_t)((p->keep + p->hop - 1) / p->hop) +
+                           (p->cfg.mode == GLFER_MODE_LMP ? (size_t)p->lmp_av - 1 : 0);
+  size_t chunk = job.chunk_frames;
+  if (chunk == 0) {                                            // default: 16384 frames, at most 256 MiB of samples
+    chunk = 16384;
+    const size_t cap = ((size_t)256 << 20) / (hop * esz);
+    if (chunk > cap) chunk = cap;
+  }
+  if (chunk < 1) chunk = 1;
+  chunk = (chunk + GLFER_FRAME_ALIGN - 1) / GLFER_FRAME_ALIGN * GLFER_FRAME_ALIGN;   // see launch_by_n
+  // chunk boundaries sit on GLOBAL multiples of GLFER_FRAME_ALIGN: the first chunk of a job that
+  // starts off the grid is shortened to reach it
+  const bool waterfall = job.sink.disp != nullptr;
+  const size_t row_bytes = waterfall ? bins * 3 : bins * sizeof(float);
+
+  DeviceGuard guard(p->cfg.device);
+  HIP_TRY(guard.error());
+  const bool direct_out = waterfall ? is_pinned_host(job.sink.h_rgb) && (!job.sink.h_lev || is_pinned_host(job.sink.h_lev))
+                                    : is_pinned_host(job.sink.h_psd);
+  unsigned char *h_in[2] = {nullptr, nullptr}, *d_in[2] = {nullptr, nullptr};
+  unsigned char *h_out[2] = {nullptr, nullptr};
+  short *h_lev[2] = {nullptr, nullptr};
+  float *d_psd[2] = {nullptr, nullptr}, *d_stats[2] = {nullptr, nullptr};
+  unsigned char *d_rgb[2] = {nullptr, nullptr};
+  short *d_lev[2] = {nullptr, nullptr};
+  hipStream_t st[2] = {nullptr, nullptr};
+  const size_t in_bytes = (halo_hops + chunk + 1) * hop * esz;       // + 1: a trailing partial block rides on the last chunk
+  const size_t rows_cap = chunk + 1;
+  hipError_t e = hipSuccess;
+  for (int b = 0; b < 2 && e == hipSuccess; b++) {
+    e = hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h_in[b], in_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_in[b], in_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_psd[b], rows_cap * bins * sizeof(float));
+    if (e == hipSuccess && !direct_out) e = hipHostMalloc((void **)&h_out[b], rows_cap * row_bytes, hipHostMallocDefault);
+    if (e == hipSuccess && waterfall) {
+      e = hipMalloc((void **)&d_stats[b], rows_cap * 4 * sizeof(float));
+      if (e == hipSuccess) e = hipMalloc((void **)&d_rgb[b], rows_cap * bins * 3);
+      if (e == hipSuccess && job.sink.h_lev) {
+        e = hipMalloc((void **)&d_lev[b], rows_cap * bins * sizeof(short));
+        if (e == hipSuccess && !direct_out) e = hipHostMalloc((void **)&h_lev[b], rows_cap * bins * sizeof(short), hipHostMallocDefault);
+      }
+    }
+  }
+  int rc = (e == hipSuccess) ? GLFER_OK : hip_fail(e, "ingest: allocate");
+
+  struct Pending { size_t first = 0, nf = 0; bool live = false; } pend[2];
+  // hands chunk b's rows to the caller (after its stream has drained)
+  auto drain = [&](int b) -> int {
+    if (!pend[b].live) return GLFER_OK;
+    hipError_t err = hipStreamSynchronize(st[b]);
+    pend[b].live = false;
+    if (err != hipSuccess) return hip_fail(err, "ingest: chunk");
+    if (!direct_out) {
+      const size_t off = pend[b].first - job.frame_lo, nf = pend[b].nf;
+      if (waterfall) {
+        copy_wide(job.sink.h_rgb + off * bins * 3, h_out[b], nf * bins * 3);
+        if (job.sink.h_lev) copy_wide(job.sink.h_lev + off * bins, h_lev[b], nf * bins * sizeof(short));
+      } else {
+        copy_wide(job.sink.h_psd + off * bins, h_out[b], nf * bins * sizeof(float));
+      }
+    }
+    *frames_done = pend[b].first - job.frame_lo + pend[b].nf;
+    return GLFER_OK;
+  };
+
+  const size_t frame_hi = job.frame_lo + job.frames;
+  size_t cf = job.frame_lo;                        // first frame of the chunk being prepared
+  size_t prev_lo_hop = 0, prev_hops = 0;           // what the previous chunk's pinned buffer holds
+  int b = 0;
+  bool ended = false;                              // the reader ran dry (a file shorter than announced)
+  while (rc == GLFER_OK && cf < frame_hi && !ended) {
+    size_t nf = std::min(chunk - cf % chunk, frame_hi - cf);
+    if (job.tail_fresh >= 0 && cf + nf + 1 == frame_hi) nf++;       // never leave the partial block alone in a chunk
+    const size_t lo_hop = cf > halo_hops ? cf - halo_hops : 0;       // first hop the chunk's buffer holds
+    rc = drain(b);                                 // buffer set b is free once chunk c-2 is out
+    if (rc) break;
+    // history: from the previous chunk's pinned buffer where it has it, else from the reader
+    size_t have = 0;                               // hops of [lo_hop, cf) copied so far
+    const int pb = b ^ 1;
+    if (prev_hops && lo_hop >= prev_lo_hop && lo_hop < prev_lo_hop + prev_hops) {
+      const size_t from = lo_hop - prev_lo_hop;
+      have = std::min(cf - lo_hop, prev_hops - from);
+      memcpy(h_in[b], h_in[pb] + from * hop * esz, have * hop * esz);
+    }
+    if (lo_hop + have < cf) {
+      const size_t want = cf - lo_hop - have;
+      if (job.read(h_in[b] + have * hop * esz, lo_hop + have, want) != want) { rc = GLFER_E_ARG; break; }
+    }
+    const size_t got = job.read(h_in[b] + (cf - lo_hop) * hop * esz, cf, nf);
+    if (got < nf) { nf = got; ended = true; }
+    if (nf == 0) break;
+    const bool has_tail = job.tail_fresh >= 0 && cf + nf == frame_hi;
+    const size_t up_hops = cf - lo_hop + nf;
+    e = hipMemcpyAsync(d_in[b], h_in[b], up_hops * hop * esz, hipMemcpyHostToDevice, st[b]);
+    if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
+    const unsigned char *vbase = d_in[b] - lo_hop * hop * esz;       // virtual address of stream sample 0
+    rc = glfer_run_device(p, vbase, (cf + nf) * hop, cf, nf, d_psd[b], nullptr, st[b], has_tail ? job.tail_fresh : -1);
+    if (rc) break;
+    if (waterfall) {
+      rc = glfer_hip_floor_device(d_psd[b], nf, (int)bins, d_stats[b], st[b]);
+      if (rc) break;
+      // the level tracking carries its state from column to column (g_main.c:1081, 1111-1124): the
+      // display call reads it back, so the previous chunk's display must have finished -- its
+      // stream is drained by that call itself (glfer_hip_display_device synchronises)
+      rc = glfer_hip_display_device(job.sink.disp, d_psd[b], nullptr, d_stats[b], nf, (int)bins, d_rgb[b], d_lev[b], nullptr, st[b]);
+      if (rc) break;
+      unsigned char *dst = direct_out ? job.sink.h_rgb + (cf - job.frame_lo) * bins * 3 : h_out[b];
+      e = hipMemcpyAsync(dst, d_rgb[b], nf * bins * 3, hipMemcpyDeviceToHost, st[b]);
+      if (e == hipSuccess && job.sink.h_lev) {
+        short *ldst = direct_out ? job.sink.h_lev + (cf - job.frame_lo) * bins : h_lev[b];
+        e = hipMemcpyAsync(ldst, d_lev[b], nf * bins * sizeof(short), hipMemcpyDeviceToHost, st[b]);
+      }
+    } else {
+      float *dst = direct_out ? job.sink.h_psd + (cf - job.frame_lo) * bins : reinterpret_cast<float *>(h_out[b]);
+      e = hipMemcpyAsync(dst, d_psd[b], nf * bins * sizeof(float), hipMemcpyDeviceToHost, st[b]);
+    }
+    if (e != hipSuccess) { rc = hip_fail(e, "ingest: download"); break; }
+    pend[b].first = cf;
+    pend[b].nf = nf;
+    pend[b].live = true;
+    prev_lo_hop = lo_hop;
+    prev_hops = up_hops;
+    cf += nf;
+    b ^= 1;
+  }
+  // the two chunks still in flight, oldest first
+  if (rc == GLFER_OK) rc = drain(b);
+  if (rc == GLFER_OK) rc = drain(b ^ 1);
+  for (int i = 0; i < 2; i++) {
+    if (st[i]) (void)hipStreamSynchronize(st[i]);
+    if (h_in[i]) (void)hipHostFree(h_in[i]);
+    if (h_out[i]) (void)hipHostFree(h_out[i]);
+    if (h_lev[i]) (void)hipHostFree(h_lev[i]);
+    if (d_in[i]) (void)hipFree(d_in[i]);
+    if (d_psd[i]) (void)hipFree(d_psd[i]);
+    if (d_stats[i]) (void)hipFree(d_stats[i]);
+    if (d_rgb[i]) (void)hipFree(d_rgb[i]);
+    if (d_lev[i]) (void)hipFree(d_lev[i]);
+    if (st[i]) (void)hipStreamDestroy(st[i]);
+  }
+  return rc;
+}
+
+// reader over a host array of whole hops
+std::function<size_t(unsigned char *, size_t, size_t)> array_reader(const void *h_stream, size_t hop_bytes) {
+  return [=](unsigned char *dst, size_t hop_index, size_t nhops) {
+    copy_wide(dst, (const unsigned char *)h_stream + hop_index * hop_bytes, nhops * hop_bytes);
+    return nhops;
+  };
+}
+
+// The frame range of rank r of `world` (the arithmetic of glfer_amd/shard.py frame_range): the
+// stream is dealt out in units of GLFER_FRAME_ALIGN frames, the remainder units to the low ranks.
+void frame_range(size_t total, unsigned rank, unsigned world, size_t *first, size_t *count) {
+  const size_t align = GLFER_FRAME_ALIGN;
+  const size_t units = (total + align - 1) / align;
+  const size_t base = units / world, rem = units % world;
+  const size_t u_first = rank * base + std::min<size_t>(rank, rem);
+  const size_t u_count = base + (rank < rem ? 1 : 0);
+  const size_t lo = std::min(total, u_first * align), hi = std::min(total, (u_first + u_count) * align);
+  *first = lo;
+  *count = hi - lo;
+}
+
+}  // namespace
+
+extern "C" {
+
+void *glfer_hip_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void glfer_hip_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
+void glfer_hip_frame_range(size_t total_frames, unsigned rank, unsigned world, size_t *first, size_t *count) {
+  size_t f = 0, c = 0;
+  if (world && rank < world) frame_range(total_frames, rank, world, &f, &c);
+  if (first) *first = f;
+  if (count) *count = c;
+}
+
+int glfer_hip_spectrogram_host(glfer_hip_plan *p, const void *h_stream, size_t nsamples, float *h_psd,
+                               size_t *nframes_out) {
+  if (!p || !h_stream || !nframes_out) return GLFER_E_ARG;
+  const size_t frames = nsamples / (size_t)p->hop;
+  *nframes_out = frames;
+  if (frames == 0) return GLFER_OK;
+  if (!h_psd) return GLFER_E_ARG;
+  const size_t esz = sample_bytes(p->cfg.sample_format);
+  const size_t hop_bytes = (size_t)p->hop * esz;
+  if (frames * hop_bytes + frames * (size_t)p->bins * sizeof(float) < ((size_t)4 << 20)) {
+    // a few megabytes: one copy each way costs less than setting the pipeline up
+    DeviceGuard guard(p->cfg.device);
+    HIP_TRY(guard.error());
+    const size_t used = frames * (size_t)p->hop;
+    void *d_in = nullptr;
+    float *d_out = nullptr;
+    int rc = GLFER_OK;
+    hipError_t e = hipMalloc(&d_in, used * esz);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, frames * (size_t)p->bins * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_in, h_stream, used * esz, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: staging");
+    if (rc == GLFER_OK) rc = glfer_run_device(p, d_in, used, 0, frames, d_out, nullptr, nullptr);
+    if (rc == GLFER_OK) {
+      e = hipMemcpy(h_psd, d_out, frames * (size_t)p->bins * sizeof(float), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = hip_fail(e, "spectrogram_host: copy back");
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+  }
+  Job job;
+  job.p = p;
+  job.frames = frames;
+  job.read = array_reader(h_stream, hop_bytes);
+  job.sink.h_psd = h_psd;
+  return run_job(job, nframes_out);
+}
+
+// Host samples -> RGB waterfall columns (and levbuf): estimator, compute_floor and the display
+// mapping on the device, 3 (+2) bytes per bin back over PCIe.
+int glfer_hip_waterfall_host(glfer_hip_plan *p, glfer_hip_display *disp, const void *h_stream, size_t nsamples,
+                             unsigned char *h_rgb, short *h_lev, size_t *nframes_out) {
+  if (!p || !disp || !h_stream || !nframes_out) return GLFER_E_ARG;
+  if (disp->scale_type < GLFER_SCALE_LIN || disp->scale_type > GLFER_SCALE_LOG_MAX0) return GLFER_E_ARG;
+  const size_t frames = nsamples / (size_t)p->hop;
+  *nframes_out = frames;
+  if (frames == 0) return GLFER_OK;
+  if (!h_rgb) return GLFER_E_ARG;
+  Job job;
+  job.p = p;
+  job.frames = frames;
+  job.read = array_reader(h_stream, (size_t)p->hop * sample_bytes(p->cfg.sample_format));
+  job.sink.disp = disp;
+  job.sink.h_rgb = h_rgb;
+  job.sink.h_lev = h_lev;
+  return run_job(job, nframes_out);
+}
+
+// ---- multi-GPU: source.c:130-158 over one stream, the frame range dealt out over the GPUs of the
+// node.  One host thread per GPU, each with its own plan, streams and pinned ring (run_job); the
+// ranges come from the same arithmetic as glfer_amd/shard.py; rows land in disjoint ranges of
+// h_psd; nothing is exchanged between GPUs.
+int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned device_mask, const void *h_stream,
+                                     size_t nsamples, float *h_psd, size_t *nframes_out) {
+  if (!cfg || !h_stream || !nframes_out || device_mask == 0) return GLFER_E_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return hip_fail(hipGetLastError(), "hipGetDeviceCount");
+  std::vector<int> devs;
+  for (int d = 0; d < 32; d++)
+    if (device_mask & (1u << d)) {
+      if (d >= ndev) return GLFER_E_ARG;
+      devs.push_back(d);
+    }
+  // hop and bins as every plan will compute them (fft.c:70)
+  const int hop = (int)(cfg->n * (1.0 - cfg->overlap));
+  if (hop <= 0) return GLFER_E_ARG;
+  const size_t frames = nsamples / (size_t)hop, bins = (size_t)cfg->n / 2 + 1;
+  *nframes_out = frames;
+  if (frames == 0) return GLFER_OK;
+  if (!h_psd) return GLFER_E_ARG;
+  const unsigned world = (unsigned)devs.size();
+  const size_t hop_bytes = (size_t)hop * sample_bytes(cfg->sample_format);
+  std::vector<int> rcs(world, GLFER_OK);
+  std::vector<std::string> msgs(world);
+  std::vector<size_t> done(world, 0);
+  auto work = [&](unsigned r) {
+    size_t first = 0, count = 0;
+    frame_range(frames, r, world, &first, &count);
+    if (count == 0) return;
+    glfer_hip_config c = *cfg;
+    c.device = devs[r];
+    glfer_hip_plan *plan = nullptr;
+    int rc = glfer_hip_plan_create(&c, &plan);
+    if (rc == GLFER_OK) {
+      Job job;
+      job.p = plan;
+      job.frame_lo = first;
+      job.frames = count;
+      job.read = array_reader(h_stream, hop_bytes);
+      job.sink.h_psd = h_psd + first * bins;
+      rc = run_job(job, &done[r]);
+      if (rc == GLFER_OK && done[r] != count) rc = GLFER_E_HIP;
+    }
+    if (rc) msgs[r] = glfer::error_text();
+    glfer_hip_plan_destroy(plan);
+    rcs[r] = rc;
+  };
+  std::vector<std::thread> th;
+  for (unsigned r = 1; r < world; r++) {
+    try {
+      th.emplace_back(work, r);
+    } catch (...) {
+      work(r);                                   // no thread to be had: this one does that share too
+    }
+  }
+  work(0);
+  for (auto &t : th) t.join();
+  for (unsigned r = 0; r < world; r++)
+    if (rcs[r]) {
+      glfer::set_error_text(msgs[r]);
+      return rcs[r];
+    }
+  return GLFER_OK;
+}
+
+// ---- ingest (wav_fmt.c:45-121, source.c:118-128) ------------------------------------------
+static unsigned rd_u16(const unsigned char *b) { return b[0] | (b[1] << 8); }
+static unsigned rd_u32(const unsigned char *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24); }
+
+int glfer_hip_wav_probe(const char *path, glfer_wav_info *info) {
+  if (!path || !info) return GLFER_E_ARG;
+  FILE *f = fopen(path, "rb");
+  if (!f) return GLFER_E_ARG;                                    // wav_fmt.c:53-56 exits; we report
+  unsigned char hd[44];
+  const size_t got = fread(hd, 1, sizeof hd, f);
+  long end = 0;
+  if (fseek(f, 0, SEEK_END) == 0) end = ftell(f);
+  fclose(f);
+  if (got < sizeof hd) return GLFER_E_ARG;                       // "input file less than 20 bytes long", wav_fmt.c:61-62
+  if (memcmp(hd, "RIFF", 4) != 0) return GLFER_E_ARG;            // "input file not in WAV format", wav_fmt.c:63-64
+  info->format = (int)rd_u16(hd + 20);                           // wav_fmt.h:42
+  info->channels = (int)rd_u16(hd + 22);                         // wav_fmt.h:43
+  info->sample_rate = (int)rd_u32(hd + 24);                      // wav_fmt.h:44  -> *speed, wav_fmt.c:70
+  info->bits_per_sample = (int)rd_u16(hd + 34);                  // wav_fmt.h:47  -> bits, wav_fmt.c:71
+  info->data_offset = 44;
+  if (info->format != 1) return GLFER_E_ARG;                     // "input is not a PCM WAV file", wav_fmt.c:68-69
+  if (info->bits_per_sample != 8 && info->bits_per_sample != 16) return GLFER_E_ARG;   // wav_fmt.c:87-96 handles only these
+  const size_t avail = end > 44 ? (size_t)(end - 44) : 0;
+  info->data_bytes = avail;
+  info->nsamples = avail / (size_t)(info->bits_per_sample / 8);  // the reference reads until read() returns 0
+  return GLFER_OK;
+}
+
+int glfer_hip_spectrogram_wav_ex(glfer_hip_plan *p, const char *path, float *h_psd, size_t max_frames,
+                                 size_t *nframes_out, size_t chunk_frames, unsigned flags) {
+  if (!p || !path || !nframes_out || (flags & ~(unsigned)GLFER_WAV_PARTIAL_TAIL)) return GLFER_E_ARG;
+  glfer_wav_info wi;
+  int rc = glfer_hip_wav_probe(path, &wi);
+  if (rc) return rc;
+  const int fmt = wi.bits_per_sample == 8 ? GLFER_SAMPLES_U8 : GLFER_SAMPLES_S16;
+  if (p->cfg.sample_format != fmt) return GLFER_E_ARG;
+  const size_t esz = (size_t)wi.bits_per_sample / 8, hop = (size_t)p->hop, hop_bytes = hop * esz;
+  const size_t whole = wi.data_bytes / hop_bytes;                // full blocks, wav_fmt.c:102
+  // wav_fmt.c:102-119: a short last read still counts as a block (n_read != 0) and converts
+  // n_read (8 bit) or n_read/2 (16 bit: an odd last byte is dropped) samples over the stale rest
+  const size_t rest = wi.data_bytes - whole * hop_bytes;
+  const bool tail = (flags & GLFER_WAV_PARTIAL_TAIL) && rest > 0 && p->cfg.mode != GLFER_MODE_LMP;
+  const size_t fresh = rest / esz;
+  size_t frames = whole + (tail ? 1 : 0);
+  bool with_tail = tail;
+  if (frames > max_frames) { frames = max_frames; with_tail = false; }
+  *nframes_out = frames;
+  if (frames == 0) return GLFER_OK;
+  if (!h_psd) return GLFER_E_ARG;
+  FILE *f = fopen(path, "rb");
+  if (!f) return GLFER_E_ARG;
+  Job job;
+  job.p = p;
+  job.frames = frames;
+  job.chunk_frames = chunk_frames;
+  // (a partial block with no fresh sample at all -- one odd byte of a 16-bit file -- is the previous
+  // block over again: tail_fresh = 0)
+  job.tail_fresh = with_tail ? (long)fresh : -1;
+  job.sink.h_psd = h_psd;
+  const size_t data_offset = wi.data_offset;
+  job.read = [=](unsigned char *dst, size_t hop_index, size_t nhops) -> size_t {
+    if (fseek(f, (long)(data_offset + hop_index * hop_bytes), SEEK_SET) != 0) return 0;
+    const size_t full = hop_index + nhops <= whole ? nhops : (hop_index < whole ? whole - hop_index : 0);
+    if (fread(dst, 1, full * hop_bytes, f) != full * hop_bytes) return 0;
+    if (full == nhops) return nhops;
+    if (!with_tail || hop_index + nhops != whole + 1) return full;
+    // the trailing partial block: its fresh samples, then the RAW samples of the block before at
+    // the same positions (zeros -- the calloc of wav_fmt.c:99 -- for a file shorter than one block).
+    // With per-hop mean removal the device replaces the stale part by the corrected previous hop.
+    unsigned char *last = dst + full * hop_bytes;
+    if (whole == 0) {
+      memset(last, esz == 1 ? 0x80 : 0, hop_bytes);               // sample value 0.0 (u8: 128)
+    } else if (full > 0) {
+      memcpy(last, last - hop_bytes, hop_bytes);
+    } else {
+      if (fseek(f, (long)(data_offset + (whole - 1) * hop_bytes), SEEK_SET) != 0) return full;
+      if (fread(last, 1, hop_bytes, f) != hop_bytes) return full;
+      if (fseek(f, (long)(data_offset + whole * hop_bytes), SEEK_SET) != 0) return full;
+    }
+    if (fresh && fread(last, 1, fresh * esz, f) != fresh * esz) return full;
+    return nhops;
+  };
+  rc = run_job(job, nframes_out);
+  fclose(f);
+  return rc;
+}
+
+int glfer_hip_spectrogram_wav(glfer_hip_plan *p, const char *path, float *h_psd, size_t max_frames,
+                              size_t *nframes_out, size_t chunk_frames) {
+  return glfer_hip_spectrogram_wav_ex(p, path, h_psd, max_frames, nframes_out, chunk_frames, 0);
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// plan.h -- what the translation units of the C-ABI layer share: the plan (fft_init / mtm_init
+// state, fft.c:168-187, mtm.c:88-151), error plumbing and the device guard.  Internal.
+#pragma once
+#include "../../include/glfer_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace glfer {
+
+int hip_fail(hipError_t e, const char *what);      // records the text for glfer_hip_last_hip_error(), returns GLFER_E_HIP
+std::string error_text();                          // this thread's recorded text
+void set_error_text(const std::string &text);      // (worker threads hand theirs to the calling thread)
+
+// Every entry point runs on the device its plan (or its data) lives on and leaves the caller's
+// current device as it found it (torch reads it through hipGetDevice).
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+    err_ = (device == prev_) ? hipSuccess : hipSetDevice(device);
+    changed_ = err_ == hipSuccess && device != prev_;
+  }
+  ~DeviceGuard() {
+    if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_);
+  }
+  hipError_t error() const { return err_; }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+
+ private:
+  int prev_ = -1;
+  bool changed_ = false;
+  hipError_t err_ = hipSuccess;
+};
+
+// the device a device pointer belongs to (-1: not a device pointer HIP knows)
+int device_of(const void *d_ptr);
+
+}  // namespace glfer
+
+#define HIP_TRY(call)                                          \
+  do {                                                         \
+    hipError_t e_ = (call);                                    \
+    if (e_ != hipSuccess) return glfer::hip_fail(e_, #call);   \
+  } while (0)
+
+struct glfer_hip_plan {
+  glfer_hip_config cfg;
+  int n, hop, keep, bins, ntapers, npairs, lanes;
+  int lmp_av = 0;                   // LMP mode: periodograms in the ring (lmp.c:85)
+  std::vector<float> window;        // [n] as the reference stores it (unit power)
+  std::vector<double> tapers;       // [ntapers][n]
+  std::vector<double> sig;          // [ntapers]
+  float *d_taps = nullptr;          // [npairs][8][n/16][4] scaled tables (tap_slot)
+  float *d_window = nullptr;        // [n] the window itself (FFT mode, not rectangular): prepare_audio's multiply
+  float2 *d_tw = nullptr;           // [slots][lanes]
+  float *d_htaps = nullptr;         // real-input form (spectro16h.hip): window pairs, [htapers][8][n/32][4]
+  int htapers = 0;                  // 1: periodogram window; > 1: the tapers of the multitaper form (n >= 8192)
+  float2 *d_htw = nullptr;          //   twiddles of the n/2-point transform
+  float2 *d_hrot = nullptr;         //   (cos,sin)(2 pi t/n), t < n/32
+  float *d_xtaps = nullptr;         // odd taper counts (spectro16x.hip): the last taper alone, [4][n/16][4]
+  float *d_ltaps = nullptr;         // odd taper counts, LDS-resident half tables (spectro16xl.hip)
+  uint16_t *d_lagmap = nullptr;     // HP-ARMA: [t][p_e+1] lag held by each matrix cell
+  float2 *d_unit = nullptr;         // HP-ARMA: [n/2+1] exp(-2 pi i k/n)
+  // harmonic F-test (mtm.c:124-136): built on first use
+  float *d_ftaps = nullptr;         // [ntapers+1][2n]: taper j (and hn, last) alone in slot 0 of the packed layout
+  double *d_U0 = nullptr;           // [ntapers]
+  std::vector<double> U0;           // [ntapers]
+  std::vector<float> hn;            // [n]
+  float sum_U0_sqr = 0.0f;
+  float spec_unscale = 1.0f;
+  bool nonlin = false;
+};
+
+// frames [first, first+nframes) of a device-resident stream (virtual base allowed); psd and/or
+// halfcomplex spectra out.  Asynchronous on `st`.  Defined in glfer_hip.cpp.
+// tail_fresh >= 0: the LAST frame of the call is the file source's trailing partial block with that
+// many fresh samples (wav_fmt.c:102-119); see glfer_hip_spectrogram_wav_ex.
+int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first, size_t nframes,
+                     float *d_psd, float *d_spec, hipStream_t st, long tail_fresh = -1);

@@ -266,6 +266,30 @@ __global__ __launch_bounds__(256) void submean_kernel(const void *in, float *out
   for (int i = threadIdx.x; i < H; i += 256) dst[i] = cvt_sample<FMT>(src, (unsigned)i) - mean;
 }
 
+// The file source's trailing partial block (wav_fmt.c:102-119): `fresh` new samples over the stale
+// tail of the reader's buffer, which holds the PREVIOUS block as prepare_audio left it -- mean
+// removed in place (fft.c:93-95); prev = that corrected hop (NULL: the buffer was never filled,
+// calloc zeros, wav_fmt.c:99).  Then this block's own mean removal.  One block.
+template <int FMT>
+__global__ __launch_bounds__(256) void submean_tail_kernel(const void *raw_last, const float *prev, float *out, int H,
+                                                           int fresh) {
+  __shared__ float part[256];
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < H; i += 256) {
+    const float v = i < fresh ? cvt_sample<FMT>(raw_last, (unsigned)i) : (prev ? prev[i] : 0.0f);
+    out[i] = v;
+    s += v;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  const float mean = part[0] / (float)H;
+  for (int i = threadIdx.x; i < H; i += 256) out[i] -= mean;       // each thread revisits its own elements
+}
+
 }  // namespace glfer
 
 // ---------------------------------------------------------------------------
@@ -314,6 +338,17 @@ extern "C" hipError_t glfer_launch_submean(const void *in, float *out, int H, lo
     case GLFER_FMT_F32: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_F32>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
     case GLFER_FMT_S16: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_S16>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
     case GLFER_FMT_U8: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_U8>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t glfer_launch_submean_tail(const void *raw_last, const float *prev, float *out, int H, int fresh,
+                                                int fmt, hipStream_t st) {
+  switch (fmt) {
+    case GLFER_FMT_F32: hipLaunchKernelGGL((submean_tail_kernel<GLFER_FMT_F32>), dim3(1), dim3(256), 0, st, raw_last, prev, out, H, fresh); break;
+    case GLFER_FMT_S16: hipLaunchKernelGGL((submean_tail_kernel<GLFER_FMT_S16>), dim3(1), dim3(256), 0, st, raw_last, prev, out, H, fresh); break;
+    case GLFER_FMT_U8: hipLaunchKernelGGL((submean_tail_kernel<GLFER_FMT_U8>), dim3(1), dim3(256), 0, st, raw_last, prev, out, H, fresh); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

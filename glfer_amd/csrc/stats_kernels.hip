@@ -1,0 +1,161 @@
+// stats_kernels.hip -- per-bin epilogues over spectra the estimator kernels have produced, and the
+// frame-preparation kernel.  Built with -ffp-contract=off: the float/double expression order of
+// the reference IS the contract here (every statement below is the reference's statement with the
+// same operand types).
+//   lmp_kernel      lmp.c:132-160   detection statistic over the ring of the last nl periodograms
+//   ftest_kernel    mtm.c:203-210, 222-233   harmonic F statistic from the tapered spectra and mu
+//   prepare_kernel  fft.c:98-156    what prepare_audio leaves in inbuf_fft, for a batch of frames
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "spectro_params.h"
+
+namespace glfer {
+
+// One thread per (frame, bin).  rows: periodograms of frames [row0, row0 + nrows) (global frame
+// indices), [nrows][bins]; out: frames [first, first + nframes).  The reference keeps the last nl
+// periodograms in a ring written round-robin (slot = frame mod nl, zero before its first write)
+// and sums over the SLOTS in slot order; slot j of frame f holds frame f - ((f - j) mod nl).
+__global__ __launch_bounds__(256) void lmp_kernel(const float *__restrict__ rows, long long row0, long long first,
+                                                  long long nframes, int bins, int nl, float *__restrict__ out) {
+  const long long fi = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (fi >= nframes || i >= bins) return;
+  const long long f = first + fi;
+  float *o = out + (size_t)fi * bins;
+  if (i == 0) {                                                    // lmp.c:160
+    o[0] = 1e-3;
+    return;
+  }
+  const int jl = (int)(f % nl);
+  double my = 0.0;                                                 // lmp.c:134-140
+  for (int j = 0; j < nl; j++) {
+    const long long g = f - (long long)((jl - j + nl) % nl);
+    const float v = g >= 0 ? rows[(size_t)(g - row0) * bins + i] : 0.0f;
+    my += v;
+  }
+  my /= nl;
+  double sy = 0.0;                                                 // lmp.c:143-149
+  for (int j = 0; j < nl; j++) {
+    const long long g = f - (long long)((jl - j + nl) % nl);
+    const float v = g >= 0 ? rows[(size_t)(g - row0) * bins + i] : 0.0f;
+    sy += (v - my) * (v - my);
+  }
+  sy /= (nl - 1);
+  double v_hat = my * my - sy;                                     // lmp.c:153-159
+  if (v_hat < 0.0) v_hat = 0.0;
+  v_hat = 0.5 * (my - sqrt(v_hat));
+  float r = -sqrt(nl / 2.0) + (nl * my) / (2.0 * sqrt(2.0 * nl) * v_hat);
+  if (r <= 1.0e-3) r = 1e-3;
+  o[i] = r;
+}
+
+// One thread per (frame, bin).  spec: [ntap + 1][nframes][n] halfcomplex spectra (fft_radix2.c
+// layout) of the frame under taper j, the last one under hn (mu); mu_live = 0: mu is all zeros (the
+// reference build without FFTW never writes it, mtm.c:173).
+__global__ __launch_bounds__(256) void ftest_kernel(const float *__restrict__ spec, long long nframes, int n, int ntap,
+                                                    const double *__restrict__ U0, float sum_U0_sqr, int mu_live,
+                                                    float *__restrict__ ftest) {
+  const long long fi = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int bins = n / 2 + 1;
+  if (fi >= nframes || i >= bins) return;
+  const int k = ntap - 1;                                          // params->kmax
+  const size_t fstride = (size_t)nframes * n;
+  const float *mu = spec + (size_t)ntap * fstride + (size_t)fi * n;
+  const float mur = mu_live ? mu[i] : 0.0f;                        // mu[i]
+  const float mui = mu_live ? mu[(n - i) % n] : 0.0f;              // mu[n_fft - i]  (i = 0: unused)
+  float ft = 0.0;                                                  // mtm.c:179-186
+  double tmpr, tmpi, num_ftest;
+  if (i < (n + 1) / 2) {
+    for (int j = 0; j < ntap; j++) {                               // mtm.c:203-210
+      const float *ob = spec + (size_t)j * fstride + (size_t)fi * n;
+      if (i == 0) {
+        tmpr = ob[0] - mur * U0[j];
+        ft += tmpr * tmpr;
+      } else {
+        tmpr = ob[i] - mur * U0[j];
+        tmpi = ob[n - i] - mui * U0[j];
+        ft += tmpr * tmpr + tmpi * tmpi;
+      }
+    }
+  }
+  if (i == 0) num_ftest = k * (mur * mur) * sum_U0_sqr;            // mtm.c:222-223
+  else num_ftest = k * (mur * mur + mui * mui) * sum_U0_sqr;       // mtm.c:225, 230 (the Nyquist bin counts mu[n/2] twice)
+  ftest[(size_t)fi * bins + i] = num_ftest / ft;
+}
+
+// prepare_audio's output (fft.c:98-156) for frames [frame0, frame0 + nframes): history / zero
+// history, RA9MB, window (NULL = rectangular: no multiply, fft.c:132,139), limiter.
+template <int FMT>
+__global__ __launch_bounds__(256) void prepare_kernel(SpectroParams p, int n, const float *__restrict__ window,
+                                                      float *__restrict__ out) {
+  const long long fi = blockIdx.x;
+  if (fi >= p.nframes) return;
+  const long long s0 = (p.frame0 + fi) * (long long)p.H - p.R;
+  constexpr int esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  const char *base = reinterpret_cast<const char *>(p.stream);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const long long s = s0 + i;
+    float x = 0.0f;
+    if (s >= 0 && !(p.history_mode && i < p.R)) {
+      if constexpr (FMT == GLFER_FMT_F32) x = *reinterpret_cast<const float *>(base + s * esz);
+      else if constexpr (FMT == GLFER_FMT_S16) x = (float)*reinterpret_cast<const short *>(base + s * esz) / 32768;
+      else x = ((float)*reinterpret_cast<const unsigned char *>(base + s) - 128) / 128;
+    }
+    float y;
+    if (p.a > 0.0) {                                               // fft.c:127-136
+      y = x / (p.a + x * x);
+      if (window) y *= window[i];
+    } else if (window) {                                           // fft.c:139-146
+      y = window[i] * x;
+    } else {                                                       // fft.c:147-148
+      y = x;
+    }
+    if (p.limiter) {                                               // fft.c:151-156
+      const float ftmp = log(fabs(y));
+      y = (y > 0 ? exp(ftmp * 0.1) : -exp(ftmp * 0.1));
+    }
+    out[(size_t)fi * n + i] = y;
+  }
+}
+
+}  // namespace glfer
+
+using namespace glfer;
+
+extern "C" hipError_t glfer_launch_lmp(const float *rows, long long row0, long long first, size_t nframes, int bins,
+                                       int nl, float *out, hipStream_t st) {
+  if (nframes == 0) return hipSuccess;
+  if (nl < 1 || bins < 1 || nframes > 65535u * 65535ull) return hipErrorInvalidValue;
+  // blockIdx.y carries the frame: at most 65535 per launch
+  for (size_t done = 0; done < nframes; done += 65535) {
+    const size_t nf = nframes - done < 65535 ? nframes - done : 65535;
+    hipLaunchKernelGGL(lmp_kernel, dim3((unsigned)((bins + 255) / 256), (unsigned)nf), dim3(256), 0, st, rows, row0,
+                       first + (long long)done, (long long)nf, bins, nl, out + done * (size_t)bins);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+extern "C" hipError_t glfer_launch_ftest(const float *spec, size_t nframes, int n, int ntap, const double *U0,
+                                         float sum_U0_sqr, int mu_live, float *ftest, hipStream_t st) {
+  if (nframes == 0) return hipSuccess;
+  if (nframes > 65535 || ntap < 1) return hipErrorInvalidValue;    // the caller chunks the frames
+  hipLaunchKernelGGL(ftest_kernel, dim3((unsigned)((n / 2 + 1 + 255) / 256), (unsigned)nframes), dim3(256), 0, st, spec,
+                     (long long)nframes, n, ntap, U0, sum_U0_sqr, mu_live, ftest);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t glfer_launch_prepare(const SpectroParams *p, int n, const float *window, float *out,
+                                           hipStream_t st) {
+  if (p->nframes <= 0) return hipSuccess;
+  const dim3 grid((unsigned)p->nframes), block(256);
+  switch (p->fmt) {
+    case GLFER_FMT_F32: hipLaunchKernelGGL(prepare_kernel<GLFER_FMT_F32>, grid, block, 0, st, *p, n, window, out); break;
+    case GLFER_FMT_S16: hipLaunchKernelGGL(prepare_kernel<GLFER_FMT_S16>, grid, block, 0, st, *p, n, window, out); break;
+    case GLFER_FMT_U8: hipLaunchKernelGGL(prepare_kernel<GLFER_FMT_U8>, grid, block, 0, st, *p, n, window, out); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}

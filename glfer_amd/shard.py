@@ -35,11 +35,13 @@ def halo_samples(hop, n, history_mode=0):
     return -(-(n - hop) // hop) * hop
 
 
-def sample_window(first, count, hop, n, history_mode=0):
-    """[begin, end) of the stream samples the frames [first, first+count) read."""
+def sample_window(first, count, hop, n, history_mode=0, extra_frames=0):
+    """[begin, end) of the stream samples the frames [first, first+count) read.  extra_frames:
+    whole frames recomputed in front of the block instead of carried over a boundary -- lmp_av - 1
+    for the LMP estimator's ring (lmp.c:85), D - 1 for a moving average of depth D."""
     if count == 0:
         return 0, 0
-    begin = max(0, first * hop - halo_samples(hop, n, history_mode))
+    begin = max(0, (first - extra_frames) * hop - halo_samples(hop, n, history_mode))
     return begin, (first + count) * hop
 
 

@@ -2,8 +2,9 @@
  *
  * libglfer_compat.so exports exactly the L2 functions that source.c and g_main.c call, with
  * the reference's signatures and struct layouts, so that glfer links against it instead of
- * its fft.o / fft_radix2.o / mtm.o / g-l_dpss.o / avg.o (INTEGRATION.md shows the link line
- * and the six-line glue file).  Each call is one hop, as in the reference's main loop
+ * its fft.o / fft_radix2.o / mtm.o / g-l_dpss.o / avg.o / hparma.o / lmp.o (INTEGRATION.md
+ * shows the link line; no source change and no glue file are needed: the library reads glfer's
+ * own globals `opt` and `glfer`, see below).  Each call is one hop, as in the reference's main loop
  * (source.c:130-158): the frame is assembled in params->inbuf_audio exactly as
  * prepare_audio() does, then window/taper, FFT, |X|^2 and the taper sum run on the GPU
  * through the batch C-ABI of glfer_hip.h.  Nothing is computed by a CPU fallback; if HIP
@@ -55,6 +56,16 @@ typedef struct {
   int q_e;                      /* only -1 is supported (what source.c:375 sets) */
 } hparma_params_t;
 
+/* lmp.h:36-45 */
+typedef struct {
+  fft_params_t fft;
+  int avg;                      /* opt.lmp_av: periodograms in the ring (source.c:397) */
+  double **window;              /* unused by lmp.c */
+  double *sig;
+  float w;
+  int kmax;
+} lmp_params_t;
+
 /* avg.h:28-36 */
 typedef struct {
   int    avgwidth;
@@ -84,6 +95,11 @@ void hparma_init(hparma_params_t *params);
 void hparma_do(float *audio_buf, float *psd_buf, float *phase_buf, hparma_params_t *params);
 void hparma_close(hparma_params_t *params);
 
+/* lmp.h:48-50 */
+void lmp_init(lmp_params_t *params);
+void lmp_do(float *audio_buf, float *psd_buf, float *phase_buf, lmp_params_t *params);
+void lmp_close(lmp_params_t *params);
+
 /* avg.h:38-43 */
 void init_avg(avg_data_t *avgdata);
 void alloc_avg(avg_data_t *avgdata, int width, int depth);
@@ -94,16 +110,81 @@ double update_avg_sumextreme(avg_data_t *avgdata, int N, float *psd, int max0, i
 double update_avg_sumavg(avg_data_t *avgdata, int N, float *psd, int max0, int minbin, int maxbin,
                          int *peakbin, double *variance);
 
-/* The two globals the reference's estimators read directly: opt.autoscale at *_init
- * (fft.c:186, mtm.c:111) and glfer.first_buffer on every hop (fft.c:99).  opt_t / glfer_t
- * cannot be declared here (glfer.h drags in GTK), so the library reads them through these
- * two hooks.  They are WEAK: inside glfer the glue file of INTEGRATION.md overrides them
- * with `return opt.autoscale;` / `return glfer.first_buffer;`; stand-alone users set the
- * variables below. */
-int glfer_compat_get_autoscale(void);
-int glfer_compat_get_first_buffer(void);
-extern int glfer_compat_autoscale;      /* default 1 (glfer.c default for opt.autoscale) */
-extern int glfer_compat_first_buffer;   /* default 1 until the caller clears it, as g_main.c:1120 does */
+/* The two globals the reference's estimators read directly: opt.autoscale at *_init (fft.c:186,
+ * mtm.c:111, hparma.c:62, lmp.c:82) and glfer.first_buffer on every hop (fft.c:99).  Inside glfer
+ * they are the program's own `opt_t opt` and `glfer_t glfer` (glfer.c:56-57): the library refers
+ * to those two symbols WEAKLY and reads the fields through the layout-compatible declarations
+ * below (glfer.h:62-139 with the GTK pointer types as void*: same sizes, same offsets), so the
+ * relink needs no added source.  A program that defines neither (a stand-alone user of these
+ * entry points) sets glfer_compat_autoscale / glfer_compat_first_buffer instead.
+ * Skipped when the real glfer.h is in the translation unit. */
+#ifndef _GLFER_H_
+typedef enum { NO_AVG, AVG_SUMAVG, AVG_PLAIN, AVG_SUMEXTREME } avgmode_t;                 /* glfer.h:54-56 */
+typedef enum { SOURCE_NONE, SOUNDCARD_SOURCE, FILE_SOURCE } datasource_t;                 /* glfer.h:49-51 */
+typedef struct {                                                                          /* glfer.h:62-120 */
+  char *program_name;
+  int mode;
+  int scale_type;
+  int data_block_size;
+  float data_blocks_overlap;
+  float display_update_time;
+  float limiter_a;
+  int enable_limiter;
+  float mtm_w;
+  int mtm_k;
+  int hparma_t;
+  int hparma_p_e;
+  int lmp_av;
+  int window_type;
+  char *audio_device;
+  int sample_rate;
+  float dot_time;
+  float dfcw_gap_time;
+  int tx_mode;
+  float dash_dot_ratio;
+  float ptt_delay;
+  float sidetone_freq;
+  int sidetone;
+  float dfcw_dot_freq;
+  float dfcw_dash_freq;
+  int beacon_mode;
+  float beacon_pause;
+  int beacon_tx_pause;
+  char *ctrl_device;
+  int device_type;
+  float offset_freq;
+  float thr_level;
+  int autoscale;
+  float max_level_db;
+  float min_level_db;
+  avgmode_t averaging;
+  int avgsamples;
+  float min_avgband;
+  float max_avgband;
+  int palette;
+} opt_t;
+typedef struct {                                                                          /* glfer.h:123-139 */
+  void *tt;                     /* GtkTooltips * */
+  void *qso_menu_item;          /* GtkWidget *   */
+  void *test_menu_item;         /* GtkWidget *   */
+  int init_done;
+  int first_buffer;
+  datasource_t input_source;
+  float cpu_usage;
+  int current_mode;
+  void *scope_window;           /* GtkWidget *   */
+  float avgmax;
+  double avgvar;
+  int avgfill;
+  float peakfreq;
+  float peakval;
+  float avgtime;
+} glfer_t;
+#endif /* _GLFER_H_ */
+int glfer_compat_get_autoscale(void);      /* opt.autoscale when the program defines `opt`, else the variable below */
+int glfer_compat_get_first_buffer(void);   /* glfer.first_buffer when the program defines `glfer`, else the variable */
+extern int glfer_compat_autoscale;         /* default 1 (glfer.c:275 default for opt.autoscale) */
+extern int glfer_compat_first_buffer;      /* default 1 until the caller clears it, as g_main.c:1120 does */
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ extern "C" {
 #define GLFER_MODE_FFT 0
 #define GLFER_MODE_MTM 1
 #define GLFER_MODE_HPARMA 2
+#define GLFER_MODE_LMP 3
 
 /* window ids: fft.h:67 */
 #define GLFER_WIN_HANNING 0
@@ -82,12 +83,24 @@ typedef struct glfer_hip_config {
   int device;          /* HIP device ordinal                                            */
   int hparma_t;        /* opt.hparma_t: number of equations (rows), HP-ARMA mode (source.c:373) */
   int hparma_p_e;      /* opt.hparma_p_e: number of poles (source.c:374); q_e is fixed to -1 (source.c:375) */
+  int lmp_av;          /* opt.lmp_av: periodograms in the LMP estimator's ring (source.c:397, lmp.c:85) */
 } glfer_hip_config;
 
-/* Cut a stream into launches, chunks or shards at frame indices that are multiples of this and
- * every frame's PSD is bit-identical to the one-shot run (the multitaper kernel for odd taper
- * counts works on aligned groups of up to 32 frames). Other cuts are still correct, to rounding. */
+/* Cutting a stream into launches, chunks or shards.
+ * (1) Cut at frame indices that are multiples of GLFER_FRAME_ALIGN and every frame's PSD is
+ *     bit-identical to the one-shot run (the multitaper kernel for odd taper counts works on
+ *     aligned groups of up to 32 frames).  Other cuts are still correct, to rounding.
+ * (2) A piece that starts at frame f > 0 must hold, to the left of sample f*H, the N-H history
+ *     ROUNDED UP TO WHOLE HOPS: ceil((N-H)/H)*H samples.  Whole hops because per-hop mean removal
+ *     (cfg.sub_mean, fft.c:86-96) corrects every history sample by the mean of the hop it arrived
+ *     in, so the engine reads complete hops back.  (history_mode ZERO_ALWAYS needs no history.)
+ *     LMP mode adds lmp_av-1 hops: the frames its ring still holds are recomputed, not carried.
+ *     The device entries take the stream's VIRTUAL base (address of sample 0), so a piece is
+ *     passed as  d_piece - begin*sample_size  with frame indices left global.
+ * glfer_hip_frame_range() deals a stream out over `world` ranks by these rules (the arithmetic
+ * of glfer_amd/shard.py): contiguous ranges, boundaries on multiples of GLFER_FRAME_ALIGN. */
 #define GLFER_FRAME_ALIGN 32
+void glfer_hip_frame_range(size_t total_frames, unsigned rank, unsigned world, size_t *first, size_t *count);
 
 typedef struct glfer_hip_plan glfer_hip_plan;
 
@@ -130,6 +143,11 @@ int glfer_hip_spectrogram_device(glfer_hip_plan *plan, const void *d_stream, siz
                                  size_t first_frame, size_t nframes, float *d_psd,
                                  void *hip_stream);
 
+/* In LMP mode (GLFER_MODE_LMP, lmp.c:101-181) the same entry writes the detection statistic:
+ * per frame the rectangular-window periodogram of the assembled frame (lmp.c:114-125), then per
+ * bin mean and variance over the ring of the last lmp_av periodograms (zeros before the stream,
+ * slot order as lmp.c:134-149) and the clamped statistic of lmp.c:151-160. */
+
 /* Same, also writing the halfcomplex spectrum of each tapered frame in the layout of
  * fft_radix2.c:75-177 (data[k]=Re X_k, data[N-k]=Im X_k).  FFT mode only: this is
  * what fft_do leaves in params->outbuf.  d_spec: [nframes][N] floats. */
@@ -137,11 +155,46 @@ int glfer_hip_spectrum_device(glfer_hip_plan *plan, const void *d_stream, size_t
                               size_t first_frame, size_t nframes, float *d_psd, float *d_spec,
                               void *hip_stream);
 
-/* Host-buffer convenience: stages h_stream through pinned memory to the device,
- * runs the hot path and copies the PSD rows back; blocks until done.
+/* prepare_audio (fft.c:66-165) on its own: what it leaves in params->inbuf_fft for every frame
+ * (history, RA9MB, window, limiter) -- lmp.c:101-120 and the scope (g_scope.c:194-197) read it.
+ * d_frames: [nframes][N] floats. */
+int glfer_hip_prepare_device(glfer_hip_plan *plan, const void *d_stream, size_t nsamples,
+                             size_t first_frame, size_t nframes, float *d_frames, void *hip_stream);
+
+/* The harmonic F-test that mtm_do computes beside the spectrum (mtm.c:165-174 mu = transform of
+ * the hn-windowed frame; mtm.c:203-210 denominator; mtm.c:222-233 F = k |mu|^2 sum(U0^2) / den).
+ * MTM plans only.  d_ftest: [nframes][N/2+1] floats.
+ *   mu_live = 0: the reference as built without FFTW -- the transform at mtm.c:173 runs in place
+ *                and `mu` stays zero, so F is 0 (NaN where the denominator is 0);
+ *   mu_live = 1: mu as the FFTW build computes it (mtm.c:171) -- the statistic as intended.
+ * Quirks kept: the Nyquist bin's denominator is never accumulated (x/0), its numerator counts
+ * mu[N/2] twice; sums in float with double terms, as the reference's declarations give. */
+int glfer_hip_mtm_ftest_device(glfer_hip_plan *plan, const void *d_stream, size_t nsamples,
+                               size_t first_frame, size_t nframes, float *d_ftest, int mu_live,
+                               void *hip_stream);
+
+/* Host-buffer entry: h_stream goes to the device in chunks through a two-deep ring (two pinned
+ * sample buffers, two device buffers each way, two streams: a chunk's upload runs under the
+ * previous chunk's compute and download), the PSD rows come back; blocks until done.
+ * h_psd in pinned memory (glfer_hip_host_alloc) receives its rows by DMA directly; any other
+ * memory goes through pinned staging and a host copy.
  * *nframes_out receives glfer_hip_num_frames(nsamples). */
 int glfer_hip_spectrogram_host(glfer_hip_plan *plan, const void *h_stream, size_t nsamples,
                                float *h_psd, size_t *nframes_out);
+
+/* Pinned host memory for the ring's ends (source.c / wav_fmt.c side buffers). */
+void *glfer_hip_host_alloc(size_t bytes);
+void glfer_hip_host_free(void *p);
+
+/* The same over several GPUs of one node: the frame range is dealt out with
+ * glfer_hip_frame_range() over the devices whose bit is set in device_mask (bit d = HIP device
+ * d; cfg->device is ignored), one host thread per GPU, each with its own plan, streams and
+ * pinned ring; every GPU reads its hops plus the history rule (2) above from h_stream and writes
+ * a disjoint row range of h_psd.  No data moves between GPUs (frames are independent:
+ * source.c:130-158 is a loop over hops).  Rows are bit-identical to the one-GPU run. */
+int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned device_mask,
+                                     const void *h_stream, size_t nsamples, float *h_psd,
+                                     size_t *nframes_out);
 
 /* ---- ingest: the file source of source.c:118-128 / wav_fmt.c:45-121 ------------------------
  * The canonical 44-byte RIFF/WAVE header of wav_fmt.h:34-52, read with fixed-width fields
@@ -155,6 +208,7 @@ typedef struct glfer_wav_info {
   int bits_per_sample;   /* bit_p_spl: 8 or 16                       wav_fmt.h:47 */
   size_t data_offset;    /* 44                                                     */
   size_t nsamples;       /* samples present after the header                      */
+  size_t data_bytes;     /* bytes present after the header                        */
 } glfer_wav_info;
 int glfer_hip_wav_probe(const char *path, glfer_wav_info *info);
 
@@ -166,6 +220,15 @@ int glfer_hip_wav_probe(const char *path, glfer_wav_info *info);
  * chunk_frames = frames per upload (0 = default 16384). */
 int glfer_hip_spectrogram_wav(glfer_hip_plan *plan, const char *path, float *h_psd, size_t max_frames,
                               size_t *nframes_out, size_t chunk_frames);
+/* flags = GLFER_WAV_PARTIAL_TAIL: a file whose data is not a whole number of hop blocks yields
+ * one more frame, as in the reference: wav_read (wav_fmt.c:102-119) converts the samples of the
+ * short last read over the STALE rest of its buffer -- the previous block as the estimator left it
+ * (prepare_audio removes the hop's mean in place, fft.c:93-95) -- and reports a block.  An odd last
+ * byte of a 16-bit file is dropped (n_read/2 samples).  Without the flag (and in
+ * glfer_hip_spectrogram_wav) whole blocks only.  Not available in LMP mode. */
+#define GLFER_WAV_PARTIAL_TAIL 1u
+int glfer_hip_spectrogram_wav_ex(glfer_hip_plan *plan, const char *path, float *h_psd, size_t max_frames,
+                                 size_t *nframes_out, size_t chunk_frames, unsigned flags);
 
 /* K0 on its own: per-hop mean removal (fft.c:86-96).  d_out[i] = sample(d_in[i]) - mean of the
  * hop i belongs to; nhops hops of `hop` samples each.  (The spectrogram entries apply it
@@ -188,6 +251,10 @@ int glfer_hip_floor_device(const float *d_psd, size_t nframes, int bins, float *
 int glfer_hip_avg_device(int avg_mode, const float *d_psd, size_t nframes, int bins, int n_out,
                          int depth, int minbin, int maxbin, int max0, double *d_avg,
                          double *d_ret, void *hip_stream);
+/* The sliding sums alone: d_cum [nframes][n_out] = avgdata->cum after each frame (avg.c:114-127);
+ * columns outside [minbin, maxbin) are left untouched. */
+int glfer_hip_avg_cum_device(const float *d_psd, size_t nframes, int bins, int n_out, int depth,
+                             int minbin, int maxbin, double *d_cum, void *hip_stream);
 
 /* ---- display mapping: main_window_draw's column loop (g_main.c:1099-1236) over a batch ---- */
 enum { GLFER_SCALE_LIN = 0, GLFER_SCALE_LIN_MAX0, GLFER_SCALE_LOG, GLFER_SCALE_LOG_MAX0 };   /* glfer.h:43 */
@@ -225,6 +292,13 @@ int glfer_hip_palette(int palette, unsigned char colortab[768]);
 int glfer_hip_display_device(glfer_hip_display *disp, const float *d_psd, const double *d_avg,
                              const float *d_stats, size_t nframes, int bins, unsigned char *d_rgb,
                              short *d_lev, float *d_levels, void *hip_stream);
+
+/* Host samples -> waterfall columns: estimator, compute_floor and the display mapping on the
+ * device, chunked through the same ring as glfer_hip_spectrogram_host; what comes back is
+ * h_rgb [frames][bins][3] (and h_lev [frames][bins] shorts, or NULL): 3-5 bytes per bin over PCIe
+ * instead of 4, and pixels instead of PSD rows.  disp carries the level-tracking state. */
+int glfer_hip_waterfall_host(glfer_hip_plan *plan, glfer_hip_display *disp, const void *h_stream,
+                             size_t nsamples, unsigned char *h_rgb, short *h_lev, size_t *nframes_out);
 
 const char *glfer_hip_strerror(int code);
 /* text of the last HIP error seen by this thread ("" if none) */

@@ -190,3 +190,78 @@ def test_c_program_against_the_shim(oracle, tmp_path, mode, n, overlap):
         want = oracle.spectrogram_mtm(x, n, overlap, 2.5, 4, sub_mean=1)
     for f in range(7):
         assert np.abs(got[f] - want[f]).max() <= TOL * want[f].max(), f
+
+
+class LmpParams(C.Structure):       # lmp.h:36-45
+    _fields_ = [("fft", FftParams), ("avg", C.c_int), ("window", C.POINTER(C.POINTER(C.c_double))),
+                ("sig", C.POINTER(C.c_double)), ("w", C.c_float), ("kmax", C.c_int)]
+
+
+def test_lmp_do_hop_by_hop(compat, oracle):
+    """lmp_init / lmp_do / lmp_close (lmp.c:59-194) as source.c:390-398, 155-157 drives them, over more
+    hops than the shim's device history holds (it slides), against the oracle within the statistic's
+    conditioning (tests/test_gpu_round2.py::test_lmp_vs_oracle measures it)."""
+    n, ovl, nl = 1024, 0.5, 4
+    h = oracle.hop(n, ovl)
+    frames = 27
+    x = synth(frames * h, fs=8000.0, seed=19)
+    _set(compat, "glfer_compat_autoscale", 1)
+    _set(compat, "glfer_compat_first_buffer", 1)
+    p = LmpParams()
+    p.fft.n, p.fft.window_type, p.fft.overlap, p.fft.a, p.fft.limiter, p.avg = n, 5, ovl, 0.0, 0, nl
+    compat.lmp_init(C.byref(p))
+    want = oracle.spectrogram_lmp(x, n, ovl, nl, sub_mean=1)
+    psd = np.empty(n // 2 + 1, np.float32)
+    for f in range(frames):
+        hop = x[f * h:(f + 1) * h].copy()
+        compat.lmp_do(_fp(hop), _fp(psd), None, C.byref(p))
+        _set(compat, "glfer_compat_first_buffer", 0)
+        assert psd[0] == np.float32(1e-3)
+        assert np.abs(psd.astype(np.float64) - want[f]).max() <= 2e-4 * want[f].max(), f
+    compat.lmp_close(C.byref(p))
+
+
+def test_prepare_audio_leaves_the_windowed_frame(compat, oracle):
+    """prepare_audio() alone (fft.h:77): inbuf_audio = the assembled frame, inbuf_fft = RA9MB + window
+    applied to it (fft.c:98-149) -- what lmp.c:101-120 and the scope (g_scope.c:194-197) read."""
+    n, ovl = 1024, 0.75
+    h = oracle.hop(n, ovl)
+    x = synth(6 * h, fs=8000.0, seed=8)
+    _set(compat, "glfer_compat_autoscale", 0)
+    _set(compat, "glfer_compat_first_buffer", 1)
+    p = FftParams(n=n, window_type=1, overlap=ovl, a=0.001, limiter=0)           # Blackman + RA9MB
+    compat.fft_init(C.byref(p))
+    w = oracle.window(1, n)
+    frame = np.zeros(n, np.float32)
+    for f in range(6):
+        hop = x[f * h:(f + 1) * h].copy()
+        compat.prepare_audio(_fp(hop), C.byref(p))
+        _set(compat, "glfer_compat_first_buffer", 0)
+        frame = np.concatenate([frame[h:], x[f * h:(f + 1) * h]])
+        assert np.array_equal(np.ctypeslib.as_array(p.inbuf_audio, (n,)), frame)
+        want = (frame / (np.float32(0.001) + frame * frame)) * w                # float ops, fft.c:127-136
+        assert np.array_equal(np.ctypeslib.as_array(p.inbuf_fft, (n,)).view(np.uint32), want.astype(np.float32).view(np.uint32))
+    compat.fft_close(C.byref(p))
+
+
+def test_update_avg_fills_cum_and_avgarray(compat, oracle):
+    """avgdata->cum (the sliding sums) and avgdata->avgarray (the per-bin shift registers) after
+    every update, against the oracle's state (avg.c:114-127)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "avg_floor_fft1024.npz"))
+    psd, depth, lo, hi = g["psd"], int(g["depth"]), int(g["minbin"]), int(g["maxbin"])
+    a = AvgData()
+    compat.init_avg(C.byref(a))
+    compat.alloc_avg(C.byref(a), 1024, depth)
+    ref = oracle.Averager(1024, depth)
+    peak = C.c_int(-1)
+    for f in range(psd.shape[0]):
+        row = psd[f].copy()
+        compat.update_avg_plain(C.byref(a), 513, _fp(row), lo, hi, C.byref(peak))
+        ref.update("plain", psd[f], lo, hi, n=513)
+        want_cum = np.ctypeslib.as_array(ref._a.cum, (1024,))[lo:hi]
+        assert np.array_equal(np.ctypeslib.as_array(a.cum, (1024,))[lo:hi], want_cum), f
+        for b in (lo, (lo + hi) // 2, hi - 1):
+            regs = np.ctypeslib.as_array(a.avgarray[b], (depth,))
+            hist = [float(psd[g_][b]) if g_ >= 0 else 0.0 for g_ in range(f - depth + 1, f + 1)]
+            assert np.array_equal(regs, np.array(hist)), (f, b)
+    compat.delete_avg(C.byref(a))

@@ -28,8 +28,53 @@ def test_compat_library_exports_reference_entry_points():
     L = ctypes.CDLL(path)
     for sym in ("fft_init", "fft_do", "fft_psd", "fft_close", "mtm_init", "mtm_do", "mtm_close",
                 "hparma_init", "hparma_do", "hparma_close", "compute_floor", "init_avg", "alloc_avg", "delete_avg", "update_avg_plain",
-                "update_avg_sumextreme", "update_avg_sumavg"):
+                "update_avg_sumextreme", "update_avg_sumavg", "lmp_init", "lmp_do", "lmp_close", "prepare_audio"):
         assert hasattr(L, sym), sym
+
+
+def test_compat_reads_the_programs_own_globals(tmp_path):
+    """Boundary: glfer defines `opt_t opt; glfer_t glfer;` (glfer.c:56-57) and the estimators read
+    opt.autoscale / glfer.first_buffer directly (fft.c:186, fft.c:99).  A C program that defines
+    the two globals and links libglfer_compat.so -- no glue file, no hook -- must be read through."""
+    import subprocess
+    libdir = os.path.join(ROOT, "glfer_amd", "lib")
+    exe = tmp_path / "c_compat_globals"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_compat_globals.c"), "-o", str(exe), "-L", libdir, "-lglfer_compat",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath-link," + libdir], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    # LP64 layout of glfer.h:62-139: three pointers ahead of init_done / first_buffer in glfer_t
+    size_opt, off_auto, size_glfer, off_first = map(int, r.stdout.split())
+    assert (size_opt, off_auto, size_glfer, off_first) == (184, 148, 88, 28)
+
+
+def test_compat_struct_fields_follow_the_reference_header():
+    """opt_t / glfer_t in include/glfer_compat.h list the fields of glfer.h:62-139 in the same
+    order with the same scalar types (GTK pointers as void *).  Reads the reference header as text
+    where the reference tree is mounted (build container); skipped elsewhere."""
+    ref = "/root/reference/glfer.h"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not mounted")
+
+    def fields(text, name):
+        body = re.search(r"typedef struct\s*\{([^}]*)\}\s*" + name + r"\s*;", re.sub(r"/\*.*?\*/", "", text, flags=re.S), re.S).group(1)
+        out = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(.*?)(\**)\s*(\w+)$", decl)
+            typ, ptr, ident = m.group(1).strip(), m.group(2), m.group(3)
+            if ptr and typ in ("GtkWidget", "GtkTooltips", "void"):
+                typ = "void"
+            out.append((typ + ptr, ident))
+        return out
+
+    ours = open(os.path.join(ROOT, "include", "glfer_compat.h")).read()
+    theirs = open(ref).read()
+    for name in ("opt_t", "glfer_t"):
+        assert fields(ours, name) == fields(theirs, name), name
 
 
 @pytest.mark.parametrize("n", [256, 1024, 4096, 16384])

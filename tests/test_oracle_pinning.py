@@ -155,7 +155,9 @@ def test_pcm_conversion(oracle):
                           np.array([-1.0, 0.0, 32767 / 32768], np.float32))
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.npz"))), ids=os.path.basename)
+@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz"))
+                                        if os.path.basename(p)[:2] not in ("l_", "f_", "w_")),     # round-2 rows: test_oracle_extras.py
+                         ids=os.path.basename)
 def test_oracle_reproduces_golden(oracle, path):
     g = np.load(path)
     name = os.path.basename(path)

@@ -36,3 +36,25 @@ for name, params in (("C2 periodogram n=4096 overlap 0.75", dict(kind="fft", n=4
     print("%s, s16 host buffer -> host PSD rows: %.2f M frames/s, %.1f GB/s over PCIe both ways"
           % (name, out.shape[0] / dt / 1e6, (ns * 2 + out.nbytes) / dt / 1e9), flush=True)
     del out
+    # rows into pinned memory (glfer_hip_host_alloc): DMA straight into the caller's array, no staging copy
+    import ctypes as C
+    pin = G.PinnedArray((frames, sp.bins), np.float32)
+    nf = C.c_size_t(0)
+    lib = G.api.lib()
+    lib.glfer_hip_spectrogram_host(sp._h, raw.ctypes.data, raw.size, pin.ptr, C.byref(nf))
+    t0 = time.perf_counter()
+    lib.glfer_hip_spectrogram_host(sp._h, raw.ctypes.data, raw.size, pin.ptr, C.byref(nf))
+    dt = time.perf_counter() - t0
+    print("%s, s16 host buffer -> PINNED host PSD rows: %.2f M frames/s, %.1f GB/s over PCIe both ways"
+          % (name, nf.value / dt / 1e6, (ns * 2 + pin.nbytes) / dt / 1e9), flush=True)
+    pin.free()
+    # waterfall: RGB + levbuf back instead of float PSD (5 bytes per bin instead of 4 -- or 3 without levbuf)
+    for want_lev in (True, False):
+        d = G.Display(scale_type=G.SCALE_LOG, autoscale=1, overlap=params["overlap"], palette=0)
+        sp.waterfall_host(raw[: 4096 * hop], d, want_lev=want_lev)
+        d = G.Display(scale_type=G.SCALE_LOG, autoscale=1, overlap=params["overlap"], palette=0)
+        t0 = time.perf_counter(); rgb, lev = sp.waterfall_host(raw, d, want_lev=want_lev); dt = time.perf_counter() - t0
+        back = rgb.nbytes + (lev.nbytes if want_lev else 0)
+        print("%s, s16 host buffer -> host RGB%s: %.2f M frames/s, %.1f GB/s over PCIe both ways"
+              % (name, " + levbuf" if want_lev else "", rgb.shape[0] / dt / 1e6, (ns * 2 + back) / dt / 1e9), flush=True)
+        del rgb, lev
