@@ -289,6 +289,42 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     }
   }
 
+  // --- the same real-input form with wavefront-private 1024-point sub-transforms (spectro16w.hip),
+  // N = 2048 .. 16384: z index n = W*(t + 64 m) + w for wavefront w, lane t, register m
+  std::vector<float> wtaps, wtw, wcomb;
+  const bool w_form = ((cfg->mode == GLFER_MODE_FFT || lmp) && !p->nonlin || cfg->mode == GLFER_MODE_MTM) && n >= 2048 && n <= 16384;
+  if (w_form) {
+    const int M = n / 2, W = M / 1024, LF = 64 * W, IPL = LF <= 512 ? 512 / LF : 1;
+    const bool mt = cfg->mode == GLFER_MODE_MTM;
+    const int nwin = mt ? p->ntapers : 1;
+    const bool rect = !mt && (p->cfg.window_type == GLFER_WIN_RECTANGULAR);
+    wtaps.resize((size_t)nwin * n);
+    for (int j = 0; j < nwin; j++) {
+      const double scale = std::sqrt(1.0 / (4.0 * n * (mt ? 1.0 + p->sig[j] : 1.0)));
+      for (int w = 0; w < W; w++)
+        for (int m = 0; m < 16; m++)
+          for (int t = 0; t < 64; t++)
+            for (int e = 0; e < 2; e++) {
+              const int i = 2 * (W * (t + 64 * m) + w) + e;
+              const double v = mt ? p->tapers[(size_t)j * n + i] : (rect ? 1.0 : (double)p->window[i]);
+              wtaps[((((size_t)j * W + w) * 8 + m / 2) * 64 + t) * 4 + (size_t)(m & 1) * 2 + e] = (float)(v * scale);
+            }
+    }
+    p->wtapers = nwin;
+    wtw.resize((size_t)2 * glfer::make_twiddles16(10, nullptr) * 64);
+    glfer::make_twiddles16(10, wtw.data());
+    wcomb.resize((size_t)2 * IPL * W * LF);
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    for (int i = 0; i < IPL; i++)
+      for (int ww = 0; ww < W; ww++)
+        for (int u = 0; u < LF; u++) {
+          const long long k1 = u + (long long)LF * i;
+          const double ang = ww == 0 ? two_pi * (double)k1 / n : two_pi * (double)((ww * k1) % M) / M;
+          wcomb[2 * ((size_t)(i * W + ww) * LF + u)] = (float)std::cos(ang);
+          wcomb[2 * ((size_t)(i * W + ww) * LF + u) + 1] = (float)std::sin(ang);
+        }
+  }
+
   // --- odd taper count (spectro16x.hip): the last taper shares a transform with the next frame's;
   // |Y|^2 = |E|^2/4 there (no mirror-sum doubling), so its scale carries 1/4 instead of 1/2
   std::vector<float> xtaps;
@@ -377,6 +413,14 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     if (e == hipSuccess) e = hipMemcpy(p->d_htw, htw.data(), htw.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_hrot, hrot.data(), hrot.size() * sizeof(float), hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && !wtaps.empty()) {
+    e = hipMalloc((void **)&p->d_wtaps, wtaps.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_wtw, wtw.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_wcomb, wcomb.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->d_wtaps, wtaps.data(), wtaps.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_wtw, wtw.data(), wtw.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_wcomb, wcomb.data(), wcomb.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess && !xtaps.empty()) {
     e = hipMalloc((void **)&p->d_xtaps, xtaps.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->d_xtaps, xtaps.data(), xtaps.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -412,6 +456,9 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (p->d_htw) (void)hipFree(p->d_htw);
   if (p->d_hrot) (void)hipFree(p->d_hrot);
   if (p->d_xtaps) (void)hipFree(p->d_xtaps);
+  if (p->d_wtaps) (void)hipFree(p->d_wtaps);
+  if (p->d_wtw) (void)hipFree(p->d_wtw);
+  if (p->d_wcomb) (void)hipFree(p->d_wcomb);
   if (p->d_ltaps) (void)hipFree(p->d_ltaps);
   if (p->d_lagmap) (void)hipFree(p->d_lagmap);
   if (p->d_unit) (void)hipFree(p->d_unit);
@@ -474,6 +521,28 @@ static hipError_t launch_real_input(const SpectroParams &sp, int n, hipStream_t 
   return hipErrorInvalidValue;
 }
 
+// measured defaults: where spectro16w.hip is the faster form (profiles/r02_form_ab.txt)
+#define GLFER_W_PERIODOGRAM(n) ((n) >= 2048)
+#define GLFER_W_MULTITAPER(n, tapers) ((n) >= 8192)
+
+static hipError_t launch_wave_private(const SpectroParams &sp, int n, hipStream_t st) {
+  switch (n) {
+    case 2048: return glfer_launch_spectro16w_n11(&sp, st);
+    case 4096: return glfer_launch_spectro16w_n12(&sp, st);
+    case 8192: return glfer_launch_spectro16w_n13(&sp, st);
+    case 16384: return glfer_launch_spectro16w_n14(&sp, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// Which form takes a configuration is a measured choice (profiles/r02_*): GLFER_FORM=h|w|x in the
+// environment overrides it for A/B runs on one box (h: spectro16h, w: spectro16w, x: the packed /
+// shared-odd-taper forms).
+static int form_override() {
+  const char *e = getenv("GLFER_FORM");          // read per launch: tests and A/B runs switch it in-process
+  return e && *e ? (int)*e : 0;
+}
+
 static hipError_t launch_shared_odd(const SpectroParams &sp, int n, hipStream_t st) {
   if (n == 4096) return glfer_launch_spectro16y_n12(&sp, st);   // two frames interleaved per wavefront
   if (sp.ltaps) {                      // taper half tables resident in LDS
@@ -508,9 +577,17 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   const unsigned esz = sp.fmt == GLFER_FMT_F32 ? 4u : (sp.fmt == GLFER_FMT_S16 ? 2u : 1u);
   const bool pairs_aligned = sp.fmt == GLFER_FMT_F32 ||
                              ((sp.H & 1) == 0 && (reinterpret_cast<uintptr_t>(sp.stream) & (2u * esz - 1u)) == 0);
-  const bool real_input = sp.htaps && (sp.npairs == 1 || sp.htapers > 1) && n >= 512 && pairs_aligned;
+  const int force = form_override();
+  bool real_input = sp.htaps && (sp.npairs == 1 || sp.htapers > 1) && n >= 512 && pairs_aligned;
   // built where it fits 3 waves/SIMD without spilling (N = 2048 and N >= 8192 do not: they stay packed)
-  const bool shared_odd = sp.xtaps && sp.npairs >= 2 && (sp.ltaps || n <= 1024 || n == 4096);
+  bool shared_odd = sp.xtaps && sp.npairs >= 2 && (sp.ltaps || n <= 1024 || n == 4096);
+  // wavefront-private sub-transforms: the periodogram and the large-block multitaper by default
+  // (GLFER_WAVE_PRIVATE_DEFAULT below), any multitaper at N >= 2048 on request
+  bool wave_private = sp.wtaps && n >= 2048 && pairs_aligned &&
+                      (force == 'w' || (force == 0 && (sp.npairs == 1 ? GLFER_W_PERIODOGRAM(n) : GLFER_W_MULTITAPER(n, sp.wtapers))));
+  if (force == 'h') wave_private = false;
+  if (force == 'x') wave_private = real_input = false;
+  if (wave_private) real_input = true, shared_odd = false;
   if (sp.spec || sp.nonlin || !(real_input || shared_odd)) return launch_packed(sp, n, st);
   const long long first_inside = ((long long)sp.R + sp.H - 1) / sp.H;          // first frame f with f*H >= R
   // spectro16x.hip works on groups of G consecutive frames (frame f shares its last transform with
@@ -542,6 +619,7 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   const SpectroParams body = sub(b0, b1);
+  if (wave_private) return launch_wave_private(body, n, st);
   return real_input ? launch_real_input(body, n, st) : launch_shared_odd(body, n, st);
 }
 
@@ -568,6 +646,10 @@ static void fill_params(const glfer_hip_plan *p, SpectroParams &sp) {
   sp.hrot = p->d_hrot;
   sp.xtaps = p->d_xtaps;
   sp.ltaps = p->d_ltaps;
+  sp.wtaps = p->d_wtaps;
+  sp.wtapers = p->wtapers;
+  sp.wtw = p->d_wtw;
+  sp.wcomb = p->d_wcomb;
 }
 
 // K0 (fft.c:86-96) for the hops that frames [first, first+nframes) touch: the mean of each hop's

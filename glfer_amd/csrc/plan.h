@@ -62,6 +62,10 @@ struct glfer_hip_plan {
   int htapers = 0;                  // 1: periodogram window; > 1: the tapers of the multitaper form (n >= 8192)
   float2 *d_htw = nullptr;          //   twiddles of the n/2-point transform
   float2 *d_hrot = nullptr;         //   (cos,sin)(2 pi t/n), t < n/32
+  float *d_wtaps = nullptr;         // wavefront-private real-input form (spectro16w.hip): [wtapers][W][8][64][4]
+  int wtapers = 0;
+  float2 *d_wtw = nullptr;          //   [27][64] twiddles of the 1024-point transform
+  float2 *d_wcomb = nullptr;        //   combine / split twiddles per lane
   float *d_xtaps = nullptr;         // odd taper counts (spectro16x.hip): the last taper alone, [4][n/16][4]
   float *d_ltaps = nullptr;         // odd taper counts, LDS-resident half tables (spectro16xl.hip)
   uint16_t *d_lagmap = nullptr;     // HP-ARMA: [t][p_e+1] lag held by each matrix cell

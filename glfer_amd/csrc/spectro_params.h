@@ -27,6 +27,11 @@ struct SpectroParams {
   const float2 *htw;       /* device: [slots][N/32] inter-pass twiddles of the N/2-point transform      */
   int htapers;             /* windows in htaps: 0/1 = periodogram; > 1 = multitaper via the real-input form, [htapers] tables */
   const float2 *hrot;      /* device: [N/32] (cos,sin)(2 pi t/N), the lane part of the post twiddle     */
+  /* real-input form with wavefront-private 1024-point transforms, spectro16w.hip (N >= 2048); NULL when not built */
+  const float *wtaps;      /* device: [wtapers][W][8][64][4] window/taper pairs in lane order, sqrt(1/(4N(1+sig))) folded */
+  int wtapers;             /* tables in wtaps: 1 = periodogram window; > 1 = the tapers of mtm_do       */
+  const float2 *wtw;       /* device: [27][64] inter-pass twiddles of the 1024-point transform          */
+  const float2 *wcomb;     /* device: [IPL*W][64 W] (cos,sin): [i][0] = 2 pi k1/N, [i][w] = 2 pi w k1/M, k1 = u + 64 W i */
   /* odd taper counts, spectro16x.hip: the last taper alone; NULL when not built for this plan */
   const float *xtaps;      /* device: [4][N/16][4] last taper, sqrt(1/(4N(1+sig))) folded               */
   /* odd taper counts with LDS-resident half tables, spectro16xl.hip; NULL when not built */
@@ -61,6 +66,10 @@ hipError_t glfer_launch_spectro16h_n11(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n13(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n14(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16w_n11(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16w_n12(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16w_n13(const SpectroParams *p, hipStream_t st);
+hipError_t glfer_launch_spectro16w_n14(const SpectroParams *p, hipStream_t st);
 size_t glfer_levels_scratch_floats(size_t nframes);
 hipError_t glfer_launch_levels(const float *stats, size_t nframes, int scale_log, int autoscale,
                                int first_buffer, float overlap, float max_lvl0, float min_lvl0,

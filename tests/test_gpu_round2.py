@@ -388,3 +388,56 @@ def test_hparma_error_within_the_references_own_spread(lib, oracle, torch_cuda, 
     err = np.array([max(rel_err(1.0 / got[f, :n // 2], ref[f])) for f in range(frames)])
     print("hparma n=%d: gpu err %s  oracle 1-ulp spread %s" % (n, np.array2string(err, precision=2), np.array2string(spread, precision=2)))
     assert err.max() <= max(1e-5, 3.0 * spread.max()), (err, spread)
+
+
+# ---- kernel forms: the wavefront-private real-input form against the others ------------------------------
+@pytest.mark.parametrize("n,overlap,fmt", [(2048, 0.5, "f32"), (4096, 0.75, "f32"), (4096, 0.75, "s16"), (8192, 0.0, "u8"),
+                                           (16384, 0.5, "f32"), (4096, 0.9, "f32"), (2048, 0.0, "s16")])
+def test_periodogram_forms_agree(lib, oracle, torch_cuda, n, overlap, fmt):
+    """GLFER_FORM selects the kernel form per launch (h: spectro16h, w: spectro16w, x: packed): every
+    form against the oracle, all windows' worth of options that reach the gather (history zeroed in
+    every frame, PCM pairs), odd frame counts and launches that start inside the stream."""
+    h = oracle.hop(n, overlap)
+    frames = 45
+    x = synth(frames * h + 5, seed=n) + np.float32(0.02)
+    if fmt == "s16":
+        raw = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16)
+        xf, sf = oracle.pcm_s16_to_float(raw), lib.SAMPLES_S16
+    elif fmt == "u8":
+        raw = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8)
+        xf, sf = oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
+    else:
+        raw, xf, sf = x, x, lib.SAMPLES_F32
+    try:
+        for history_mode in (0, 1):
+            want = oracle.spectrogram_fft(xf, n, overlap, 7, history_mode=history_mode)
+            sp = lib.Spectrogram(lib.FftParams(n=n, window_type=7, overlap=overlap, sample_format=sf, history_mode=history_mode))
+            dx = torch_cuda.from_numpy(raw).cuda()
+            for form in ("w", "h", "x"):
+                os.environ["GLFER_FORM"] = form
+                got = sp.run(dx).cpu().numpy()
+                worst = max(max(rel_err(got[f], want[f])) for f in range(frames))
+                assert worst < TOL, (form, history_mode, worst)
+                part = sp.run(dx, first_frame=7, nframes=frames - 10).cpu().numpy()
+                assert np.array_equal(part, got[7:frames - 3]), form
+    finally:
+        os.environ.pop("GLFER_FORM", None)
+
+
+@pytest.mark.parametrize("n,overlap,kmax,nw,sub_mean", [(2048, 0.25, 4, 2.5, 0), (4096, 0.0, 4, 2.5, 0), (4096, 0.75, 7, 4.0, 1),
+                                                       (8192, 0.5, 4, 2.5, 0), (16384, 0.0, 8, 4.5, 0), (16384, 0.75, 1, 1.5, 1)])
+def test_multitaper_forms_agree(lib, oracle, torch_cuda, n, overlap, kmax, nw, sub_mean):
+    h = oracle.hop(n, overlap)
+    frames = 19
+    x = synth(frames * h, seed=n + kmax)
+    want = oracle.spectrogram_mtm(x, n, overlap, nw, kmax, sub_mean=sub_mean)
+    sp = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=sub_mean))
+    dx = torch_cuda.from_numpy(x).cuda()
+    try:
+        for form in ("w", "h", "x"):
+            os.environ["GLFER_FORM"] = form
+            got = sp.run(dx).cpu().numpy()
+            for f in range(frames):
+                assert np.abs(got[f] - want[f]).max() <= TOL * want[f].max(), (form, f)
+    finally:
+        os.environ.pop("GLFER_FORM", None)
