@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libglfer_hip.so")
+# GLFER_LIB_PATH: another build of the library (same-box A/B runs of kernel variants, tools/)
+LIB_PATH = os.environ.get("GLFER_LIB_PATH") or os.path.join(_HERE, "lib", "libglfer_hip.so")
 
 MODE_FFT, MODE_MTM, MODE_HPARMA, MODE_LMP = 0, 1, 2, 3
 WAV_PARTIAL_TAIL = 1

@@ -521,9 +521,12 @@ static hipError_t launch_real_input(const SpectroParams &sp, int n, hipStream_t 
   return hipErrorInvalidValue;
 }
 
-// measured defaults: where spectro16w.hip is the faster form (profiles/r02_form_ab.txt)
-#define GLFER_W_PERIODOGRAM(n) ((n) >= 2048)
-#define GLFER_W_MULTITAPER(n, tapers) ((n) >= 8192)
+// measured defaults: where spectro16w.hip is the faster form (profiles/r02_form_size_sweep.txt: the
+// multitaper at N = 16384, every taper count; spectro16h.hip keeps the periodogram -- its coalesced
+// sample loads beat the sub-transforms' strided ones when a frame is transformed only once -- and
+// N = 8192)
+#define GLFER_W_PERIODOGRAM(n) (false)
+#define GLFER_W_MULTITAPER(n, tapers) ((n) >= 16384)
 
 static hipError_t launch_wave_private(const SpectroParams &sp, int n, hipStream_t st) {
   switch (n) {

@@ -35,8 +35,33 @@
 #ifndef GLFER16W_WAVES_PER_SIMD
 #define GLFER16W_WAVES_PER_SIMD (GLFER_LOGN == 12 ? 3 : (GLFER_LOGN == 15 ? 4 : 2))
 #endif
+#ifndef GLFER16W_WPREFETCH
+#define GLFER16W_WPREFETCH 1      /* VAR 1: the next transform's table is requested under this transform's passes */
+#endif
+#ifndef GLFER16W_SETPRIO
+#define GLFER16W_SETPRIO 0        /* 1: the later-dispatched half of a >= 8-wavefront workgroup runs at s_setprio 1 */
+#endif
+#ifndef GLFER16W_DEPHASE
+#define GLFER16W_DEPHASE 0        /* 1: workgroups of >= 8 wavefronts run S before C in their upper half (measured: -4 %, profiles/r02_spectro16w_variants.txt) */
+#endif
 #ifndef GLFER16W_STORE_AUX
 #define GLFER16W_STORE_AUX (GLFER_LOGN >= 12 ? 2 : 0)   /* non-temporal rows from N = 4096 up (spectro16h.hip measured it) */
+#endif
+
+// GLFER16W_STAMPS (diagnostic builds only, tools/build_variant.sh): lane 0 of every wavefront of one
+// workgroup records the shader clock at the phase boundaries of its first 64 transforms into the
+// buffer passed in p.spec; the launcher prints them.  No stamp executes in the product build.
+#ifdef GLFER16W_STAMPS
+#define W_STAMP(T, id)                                                                                       \
+  do {                                                                                                       \
+    if (blockIdx.x == 8 && t == 0 && (T) < 64u) {                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      reinterpret_cast<unsigned long long *>(p.spec)[(wv * 64u + (T)) * 8u + (id)] = __builtin_amdgcn_s_memtime(); \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }                                                                                                        \
+  } while (0)
+#else
+#define W_STAMP(T, id)
 #endif
 
 namespace glfer {
@@ -58,12 +83,18 @@ template <int LOGN, int FMT, int MT, int VAR, int SETS, int WPS>
 __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(SpectroParams p) {
   using L = LaunchW<LOGN>;
   using C = Plan16<10>;
-  constexpr int N = L::N, M = L::M, W = L::W, FPB = L::FPB, LF = L::LF, IPL = L::IPL, STRIP = L::STRIP;
+  constexpr int M = L::M, W = L::W, FPB = L::FPB, LF = L::LF, IPL = L::IPL, STRIP = L::STRIP;
   constexpr int TW1 = 15, NT = C::NTW - TW1;               // pass 2's twiddles per lane (12)
   constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
   constexpr float kSampleScale = FMT == GLFER_FMT_F32 ? 1.0f : (FMT == GLFER_FMT_S16 ? 1.0f / 32768.0f : 1.0f / 128.0f);
   static_assert(MT == 0 || VAR == 1, "the multitaper form reads a table per taper");
-  __shared__ v2f32 lds[FPB * W * STRIP * SETS + 16 * 17 + (VAR == 2 ? M : 0)];
+  // MT: bin 512 of every sub-transform and taper is set aside (side[frame parity][taper][w]) and the
+  // k1 = 512 item of ALL tapers is worked off once per frame, one taper per lane (red[taper][k2] holds
+  // the lanes' |X|^2 for the sum over tapers): one lane's extra item per taper would lengthen one
+  // wavefront of eight by 45 % and every barrier with it
+  constexpr int NTMAX = 32;                                // mtm_k <= 31 (glfer_hip_plan_create)
+  constexpr int SIDE = MT ? 2 * NTMAX * W : 0, RED = MT ? NTMAX * W / 2 : 0;   // v2f32 entries per frame slot
+  __shared__ v2f32 lds[FPB * W * STRIP * SETS + 16 * 17 + (VAR == 2 ? M : 0) + FPB * (SIDE + RED)];
 
   const unsigned tid = threadIdx.x;
   const unsigned t = tid & 63u;
@@ -73,6 +104,8 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
   const unsigned u = w * 64u + t;                          // lane index within the frame
   v2f32 *tw1 = lds + FPB * W * STRIP * SETS;
   v2f32 *wl = tw1 + 16 * 17;                               // VAR 2: window pairs, [w][m][t]
+  v2f32 *side = wl + (VAR == 2 ? M : 0) + fl * (SIDE + RED);
+  float *red = reinterpret_cast<float *>(side + SIDE);
 
   {                                                        // pass 1's 16 x 16 table (rows padded to 17)
     const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.wtw);
@@ -93,31 +126,35 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
   }
   // combine twiddles of this lane's bins: slot [i][0] = (cos, sin)(2 pi k1 / N) (the split's post
   // twiddle), [i][w'] = (cos, sin)(2 pi w' k1 / M), k1 = u + LF*i
-  v2f32 ct[IPL][W];
+  // (W = 2: only [i][0] is kept; W_M^k1 = (W_N^k1)^2 is squared out of it per item)
+  constexpr int CTW = W == 2 ? 1 : W;
+  v2f32 ct[IPL][CTW];
   {
     const v2f32 *cw = reinterpret_cast<const v2f32 *>(p.wcomb) + u;
 #pragma unroll
     for (int i = 0; i < IPL; i++)
 #pragma unroll
-      for (int ww = 0; ww < W; ww++) ct[i][ww] = cw[(i * W + ww) * LF];
+      for (int ww = 0; ww < CTW; ww++) ct[i][ww] = cw[(i * W + ww) * LF];
   }
   typedef float v4f32 __attribute__((ext_vector_type(4)));
-  v2f32 wn[16];
+  v4f32 wq[8];                                             // window / taper pairs of the lane, two registers per load
   auto load_window = [&](int j) {                          // table [taper][w][m/2][t][4]
     const v4f32 *ht = reinterpret_cast<const v4f32 *>(p.wtaps) + ((size_t)j * W + w) * (8 * 64) + t;
 #pragma unroll
-    for (int mh = 0; mh < 8; mh++) {
-      const v4f32 q = ht[64 * mh];
-      wn[2 * mh] = v2f32{q.x, q.y} * kSampleScale;
-      wn[2 * mh + 1] = v2f32{q.z, q.w} * kSampleScale;
-    }
+    for (int mh = 0; mh < 8; mh++) wq[mh] = ht[64 * mh];
+  };
+  auto window_pair = [&](auto mc) -> v2f32 {
+    constexpr int m = decltype(mc)::value;
+    const v4f32 q = wq[m / 2];
+    return (m & 1) ? v2f32{q.z, q.w} : v2f32{q.x, q.y};
   };
   if constexpr (VAR == 2) {
     if (fl == 0) {
       load_window(0);
-#pragma unroll
-      for (int m = 0; m < 16; m++) wl[(w * 16 + m) * 64 + t] = wn[m];
+      static_for<0, 16>([&](auto mc) { wl[(w * 16 + decltype(mc)::value) * 64 + t] = window_pair(mc) * kSampleScale; });
     }
+  } else if constexpr (GLFER16W_WPREFETCH != 0) {
+    load_window(0);
   }
   __syncthreads();
   const v2f32 *tw1row = tw1 + (t & 15) * 17;
@@ -189,118 +226,252 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
     else frame_sync<64>();                                 // W = 1: the frame lives in one wavefront
   };
   const int ntap = MT ? p.wtapers : 1;
-  unsigned it = 0;                                         // transforms done: picks the strip set
 
-  while (true) {
-    const long long nfblk = fblk + FPB;
-    const bool has_next = nfblk < fend;
-    float acc[MT ? IPL * 2 * W : 1], accs[MT ? 2 * W : 1];  // MT: [item][k2][bin k | bin M-k]; accs: the k1 = 512 item
+  // The k1 = 512 item: 1024 - 512 is 512 again, so one radix-W transform gives all of
+  // Z[512 + 1024 k2] = sum_w a_w W_2W^w W_W^(w k2), and bin 512 + 1024 k2 pairs with bin
+  // 512 + 1024 (W-1-k2).  v[k2] = |X[512 + 1024 k2]|^2.
+  auto special512 = [](float (&ar)[W], float (&ai)[W], float (&v)[W]) {
+    static_for<1, W>([&](auto wc) {
+      constexpr int ww = decltype(wc)::value;
+      constexpr cplx64 a = unit_root(ww, 2 * W);           // (cos, sin)(2 pi 512 ww / M)
+      constexpr float c = (float)a.c, s = (float)a.s;
+      const float xr = ar[ww], xi = ai[ww];
+      ar[ww] = __builtin_fmaf(xr, c, xi * s);
+      ai[ww] = __builtin_fmaf(xi, c, -xr * s);
+    });
+    if constexpr (W > 1) dit<W, 1, 0, W>(ar, ai);
+    static_for<0, (W > 1 ? W / 2 : 1)>([&](auto kc) {
+      constexpr int k2 = decltype(kc)::value;
+      constexpr int ia = brev(k2, W), ib = brev(W - 1 - k2, W);
+      const float er = ar[ia] + ar[ib], ei = ai[ia] - ai[ib], orr = ar[ia] - ar[ib], oi = ai[ia] + ai[ib];
+      constexpr cplx64 uu = unit_root(1 + 2 * k2, 4 * W);  // (cos, sin)(2 pi (512 + 1024 k2) / N)
+      constexpr float c = (float)uu.c, s = (float)uu.s;
+      const float pr = __builtin_fmaf(c, oi, -s * orr);
+      const float pi = -__builtin_fmaf(c, orr, s * oi);
+      const float x1r = er + pr, x1i = ei + pi, x2r = er - pr, x2i = ei - pi;
+      v[k2] = __builtin_fmaf(x1r, x1r, x1i * x1i);
+      v[W - 1 - k2] = __builtin_fmaf(x2r, x2r, x2i * x2i);
+    });
+  };
+
+  // ---- the work of a workgroup is a flat sequence of transforms T = (frame group, taper); each is a
+  // sub-transform phase S(T) -- window, the wavefront's own 1024-point transform, A_w into the strips
+  // of set T & 1 -- and, one barrier later, a shared phase C(T) -- combine, split, |X|^2.
+  //   lockstep:   S(0) | C(0) S(1) | C(1) S(2) | ...          ( | = workgroup barrier )
+  // With eight or more wavefronts in the workgroup (two per SIMD, wavefront i and i + W/2 on the same
+  // one) the upper half runs each round in the OTHER order, S(T+1) before C(T): after a barrier one
+  // wavefront of every SIMD is in the LDS-store-heavy phase and the other in the arithmetic-only
+  // one, instead of both queueing for the LDS store path and then both for the VALU.  Legal with
+  // two strip sets: S(T+1) touches set (T+1) & 1 only, C(T) reads set T & 1, which nobody writes
+  // before the next barrier.
+  constexpr bool kStagger = GLFER16W_DEPHASE != 0 && SETS == 2 && W * FPB >= 8;
+  const bool late = kStagger && w >= W / 2;
+  constexpr unsigned ROWB = (unsigned)(M + 1) * 4u;
+  constexpr int KMAX = LF * (IPL - 1) + 1024 * (W - 1);    // largest k1 + 1024 k2 offset of a lane's items
+  float acc[MT ? IPL * 2 * W : 1];                         // MT: [item][k2][bin k | bin M-k]
+
+  // S: frame group sf, taper sj.  px holds the group's samples, wq taper sj's table (VAR 1).
+  long long sf = fblk;
+  int sj = 0;
+  unsigned sit = 0;                                        // transforms started: picks the strip set
+  auto phase_S = [&] {
+    const bool last = sj == ntap - 1;
+    const long long nf = sf + FPB;
+    const bool has_next = nf < fend;
+    v2f32 *xb = lds + ((SETS == 2 ? (sit & 1u) : 0u) * FPB + fl) * (W * STRIP) + w * STRIP;
+    W_STAMP(sit, 0);                                       // S begins
+    float zr[16], zi[16];
+    if constexpr (VAR == 1 && GLFER16W_WPREFETCH == 0) load_window(sj);
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const v2f32 x = sample_pair(mc);
+      const v2f32 ww = VAR == 2 ? wl[(w * 16 + m) * 64 + t] : window_pair(mc) * kSampleScale;
+      zr[m] = x.x * ww.x;
+      zi[m] = x.y * ww.y;
+    });
+    // the next transform's table (VAR 1) and the next frame's samples are requested once pass 0 has
+    // handed its data to LDS
+    stockham16_passes<10, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
+      if constexpr (VAR == 1 && GLFER16W_WPREFETCH != 0) {
+        if (!last) load_window(sj + 1);
+        else if (has_next) load_window(0);
+      }
+      if (has_next && last) prefetch_x(nf);                // the frame's last use of px is behind us
+      W_STAMP(sit, 1);                                     // pass 0 done, exchange 0 written
+    });
+    W_STAMP(sit, 2);                                       // passes done
+    // A_w into the strip, bin k at entry k (the wavefront's last exchange reads have landed)
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int r = rho_of(m);
+      xb[t + 64 * m] = v2f32{zr[r], zi[r]};
+    });
     if constexpr (MT != 0) {
-#pragma unroll
-      for (int i = 0; i < IPL * 2 * W; i++) acc[i] = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 2 * W; i++) accs[i] = 0.0f;
+      if (t == 0) side[(((unsigned)(sf / FPB) & 1u) * NTMAX + sj) * W + w] = v2f32{zr[rho_of(8)], zi[rho_of(8)]};   // bin 512 = 0 + 64*8
     }
+    W_STAMP(sit, 3);                                       // A_w written
+    sit++;
+    if (last) { sj = 0; sf = nf; } else { sj++; }
+  };
+
+  // C: frame group cf, taper cj
+  long long cf = fblk;
+  int cj = 0;
+  unsigned cit = 0;
+  auto phase_C = [&] {
+    const bool last = cj == ntap - 1;
+    if constexpr (MT != 0) {
+      if (cj == 0) {                                       // a new frame: the sums start over
+#pragma unroll
+        for (int i = 0; i < IPL * 2 * W; i++) acc[i] = 0.0f;
+      }
+    }
+    const unsigned cpar = (unsigned)(cf / FPB) & 1u;
+    const v2f32 *strips = lds + ((SETS == 2 ? (cit & 1u) : 0u) * FPB + fl) * (W * STRIP);
+    W_STAMP(cit, 4);                                       // C begins
     // rows go out through a buffer descriptor over this workgroup's frames; frame slots past the
     // last frame fall outside num_records (their stores are dropped)
-    constexpr unsigned ROWB = (unsigned)(M + 1) * 4u;
-    const long long left = p.nframes - fblk;
+    const long long left = p.nframes - cf;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.psd + (size_t)fblk * (M + 1), 0, (unsigned)((left > FPB ? FPB : left) * (long long)ROWB), 0x00020000);
-    auto put = [&](float v, unsigned bin) {
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, fl * ROWB + bin * 4u, 0, GLFER16W_STORE_AUX);
+        p.psd + (size_t)cf * (M + 1), 0, (unsigned)((left > FPB ? FPB : left) * (long long)ROWB), 0x00020000);
+    // one VGPR offset per direction (bins k upwards from u, bins M-k from the lane's lowest one),
+    // everything else a compile-time scalar offset.  (MT stores once per frame, after the last
+    // taper: there the offsets are computed at the store, so that no scalar registers stay reserved
+    // for them across the taper loop.)
+    const unsigned vup = fl * ROWB + u * 4u, vdown = fl * ROWB + ((unsigned)M - u - (unsigned)KMAX) * 4u;
+    auto put = [&](float v, unsigned voff, unsigned soff) {
+      if constexpr (MT != 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, voff + soff, 0, GLFER16W_STORE_AUX);
+      else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, voff, soff, GLFER16W_STORE_AUX);
     };
-
-    for (int j = 0; j < ntap; j++) {
-      const bool last = j == ntap - 1;
-      v2f32 *strips = lds + ((SETS == 2 ? (it & 1u) : 0u) * FPB + fl) * (W * STRIP);   // this frame's W strips
-      v2f32 *xb = strips + w * STRIP;
-      it++;
-      float zr[16], zi[16];
-      if constexpr (VAR == 1) load_window(j);
-      static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        const v2f32 x = sample_pair(mc);
-        const v2f32 ww = VAR == 2 ? wl[(w * 16 + m) * 64 + t] : wn[m];
-        zr[m] = x.x * ww.x;
-        zi[m] = x.y * ww.y;
+    // one item = the bins k1 + 1024 k2 and their mirrors
+    auto item = [&](unsigned k1, auto offc, const v2f32 (&tw)[W], float *sum) {
+      constexpr int OFF = decltype(offc)::value;           // k1 - u
+      float ar[W], ai[W], br[W], bi[W];
+      const unsigned k1m = (1024u - k1) & 1023u;           // k1 = 0 pairs with itself
+#pragma unroll
+      for (int ww = 0; ww < W; ww++) {
+        const v2f32 a = strips[ww * STRIP + k1], b = strips[ww * STRIP + k1m];
+        if (ww == 0) {
+          ar[0] = a.x; ai[0] = a.y; br[0] = b.x; bi[0] = b.y;
+        } else {                                           // a * W_M^(ww k1),  b * conj(that)
+          const float c = tw[ww].x, sn = tw[ww].y;
+          ar[ww] = __builtin_fmaf(a.x, c, a.y * sn);
+          ai[ww] = __builtin_fmaf(a.y, c, -a.x * sn);
+          br[ww] = __builtin_fmaf(b.x, c, -b.y * sn);
+          bi[ww] = __builtin_fmaf(b.y, c, b.x * sn);
+        }
+      }
+      if constexpr (W > 1) {
+        dit<W, 1, 0, W>(ar, ai);                           // Z[k1 + 1024 k2] at index brev(k2)
+        dit<W, 1, 0, W>(br, bi);                           // Z[1024 - k1 + 1024 (k2 - 1)] at index brev(k2)
+      }
+      static_for<0, W>([&](auto kc) {
+        constexpr int k2 = decltype(kc)::value;
+        constexpr int ia = brev(k2, W), ib = brev((W - k2) % W, W);
+        const float er = ar[ia] + br[ib], ei = ai[ia] - bi[ib], orr = ar[ia] - br[ib], oi = ai[ia] + bi[ib];
+        constexpr cplx64 uu = unit_root(k2, 2 * W);        // (cos, sin)(2 pi 1024 k2 / N)
+        constexpr float cm = (float)uu.c, sm = (float)uu.s;
+        const float c = k2 == 0 ? tw[0].x : __builtin_fmaf(tw[0].x, cm, -tw[0].y * sm);
+        const float sn = k2 == 0 ? tw[0].y : __builtin_fmaf(tw[0].y, cm, tw[0].x * sm);
+        const float pr = __builtin_fmaf(c, oi, -sn * orr);             // P = -i (c - i s) O
+        const float pi = -__builtin_fmaf(c, orr, sn * oi);
+        const float x1r = er + pr, x1i = ei + pi, x2r = er - pr, x2i = ei - pi;
+        float v1, v2;
+        if constexpr (MT != 0) {
+          v1 = sum[2 * k2] = __builtin_fmaf(x1r, x1r, __builtin_fmaf(x1i, x1i, sum[2 * k2]));
+          v2 = sum[2 * k2 + 1] = __builtin_fmaf(x2r, x2r, __builtin_fmaf(x2i, x2i, sum[2 * k2 + 1]));
+        } else {
+          v1 = __builtin_fmaf(x1r, x1r, x1i * x1i);
+          v2 = __builtin_fmaf(x2r, x2r, x2i * x2i);
+        }
+        if (last) {
+          put(v1, vup, (unsigned)(OFF + 1024 * k2) * 4u);                       // bin k
+          put(v2, vdown, (unsigned)(KMAX - OFF - 1024 * k2) * 4u);              // bin M - k
+        }
       });
-
-      // ---- the wavefront's own 1024-point transform
-      stockham16_passes<10, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
-        if (has_next && last) prefetch_x(nfblk);           // the frame's last use of px is behind us
+    };
+    if (LF <= 512 || u < 512u) {
+      static_for<0, IPL>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        v2f32 tw[W];
+        tw[0] = ct[i][0];
+        if constexpr (W == 2) {                            // W_M^k1 = (W_N^k1)^2
+          tw[1] = v2f32{__builtin_fmaf(tw[0].x, tw[0].x, -tw[0].y * tw[0].y), 2.0f * tw[0].x * tw[0].y};
+        } else {
+#pragma unroll
+          for (int ww = 1; ww < W; ww++) tw[ww] = ct[i][ww];
+        }
+        item(u + LF * i, std::integral_constant<int, LF * i>{}, tw, MT ? acc + i * 2 * W : acc);
       });
-      // A_w into the strip, bin k at entry k (the wavefront's last exchange reads have landed)
-      static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        constexpr int r = rho_of(m);
-        xb[t + 64 * m] = v2f32{zr[r], zi[r]};
-      });
-      shared_sync();
-
-      // ---- shared pass + real-input split, one item = the bins k1 + 1024 k2 and their mirrors
-      auto item = [&](unsigned k1, const v2f32 (&tw)[W], float *sum, bool store) {
-        float ar[W], ai[W], br[W], bi[W];
-        const unsigned k1m = (1024u - k1) & 1023u;         // k1 = 0 pairs with itself
+    }
+    if constexpr (MT == 0) {
+      if (u == 0) {                                        // k1 = 512, this frame
+        float ar[W], ai[W], v[W];
 #pragma unroll
         for (int ww = 0; ww < W; ww++) {
-          const v2f32 a = strips[ww * STRIP + k1], b = strips[ww * STRIP + k1m];
-          if (ww == 0) {
-            ar[0] = a.x; ai[0] = a.y; br[0] = b.x; bi[0] = b.y;
-          } else {                                         // a * W_M^(ww k1),  b * conj(that)
-            const float c = tw[ww].x, s = tw[ww].y;
-            ar[ww] = __builtin_fmaf(a.x, c, a.y * s);
-            ai[ww] = __builtin_fmaf(a.y, c, -a.x * s);
-            br[ww] = __builtin_fmaf(b.x, c, -b.y * s);
-            bi[ww] = __builtin_fmaf(b.y, c, b.x * s);
-          }
+          const v2f32 a = strips[ww * STRIP + 512];
+          ar[ww] = a.x;
+          ai[ww] = a.y;
         }
-        if constexpr (W > 1) {
-          dit<W, 1, 0, W>(ar, ai);                         // Z[k1 + 1024 k2] at index brev(k2)
-          dit<W, 1, 0, W>(br, bi);                         // Z[1024 - k1 + 1024 (k2 - 1)] at index brev(k2)
-        }
-        static_for<0, W>([&](auto kc) {
-          constexpr int k2 = decltype(kc)::value;
-          constexpr int ia = brev(k2, W), ib = brev((W - k2) % W, W);
-          const float er = ar[ia] + br[ib], ei = ai[ia] - bi[ib], orr = ar[ia] - br[ib], oi = ai[ia] + bi[ib];
-          constexpr cplx64 uu = unit_root(k2, 2 * W);      // (cos, sin)(2 pi 1024 k2 / N)
-          constexpr float cm = (float)uu.c, sm = (float)uu.s;
-          const float c = k2 == 0 ? tw[0].x : __builtin_fmaf(tw[0].x, cm, -tw[0].y * sm);
-          const float s = k2 == 0 ? tw[0].y : __builtin_fmaf(tw[0].y, cm, tw[0].x * sm);
-          const float pr = __builtin_fmaf(c, oi, -s * orr);            // P = -i (c - i s) O
-          const float pi = -__builtin_fmaf(c, orr, s * oi);
-          const float x1r = er + pr, x1i = ei + pi, x2r = er - pr, x2i = ei - pi;
-          float v1, v2;
-          if constexpr (MT != 0) {
-            v1 = sum[2 * k2] = __builtin_fmaf(x1r, x1r, __builtin_fmaf(x1i, x1i, sum[2 * k2]));
-            v2 = sum[2 * k2 + 1] = __builtin_fmaf(x2r, x2r, __builtin_fmaf(x2i, x2i, sum[2 * k2 + 1]));
-          } else {
-            v1 = __builtin_fmaf(x1r, x1r, x1i * x1i);
-            v2 = __builtin_fmaf(x2r, x2r, x2i * x2i);
-          }
-          if (store) {
-            put(v1, k1 + 1024u * k2);                      // bin k
-            put(v2, (unsigned)M - k1 - 1024u * k2);        // bin M - k
-          }
-        });
-      };
-      if (LF <= 512 || u < 512u) {
+        special512(ar, ai, v);
 #pragma unroll
-        for (int i = 0; i < IPL; i++) item(u + LF * i, ct[i], MT ? acc + i * 2 * W : acc, last);
+        for (int k2 = 0; k2 < W; k2++) put(v[k2], fl * ROWB, (512u + 1024u * k2) * 4u);
       }
-      if (u == 0) {                                        // k1 = 512: 1024 - k1 is k1 again
-        v2f32 tw[W];
-        static_for<0, W>([&](auto wc) {
-          constexpr int ww = decltype(wc)::value;
-          constexpr cplx64 a = unit_root(ww == 0 ? 1 : ww, ww == 0 ? 4 * W : 2 * W);   // [0]: 2 pi 512/N; [ww]: 2 pi 512 ww/M
-          tw[ww] = v2f32{(float)a.c, (float)a.s};
-        });
-        item(512u, tw, accs, last);
+    } else if (last) {
+      // every taper's bin 512 is in `side` (written before the barrier that precedes this phase):
+      // lane l of the frame's first wavefront takes taper l, then lanes k2 < W add the tapers up in
+      // taper order
+      if (w == 0) {
+        if ((int)t < ntap) {
+          float ar[W], ai[W], v[W];
+#pragma unroll
+          for (int ww = 0; ww < W; ww++) {
+            const v2f32 a = side[(cpar * NTMAX + t) * W + ww];
+            ar[ww] = a.x;
+            ai[ww] = a.y;
+          }
+          special512(ar, ai, v);
+#pragma unroll
+          for (int k2 = 0; k2 < W; k2++) red[t * W + k2] = v[k2];
+        }
+        frame_sync<64>();
+        if (t < (unsigned)W) {
+          float sum = 0.0f;
+          for (int l = 0; l < ntap; l++) sum += red[l * W + t];
+          put(sum, fl * ROWB + (512u + 1024u * t) * 4u, 0u);
+        }
+        frame_sync<64>();                                  // red is rewritten only a frame later, by this wavefront
       }
-      if constexpr (SETS == 1) shared_sync();              // every reader is done: the strips may be rewritten
     }
-    if (!has_next) break;
-    fblk = nfblk;
+    W_STAMP(cit, 5);                                       // C done
+    cit++;
+    if (last) { cj = 0; cf += FPB; } else { cj++; }
+  };
+
+  if constexpr (GLFER16W_SETPRIO != 0 && W * FPB >= 8) {
+    if (wv >= (unsigned)(W * FPB) / 2) __builtin_amdgcn_s_setprio(1);
+  }
+  phase_S();
+  shared_sync();
+  while (true) {
+    const bool more = sf < fend;                           // a transform is left to start
+    // two half-steps: C then S, or S then C for the late half of a de-phased workgroup.  One copy of
+    // each phase's code: the order is a wave-uniform branch inside a two-trip loop.
+    if constexpr (kStagger) {
+#pragma unroll 1
+      for (int half = 0; half < 2; half++) {
+        if ((half == 0) != late) phase_C();
+        else if (more) phase_S();
+      }
+    } else {
+      phase_C();
+      if constexpr (SETS == 1) shared_sync();              // every reader is done: the strips may be rewritten
+      if (more) phase_S();
+    }
+    if (!more) break;
+    W_STAMP(cit, 6);                                       // at the barrier
+    shared_sync();
+    W_STAMP(cit, 7);                                       // through the barrier
   }
 }
 
@@ -323,8 +494,9 @@ static hipError_t launch16w_fmt(const SpectroParams &p, hipStream_t st) {
   const long long resident = 256LL * per_cu;
   unsigned grid = (unsigned)(work < 8 * resident ? work : 8 * resident);
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
-  if (p.wtapers > 1) {
-    hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+  if (p.wtapers > 1) {                             // the multitaper form keeps its sums in registers: two waves per SIMD
+    constexpr int WPS_MT = WPS > 2 ? 2 : WPS;
+    hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   } else {
     constexpr int VAR = (L <= 12) ? 2 : 1;         // the window in LDS where it costs no resident workgroup
     hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 0, VAR, GLFER16W_SETS, WPS>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
@@ -332,8 +504,43 @@ static hipError_t launch16w_fmt(const SpectroParams &p, hipStream_t st) {
   return hipGetLastError();
 }
 
+#ifdef GLFER16W_STAMPS
+#include <cstdio>
+#include <vector>
+static hipError_t launch16w_stamped(const SpectroParams &p0, hipStream_t st) {
+  static unsigned long long *d_st = nullptr;
+  const size_t n = (size_t)16 * 64 * 8;
+  if (!d_st && hipMalloc((void **)&d_st, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+  (void)hipMemsetAsync(d_st, 0, n * 8, st);
+  SpectroParams p = p0;
+  p.spec = reinterpret_cast<float *>(d_st);
+  hipError_t e = p.fmt == GLFER_FMT_F32 ? launch16w_fmt<GLFER_FMT_F32>(p, st) : hipErrorInvalidValue;
+  if (e != hipSuccess) return e;
+  std::vector<unsigned long long> h(n);
+  if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h.data(), d_st, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return hipErrorUnknown;
+  static int dumps = 0;
+  if (dumps++ == 2) {                               // the third launch: caches and clocks are warm
+    const int waves = LaunchW<GLFER_LOGN>::BLOCK / 64;
+    const unsigned long long t0 = h[(0 * 64 + 20) * 8 + 0];
+    fprintf(stderr, "# spectro16w stamps, workgroup 8, transforms 20..25; ticks since wave 0 began S(20)\n");
+    fprintf(stderr, "# wave T   S-begin  pass0+x0   passes     A_w-out  | C-begin   C-done   | at-barrier  through\n");
+    for (int T = 20; T < 26; T++)
+      for (int wvi = 0; wvi < waves; wvi++) {
+        const unsigned long long *r = &h[((size_t)wvi * 64 + T) * 8];
+        fprintf(stderr, "  %2d  %2d", wvi, T);
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %9lld", r[i] ? (long long)(r[i] - t0) : -1LL);
+        fprintf(stderr, "\n");
+      }
+  }
+  return hipSuccess;
+}
+#endif
+
 extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16w_n, GLFER_LOGN)(const SpectroParams *p, hipStream_t st) {
   if (!p->wtaps || !p->wtw || !p->wcomb || p->nonlin || p->spec) return hipErrorInvalidValue;
+#ifdef GLFER16W_STAMPS
+  if (p->fmt == GLFER_FMT_F32) return launch16w_stamped(*p, st);
+#endif
   // the gather has no zero-history path: every frame must lie wholly inside the stream
   if (p->frame0 * (long long)p->H < (long long)p->R) return hipErrorInvalidValue;
   if (p->fmt != GLFER_FMT_F32) {                   // integer pairs (y[2n], y[2n+1]) come with one load: naturally aligned
