@@ -37,7 +37,7 @@ EXPORTS = [
     "glfer_hip_avg_device", "glfer_hip_palette", "glfer_hip_display_device", "glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version",
     "glfer_hip_frame_range", "glfer_hip_prepare_device", "glfer_hip_mtm_ftest_device", "glfer_hip_host_alloc",
     "glfer_hip_host_free", "glfer_hip_spectrogram_host_multi", "glfer_hip_spectrogram_wav_ex",
-    "glfer_hip_avg_cum_device", "glfer_hip_waterfall_host",
+    "glfer_hip_avg_cum_device", "glfer_hip_waterfall_host", "glfer_hip_waterfall_device",
 ]
 
 
@@ -132,6 +132,8 @@ def lib():
     L.glfer_hip_spectrogram_host_multi.argtypes = [C.POINTER(Config), C.c_uint, vp, sz, vp, C.POINTER(sz)]
     L.glfer_hip_spectrogram_wav_ex.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz), sz, C.c_uint]
     L.glfer_hip_avg_cum_device.argtypes = [vp, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.glfer_hip_waterfall_device.argtypes = [C.POINTER(Display), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, C.c_int,
+                                             vp, vp, vp, vp]
     L.glfer_hip_waterfall_host.argtypes = [vp, C.POINTER(Display), vp, sz, vp, vp, C.POINTER(sz)]
     for f in ("glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version"):
         getattr(L, f).restype = C.c_char_p
@@ -461,6 +463,22 @@ def display(disp, src, stats, want_lev=True, want_levels=True):
         C.c_void_p(rgb.data_ptr()), C.c_void_p(lev.data_ptr()) if want_lev else None,
         C.c_void_p(levels.data_ptr()) if want_levels else None, st), "glfer_hip_display_device")
     return rgb, lev, levels
+
+
+def waterfall(disp, psd, avg_mode=0, depth=1, minbin=0, maxbin=1, max0=0, want_lev=True, want_stats=False):
+    """glfer_hip_waterfall_device: floor statistics, optional moving average, level tracking and the
+    pixel map of a batch of PSD rows, tile by tile.  Returns (rgb, lev | None, stats | None)."""
+    torch = _torch()
+    assert psd.is_cuda and psd.dtype == torch.float32 and psd.is_contiguous() and psd.dim() == 2
+    frames, bins = psd.shape
+    rgb = torch.empty((frames, bins, 3), dtype=torch.uint8, device=psd.device)
+    lev = torch.empty((frames, bins), dtype=torch.int16, device=psd.device) if want_lev else None
+    stats = torch.empty((frames, 4), dtype=torch.float32, device=psd.device) if want_stats else None
+    st = C.c_void_p(torch.cuda.current_stream(psd.device).cuda_stream)
+    _check(lib().glfer_hip_waterfall_device(C.byref(disp), int(avg_mode), depth, minbin, maxbin, int(max0), psd.data_ptr(), frames,
+                                            bins, rgb.data_ptr(), lev.data_ptr() if want_lev else None,
+                                            stats.data_ptr() if want_stats else None, st), "glfer_hip_waterfall_device")
+    return rgb, lev, stats
 
 
 def avg_cum(psd, depth, minbin, maxbin, n_out=None):

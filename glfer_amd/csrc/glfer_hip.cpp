@@ -75,6 +75,7 @@ static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // fetches registers m, m+1 of both tapers of a pair with one 16-byte load:
 //   taps[pair][m/2][t][4] = { taper 2p @m, taper 2p+1 @m, taper 2p @m+1, taper 2p+1 @m+1 }
 static size_t tap_slot(int n, int pair, int i, int which) {
+  if (n < 256) return ((size_t)pair * n + i) * 2 + which;       // spectro_small.hip: [pair][i][2]
   const int T = n / 16, t = i % T, m = i / T;
   return (size_t)pair * n * 2 + ((size_t)(m / 2) * T + t) * 4 + (size_t)(m & 1) * 2 + which;
 }
@@ -154,6 +155,61 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
   return rc;
 }
 
+// compute_floor + update_avg_* + the display mapping of main_window_draw (g_main.c:1109-1236) for a
+// batch of PSD rows in one call.  The level tracking is a chain over the columns (g_main.c:1122-1123)
+// fed by every column's floor statistics, so a row is read twice -- once for its statistics (and its
+// moving sums), once to be mapped -- and the chain walk costs ~0.1 us per column of LATENCY however
+// few columns it is given (its chunks warm up over the 4096 columns before them, display.hip).
+// Cache-sized tiles (rows still in the 256 MiB Infinity Cache when the map reads them) were
+// measured: 15 M rows/s against 117 M stage by stage over the whole batch
+// (profiles/r02_aux_sweep.txt) -- the chain's latency per tile swamps the saved HBM read.  So the
+// stages run over tiles of up to 65536 rows, which only bounds the scratch (averaged rows: 8 B/bin).
+int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, int minbin, int maxbin, int max0,
+                               const float *d_psd, size_t nframes, int bins, unsigned char *d_rgb, short *d_lev,
+                               float *d_stats, void *hip_stream) {
+  if (!d || !d_psd || !d_rgb || bins < 1 || bins > 32769) return GLFER_E_ARG;
+  const bool averaging = avg_mode != 0;
+  if (averaging && (avg_mode < GLFER_AVG_SUMAVG || avg_mode > GLFER_AVG_SUMEXTREME || depth < 1 || minbin < 0 ||
+                    maxbin <= minbin || maxbin > bins))
+    return GLFER_E_ARG;
+  if (nframes == 0) return GLFER_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  DeviceGuard guard(data_device(d_psd));
+  HIP_TRY(guard.error());
+  size_t tile = std::min<size_t>(nframes, 65536);
+  const size_t back = averaging ? (size_t)depth : 0;       // rows re-read in front of a tile to restart the sliding sums
+  float *stats = d_stats;
+  double *avg = nullptr, *ret = nullptr;
+  if (!stats) HIP_TRY(hipMallocAsync((void **)&stats, tile * 4 * sizeof(float), st));
+  int rc = GLFER_OK;
+  if (averaging) {
+    hipError_t e = hipMallocAsync((void **)&avg, (tile + back) * (size_t)bins * sizeof(double), st);
+    if (e == hipSuccess) e = hipMallocAsync((void **)&ret, (tile + back) * 4 * sizeof(double), st);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMallocAsync(waterfall tile)");
+  }
+  for (size_t f0 = 0; rc == GLFER_OK && f0 < nframes; f0 += tile) {
+    const size_t nf = std::min(tile, nframes - f0);
+    float *tstats = d_stats ? d_stats + f0 * 4 : stats;
+    rc = glfer_hip_floor_device(d_psd + f0 * (size_t)bins, nf, bins, tstats, st);
+    const double *src_avg = nullptr;
+    if (rc == GLFER_OK && averaging) {
+      // the sums of the tile's first rows reach `depth` rows back: run from there (from an empty
+      // state at row 0 of the batch, as update_avg does after alloc_avg) and use the tile's rows
+      const size_t lead = std::min(back, f0);
+      rc = glfer_hip_avg_device(avg_mode, d_psd + (f0 - lead) * (size_t)bins, nf + lead, bins, bins, depth, minbin, maxbin, max0,
+                                avg, ret, st);
+      src_avg = avg + lead * (size_t)bins;
+    }
+    if (rc == GLFER_OK)
+      rc = glfer_hip_display_device(d, averaging ? nullptr : d_psd + f0 * (size_t)bins, src_avg, tstats, nf, bins,
+                                    d_rgb + f0 * (size_t)bins * 3, d_lev ? d_lev + f0 * (size_t)bins : nullptr, nullptr, st);
+  }
+  if (avg) (void)hipFreeAsync(avg, st);
+  if (ret) (void)hipFreeAsync(ret, st);
+  if (!d_stats) (void)hipFreeAsync(stats, st);
+  return rc;
+}
+
 const char *glfer_hip_strerror(int code) {
   switch (code) {
     case GLFER_OK: return "ok";
@@ -171,7 +227,11 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   if (!cfg || !out) return GLFER_E_ARG;
   *out = nullptr;
   const int n = cfg->n;
-  if (!is_pow2(n) || n < 256 || n > 16384) return GLFER_E_ARG;
+  // any power of two the user can type (g_options.c:386-387): 8 .. 128 through spectro_small.hip,
+  // 256 .. 16384 through the 16-points-per-lane kernels, 32768 through spectro16w.hip alone
+  if (!is_pow2(n) || n < 8 || n > 32768) return GLFER_E_ARG;
+  if (cfg->mode == GLFER_MODE_HPARMA && (n < 256 || n > 16384)) return GLFER_E_ARG;
+  const bool small = n < 256, huge = n > 16384;
   if (!(cfg->overlap >= 0.0f) || !(cfg->overlap < 1.0f)) return GLFER_E_ARG;   // g_options.c:1030
   if (cfg->mode != GLFER_MODE_FFT && cfg->mode != GLFER_MODE_MTM && cfg->mode != GLFER_MODE_HPARMA &&
       cfg->mode != GLFER_MODE_LMP)
@@ -217,7 +277,8 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     glfer::make_window(p->cfg.window_type, n, p->window.data());
     p->nonlin = (p->cfg.limiter_a > 0.0f) || (p->cfg.enable_limiter == 1);
     // psd = |X|^2/N (fft.c:212-216); the pair packing contributes |Z_k|^2+|Z_{N-k}|^2 = 2|X_k|^2
-    const double scale = std::sqrt(1.0 / (2.0 * n));
+    // (N = 32768 runs the real-input form only: its inputs carry sqrt(1/(4N)), see the w tables below)
+    const double scale = std::sqrt(1.0 / ((huge ? 4.0 : 2.0) * n));
     p->spec_unscale = (float)scale;
     // device layout: taps[pair][i] = (taper 2*pair, taper 2*pair+1)[i], interleaved
     taps.assign((size_t)2 * n, 0.0f);
@@ -240,7 +301,7 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
       return GLFER_E_NUMERIC;
     }
     taps.assign((size_t)2 * p->npairs * n, 0.0f);
-    for (int j = 0; j < p->ntapers; j++) {
+    for (int j = 0; j < p->ntapers && !huge; j++) {
       // psd += |FFT(v_j x)|^2 / N / (1+sig_j)   (mtm.c:212-219), and the 1/2 of the packing
       const double scale = std::sqrt(1.0 / (2.0 * n * (1.0 + p->sig[j])));
       for (int i = 0; i < n; i++)
@@ -251,8 +312,12 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   int logn = 0;
   while ((1 << logn) < n) logn++;
   p->lanes = n / 16;
-  std::vector<float> tw((size_t)2 * glfer::make_twiddles16(logn, nullptr) * p->lanes);
-  glfer::make_twiddles16(logn, tw.data());
+  std::vector<float> tw(2, 0.0f);
+  if (!small && !huge) {
+    tw.assign((size_t)2 * glfer::make_twiddles16(logn, nullptr) * p->lanes, 0.0f);
+    glfer::make_twiddles16(logn, tw.data());
+  }
+  if (huge) taps.assign(4, 0.0f);                                  // no packed form at this size
 
   // --- real-input form of the linear periodogram (spectro16h.hip): z[i] = y[2i] + i*y[2i+1],
   // lane t of n/32 holds points i = t + (n/32)*m; |X|^2/N needs the inputs scaled by sqrt(1/(4N))
@@ -261,8 +326,8 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   // registers: the packed N-point form would need the whole N-point exchange buffer (139 KB at
   // N = 16384: one workgroup per CU), the real-input form half of it.  Each taper carries its weight:
   // sqrt(1 / (4N (1 + sig_j))).
-  const bool h_periodogram = (cfg->mode == GLFER_MODE_FFT || lmp) && !p->nonlin && n >= 512;
-  const bool h_multitaper = cfg->mode == GLFER_MODE_MTM && n >= 8192;
+  const bool h_periodogram = (cfg->mode == GLFER_MODE_FFT || lmp) && !p->nonlin && n >= 512 && !huge;
+  const bool h_multitaper = cfg->mode == GLFER_MODE_MTM && n >= 8192 && !huge;
   if (h_periodogram || h_multitaper) {
     const int th = n / 32;
     const int nwin = h_multitaper ? p->ntapers : 1;
@@ -292,7 +357,7 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   // --- the same real-input form with wavefront-private 1024-point sub-transforms (spectro16w.hip),
   // N = 2048 .. 16384: z index n = W*(t + 64 m) + w for wavefront w, lane t, register m
   std::vector<float> wtaps, wtw, wcomb;
-  const bool w_form = ((cfg->mode == GLFER_MODE_FFT || lmp) && !p->nonlin || cfg->mode == GLFER_MODE_MTM) && n >= 2048 && n <= 16384;
+  const bool w_form = (((cfg->mode == GLFER_MODE_FFT || lmp) && (!p->nonlin || huge)) || cfg->mode == GLFER_MODE_MTM) && n >= 2048;
   if (w_form) {
     const int M = n / 2, W = M / 1024, LF = 64 * W, IPL = LF <= 512 ? 512 / LF : 1;
     const bool mt = cfg->mode == GLFER_MODE_MTM;
@@ -307,7 +372,8 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
             for (int e = 0; e < 2; e++) {
               const int i = 2 * (W * (t + 64 * m) + w) + e;
               const double v = mt ? p->tapers[(size_t)j * n + i] : (rect ? 1.0 : (double)p->window[i]);
-              wtaps[((((size_t)j * W + w) * 8 + m / 2) * 64 + t) * 4 + (size_t)(m & 1) * 2 + e] = (float)(v * scale);
+              // (RA9MB / limiter, N = 32768 only: the plain window, the scale follows the limiter as post_scale)
+              wtaps[((((size_t)j * W + w) * 8 + m / 2) * 64 + t) * 4 + (size_t)(m & 1) * 2 + e] = (float)(p->nonlin ? v : v * scale);
             }
     }
     p->wtapers = nwin;
@@ -328,7 +394,7 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   // --- odd taper count (spectro16x.hip): the last taper shares a transform with the next frame's;
   // |Y|^2 = |E|^2/4 there (no mirror-sum doubling), so its scale carries 1/4 instead of 1/2
   std::vector<float> xtaps;
-  if (cfg->mode == GLFER_MODE_MTM && (p->ntapers & 1) && p->ntapers >= 3) {
+  if (cfg->mode == GLFER_MODE_MTM && (p->ntapers & 1) && p->ntapers >= 3 && !small && !huge) {
     const int T = n / 16, j = p->ntapers - 1;
     const double scale = std::sqrt(1.0 / (4.0 * n * (1.0 + p->sig[j])));
     xtaps.resize((size_t)n);
@@ -496,7 +562,11 @@ int glfer_hip_make_dpss(int n, int kmax, double nw, double *tapers, double *sig)
   return glfer::make_dpss(n, kmax, nw, tapers, sig) ? GLFER_OK : GLFER_E_NUMERIC;
 }
 
+extern "C" hipError_t glfer_launch_spectro_small(const SpectroParams *p, int n, const float *staps, hipStream_t st);
+extern "C" hipError_t glfer_launch_spectro16w_n15(const SpectroParams *p, hipStream_t st);
+
 static hipError_t launch_packed(const SpectroParams &sp, int n, hipStream_t st) {
+  if (n < 256) return glfer_launch_spectro_small(&sp, n, sp.taps, st);   // the same role below the 16-points-per-lane range
   switch (n) {
     case 256: return glfer_launch_spectro16_n8(&sp, st);
     case 512: return glfer_launch_spectro16_n9(&sp, st);
@@ -534,6 +604,7 @@ static hipError_t launch_wave_private(const SpectroParams &sp, int n, hipStream_
     case 4096: return glfer_launch_spectro16w_n12(&sp, st);
     case 8192: return glfer_launch_spectro16w_n13(&sp, st);
     case 16384: return glfer_launch_spectro16w_n14(&sp, st);
+    case 32768: return glfer_launch_spectro16w_n15(&sp, st);
   }
   return hipErrorInvalidValue;
 }
@@ -575,6 +646,7 @@ static hipError_t launch_shared_odd(const SpectroParams &sp, int n, hipStream_t 
 // The first ceil(R/H) frames of a stream reach back before sample 0 (zero history, fft.c:103-108);
 // they stay with spectro16.hip, which has the range-checked gather for that.
 static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
+  if (n > 16384) return launch_wave_private(sp, n, st);        // its general form takes every case itself
   // spectro16h.hip fetches y[2j], y[2j+1] with one load: integer samples must then sit on naturally
   // aligned pairs (even hop, so every frame starts on an even sample, and an aligned stream)
   const unsigned esz = sp.fmt == GLFER_FMT_F32 ? 4u : (sp.fmt == GLFER_FMT_S16 ? 2u : 1u);
@@ -801,6 +873,7 @@ int glfer_hip_prepare_device(glfer_hip_plan *p, const void *d_stream, size_t nsa
 int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first,
                                size_t nframes, float *d_ftest, int mu_live, void *hip_stream) {
   if (!p || !d_stream || (!d_ftest && nframes) || p->cfg.mode != GLFER_MODE_MTM) return GLFER_E_ARG;
+  if (p->n > 16384) return GLFER_E_ARG;              // needs the packed form's spectrum output
   if (nframes == 0) return GLFER_OK;
   if ((first + nframes) > nsamples / (size_t)p->hop || nframes > 0x7fffffffu) return GLFER_E_ARG;
   hipStream_t st = (hipStream_t)hip_stream;

@@ -79,7 +79,11 @@ struct LaunchW {
 };
 
 // VAR 1: window / taper read from its table per transform; 2: the window in LDS (periodogram)
-template <int LOGN, int FMT, int MT, int VAR, int SETS, int WPS>
+// GEN 1: the general form -- samples gathered one by one, range-checked (frames that reach back
+// before sample 0 read zeros, fft.c:103-108; integer pairs need no alignment), RA9MB / limiter
+// (fft.c:127-156) and the halfcomplex spectrum output of fft_do.  Used where no other kernel takes
+// those cases: N = 32768 (the packed form stops at N = 16384).
+template <int LOGN, int FMT, int MT, int VAR, int SETS, int WPS, int GEN = 0>
 __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(SpectroParams p) {
   using L = LaunchW<LOGN>;
   using C = Plan16<10>;
@@ -169,6 +173,29 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
     const unsigned lrel = flc * (unsigned)p.H + 2u * (W * t + w);
+    if constexpr (GEN != 0) {
+      // one element at a time, through a descriptor that starts at sample max(sblk, 0): samples before
+      // the stream get an out-of-range offset and read 0 (raw value 0 is not sample 0.0 for u8, hence
+      // the select); px keeps FLOAT samples here, whatever the format
+      const long long sbase = sblk > 0 ? sblk : 0;
+      const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sbase * (long long)esz, 0, 0x7fffffff, 0x00020000);
+      const int rel0 = (int)(sblk - sbase) + (int)lrel;
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int off = 2 * W * 64 * m;
+        const int jfr = 2 * (int)(W * t + w) + off;       // index in the frame
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int rel = rel0 + off + e;
+          const bool ok = p.history_mode ? (jfr + e >= p.R) : (rel >= 0);
+          const float v = buf_sample<FMT>(grsrc, ok ? (unsigned)rel * esz : 0x80000000u, 0u);
+          if (e == 0) px[m].x = ok ? v : 0.0f;
+          else px[m].y = ok ? v : 0.0f;
+        }
+      });
+      return;
+    }
     static_for<0, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       constexpr unsigned off = 2u * W * 64u * m;           // samples
@@ -201,7 +228,7 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
   };
   auto sample_pair = [&](auto mc) -> v2f32 {
     constexpr int m = decltype(mc)::value;
-    if constexpr (FMT == GLFER_FMT_F32) {
+    if constexpr (FMT == GLFER_FMT_F32 || GEN != 0) {
       return px[m];
     } else if constexpr (FMT == GLFER_FMT_S16) {
       const int raw = (int)__float_as_uint(px[m].x);
@@ -230,7 +257,7 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
   // The k1 = 512 item: 1024 - 512 is 512 again, so one radix-W transform gives all of
   // Z[512 + 1024 k2] = sum_w a_w W_2W^w W_W^(w k2), and bin 512 + 1024 k2 pairs with bin
   // 512 + 1024 (W-1-k2).  v[k2] = |X[512 + 1024 k2]|^2.
-  auto special512 = [](float (&ar)[W], float (&ai)[W], float (&v)[W]) {
+  auto special512 = [](float (&ar)[W], float (&ai)[W], float (&v)[W], auto &&spec_out) {
     static_for<1, W>([&](auto wc) {
       constexpr int ww = decltype(wc)::value;
       constexpr cplx64 a = unit_root(ww, 2 * W);           // (cos, sin)(2 pi 512 ww / M)
@@ -251,6 +278,8 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
       const float x1r = er + pr, x1i = ei + pi, x2r = er - pr, x2i = ei - pi;
       v[k2] = __builtin_fmaf(x1r, x1r, x1i * x1i);
       v[W - 1 - k2] = __builtin_fmaf(x2r, x2r, x2i * x2i);
+      spec_out(k2, x1r, x1i);
+      if (W > 1) spec_out(W - 1 - k2, x2r, -x2i);
     });
   };
 
@@ -284,10 +313,23 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
     if constexpr (VAR == 1 && GLFER16W_WPREFETCH == 0) load_window(sj);
     static_for<0, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      const v2f32 x = sample_pair(mc);
-      const v2f32 ww = VAR == 2 ? wl[(w * 16 + m) * 64 + t] : window_pair(mc) * kSampleScale;
-      zr[m] = x.x * ww.x;
-      zi[m] = x.y * ww.y;
+      v2f32 x = sample_pair(mc);
+      const v2f32 ww = VAR == 2 ? wl[(w * 16 + m) * 64 + t] : window_pair(mc) * (GEN ? 1.0f : kSampleScale);
+      if (GEN != 0 && p.nonlin) {
+        // fft.c:127-156: RA9MB x/(a+x^2), window, then sign(y)|y|^0.1; the unit-power scale comes
+        // afterwards (post_scale) because the limiter is not linear (the table holds the plain window)
+        if (p.a > 0.0f) x = v2f32{x.x / (p.a + x.x * x.x), x.y / (p.a + x.y * x.y)};
+        v2f32 y = v2f32{x.x * ww.x, x.y * ww.y};
+        if (p.limiter) {
+          const float m0 = __expf(0.1f * __logf(fabsf(y.x))), m1 = __expf(0.1f * __logf(fabsf(y.y)));
+          y = v2f32{y.x > 0.0f ? m0 : -m0, y.y > 0.0f ? m1 : -m1};
+        }
+        zr[m] = y.x * p.post_scale;
+        zi[m] = y.y * p.post_scale;
+      } else {
+        zr[m] = x.x * ww.x;
+        zi[m] = x.y * ww.y;
+      }
     });
     // the next transform's table (VAR 1) and the next frame's samples are requested once pass 0 has
     // handed its data to LDS
@@ -388,6 +430,19 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
           put(v1, vup, (unsigned)(OFF + 1024 * k2) * 4u);                       // bin k
           put(v2, vdown, (unsigned)(KMAX - OFF - 1024 * k2) * 4u);              // bin M - k
         }
+        if constexpr (GEN != 0 && MT == 0) {
+          // fft_do's halfcomplex spectrum (fft_radix2.c:75-177): data[k] = Re X_k, data[N-k] = Im X_k.
+          // x1 = 2 s X[k], x2 = 2 s conj(X[M-k]) with s the factor folded into the window.
+          if (p.spec && cf + fl < p.nframes) {
+            float *o = p.spec + (size_t)(cf + fl) * (2 * M);
+            const float inv = 0.5f / p.spec_unscale;
+            const unsigned k = k1 + 1024u * k2, km = (unsigned)M - k;
+            o[k] = x1r * inv;
+            if (k > 0) o[2 * M - k] = x1i * inv;
+            o[km] = x2r * inv;
+            if (km < (unsigned)M) o[2 * M - km] = -x2i * inv;
+          }
+        }
       });
     };
     if (LF <= 512 || u < 512u) {
@@ -413,7 +468,17 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
           ar[ww] = a.x;
           ai[ww] = a.y;
         }
-        special512(ar, ai, v);
+        special512(ar, ai, v, [&](int k2, float xr, float xi) {
+          if constexpr (GEN != 0) {
+            if (p.spec && cf + fl < p.nframes) {
+              float *o = p.spec + (size_t)(cf + fl) * (2 * M);
+              const float inv = 0.5f / p.spec_unscale;
+              const unsigned k = 512u + 1024u * k2;
+              o[k] = xr * inv;
+              o[2 * M - k] = xi * inv;
+            }
+          }
+        });
 #pragma unroll
         for (int k2 = 0; k2 < W; k2++) put(v[k2], fl * ROWB, (512u + 1024u * k2) * 4u);
       }
@@ -430,7 +495,7 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
             ar[ww] = a.x;
             ai[ww] = a.y;
           }
-          special512(ar, ai, v);
+          special512(ar, ai, v, [](int, float, float) {});
 #pragma unroll
           for (int k2 = 0; k2 < W; k2++) red[t * W + k2] = v[k2];
         }
@@ -494,8 +559,19 @@ static hipError_t launch16w_fmt(const SpectroParams &p, hipStream_t st) {
   const long long resident = 256LL * per_cu;
   unsigned grid = (unsigned)(work < 8 * resident ? work : 8 * resident);
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
+#if GLFER_LOGN >= 15
+  // N = 32768: the only kernel for this size, so also its general form (zero history, unaligned
+  // integer pairs, RA9MB / limiter, spectrum output)
+  const bool general = p.nonlin || p.spec || p.frame0 * (long long)p.H < (long long)p.R ||
+                       (p.fmt != GLFER_FMT_F32 && ((p.H & 1) || (reinterpret_cast<uintptr_t>(p.stream) & (p.fmt == GLFER_FMT_S16 ? 3u : 1u))));
+  if (general) {
+    if (p.wtapers > 1) hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 0, 1, GLFER16W_SETS, WPS, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    return hipGetLastError();
+  }
+#endif
   if (p.wtapers > 1) {                             // the multitaper form keeps its sums in registers: two waves per SIMD
-    constexpr int WPS_MT = WPS > 2 ? 2 : WPS;
+    constexpr int WPS_MT = (WPS > 2 && L < 15) ? 2 : WPS;
     hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   } else {
     constexpr int VAR = (L <= 12) ? 2 : 1;         // the window in LDS where it costs no resident workgroup
@@ -537,16 +613,19 @@ static hipError_t launch16w_stamped(const SpectroParams &p0, hipStream_t st) {
 #endif
 
 extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16w_n, GLFER_LOGN)(const SpectroParams *p, hipStream_t st) {
-  if (!p->wtaps || !p->wtw || !p->wcomb || p->nonlin || p->spec) return hipErrorInvalidValue;
+  if (!p->wtaps || !p->wtw || !p->wcomb) return hipErrorInvalidValue;
 #ifdef GLFER16W_STAMPS
   if (p->fmt == GLFER_FMT_F32) return launch16w_stamped(*p, st);
 #endif
+#if GLFER_LOGN < 15
+  if (p->nonlin || p->spec) return hipErrorInvalidValue;
   // the gather has no zero-history path: every frame must lie wholly inside the stream
   if (p->frame0 * (long long)p->H < (long long)p->R) return hipErrorInvalidValue;
   if (p->fmt != GLFER_FMT_F32) {                   // integer pairs (y[2n], y[2n+1]) come with one load: naturally aligned
     const unsigned pair = p->fmt == GLFER_FMT_S16 ? 4u : 2u;
     if ((p->H & 1) || (reinterpret_cast<uintptr_t>(p->stream) & (pair - 1u))) return hipErrorInvalidValue;
   }
+#endif
   switch (p->fmt) {
     case GLFER_FMT_F32: return launch16w_fmt<GLFER_FMT_F32>(*p, st);
     case GLFER_FMT_S16: return launch16w_fmt<GLFER_FMT_S16>(*p, st);

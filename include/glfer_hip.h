@@ -70,7 +70,7 @@ extern "C" {
  * -> history_mode, fft.c:99). */
 typedef struct glfer_hip_config {
   int mode;            /* GLFER_MODE_*                                                  */
-  int n;               /* opt.data_block_size; power of two, 256..16384                    */
+  int n;               /* opt.data_block_size; power of two, 8..32768 (HP-ARMA: 256..16384)  */
   float overlap;       /* opt.data_blocks_overlap, [0,1)                                */
   int window_type;     /* opt.window_type (FFT mode; MTM forces rectangular, source.c:344) */
   float limiter_a;     /* opt.limiter_a  -> fft_params_t.a        (FFT mode only acts)  */
@@ -292,6 +292,17 @@ int glfer_hip_palette(int palette, unsigned char colortab[768]);
 int glfer_hip_display_device(glfer_hip_display *disp, const float *d_psd, const double *d_avg,
                              const float *d_stats, size_t nframes, int bins, unsigned char *d_rgb,
                              short *d_lev, float *d_levels, void *hip_stream);
+
+/* compute_floor + update_avg_* + the mapping for a batch of PSD rows in one call (statistics,
+ * [moving average], level tracking, pixel map; scratch for at most 65536 rows at a time).  A single
+ * pass over a row is not possible: the level tracking is a chain over the columns fed by every
+ * column's statistics, so a row is read once for those and once to be mapped.  avg_mode 0 =
+ * NO_AVG (the PSD rows are mapped), else GLFER_AVG_* with depth/minbin/maxbin/max0 as
+ * glfer_hip_avg_device (the state starts empty at row 0).  d_stats: [nframes][4] or NULL.
+ * disp carries the level-tracking state in and out; the call synchronises the stream per tile. */
+int glfer_hip_waterfall_device(glfer_hip_display *disp, int avg_mode, int depth, int minbin, int maxbin,
+                               int max0, const float *d_psd, size_t nframes, int bins,
+                               unsigned char *d_rgb, short *d_lev, float *d_stats, void *hip_stream);
 
 /* Host samples -> waterfall columns: estimator, compute_floor and the display mapping on the
  * device, chunked through the same ring as glfer_hip_spectrogram_host; what comes back is

@@ -441,3 +441,106 @@ def test_multitaper_forms_agree(lib, oracle, torch_cuda, n, overlap, kmax, nw, s
                 assert np.abs(got[f] - want[f]).max() <= TOL * want[f].max(), (form, f)
     finally:
         os.environ.pop("GLFER_FORM", None)
+
+
+# ---- block sizes outside 256 .. 16384 (the reference takes any power of two, g_options.c:386-387) ---------
+@pytest.mark.parametrize("n", [8, 16, 32, 64, 128, 32768])
+def test_block_sizes_outside_the_16_point_range(lib, oracle, torch_cuda, n):
+    """N = 8..128 (spectro_small.hip) and N = 32768 (spectro16w.hip, W = 16, also its general form:
+    zero-history frames, RA9MB / limiter, spectrum output, integer samples on odd hops): periodogram
+    with every option, multitaper with odd and even taper counts, LMP, against the oracle."""
+    big = n > 16384
+    frames = 7 if big else 40
+    for window, overlap, kw in (("hanning", 0.5, {}), ("kaiser", 0.0, dict(sub_mean=1)), ("blackman", 0.75, dict(a=0.001)),
+                                ("hamming", 0.25, dict(limiter=1)), ("rectangular", 0.5, dict(history_mode=1))):
+        h = oracle.hop(n, overlap)
+        x = synth(frames * h + min(3, h - 1), fs=8000.0, seed=n) + np.float32(0.03)
+        want = oracle.spectrogram_fft(x, n, overlap, oracle.WINDOWS[window], kw.get("a", 0.0), kw.get("limiter", 0),
+                                      kw.get("sub_mean", 0), kw.get("history_mode", 0))
+        sp = lib.Spectrogram(lib.FftParams(n=n, window_type=lib.WINDOWS[window], overlap=overlap, **kw))
+        got = sp.run(torch_cuda.from_numpy(x).cuda()).cpu().numpy()
+        tol = 2e-4 if kw.get("limiter") else TOL
+        assert got.shape == want.shape == (frames, n // 2 + 1)
+        if big and not kw:
+            # At N = 32768 the REFERENCE's float32 recurrence-twiddle transform is itself ~7e-5 away from
+            # exact arithmetic in this norm (fft_radix2.c:127-141; measured here with numpy's float64
+            # rfft), so parity is: the device within 1e-6 of the exact transform, and no further from
+            # the reference than the reference is from exact (x1.1)
+            w64 = oracle.window(oracle.WINDOWS[window], n).astype(np.float64)
+            fr = np.zeros(n)
+            for f in range(frames):
+                fr = np.concatenate([fr[h:], x[f * h:(f + 1) * h].astype(np.float64)])
+                exact = np.abs(np.fft.rfft(fr * w64)) ** 2 / n
+                ref_err = max(rel_err(want[f], exact))
+                assert max(rel_err(got[f], exact)) < 1e-6, f
+                assert max(rel_err(got[f], want[f])) <= max(TOL, 1.1 * ref_err), (f, ref_err)
+            continue
+        if big:
+            tol = 2e-4                                             # the reference's own error at this size, see above
+        assert max(max(rel_err(got[f], want[f])) for f in range(frames)) < tol, (window, kw)
+    # halfcomplex spectrum (what fft_do leaves in outbuf)
+    x = synth(5 * n, fs=8000.0, seed=3)
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=0, overlap=0.0))
+    psd, spec = sp.run(torch_cuda.from_numpy(x).cuda(), spectrum=True)
+    w = oracle.window(0, n)
+    for f in range(5):
+        want = oracle.rfft_halfcomplex(w * x[f * n:(f + 1) * n])
+        if big:                                                    # the reference transform is ~4e-5 off at this size: exact arithmetic instead
+            X = np.fft.rfft((w * x[f * n:(f + 1) * n]).astype(np.float64))
+            want = np.concatenate([X.real, X.imag[1:n // 2][::-1]])
+        assert np.abs(spec[f].cpu().numpy() - want).max() <= 2e-6 * np.abs(want).max(), f
+    # integer samples on an odd hop (pairs unaligned), PCM conversion in the gather
+    raw = np.clip(np.round(synth(frames * n, seed=5) * 20000), -32768, 32767).astype(np.int16)
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=7, overlap=0.33, sample_format=lib.SAMPLES_S16))
+    want = oracle.spectrogram_fft(oracle.pcm_s16_to_float(raw), n, 0.33, 7)
+    got = sp.run(torch_cuda.from_numpy(raw).cuda()).cpu().numpy()
+    assert max(max(rel_err(got[f], want[f])) for f in range(want.shape[0])) < (2e-4 if big else TOL)
+    # multitaper, odd and even counts; LMP
+    for kmax, nw, overlap in ((4, 2.5, 0.5), (3, 2.5, 0.0), (0, 1.0, 0.0)):
+        if n < 16 and kmax > 1:
+            continue
+        h = oracle.hop(n, overlap)
+        x = synth(frames * h, fs=8000.0, seed=n + kmax)
+        want = oracle.spectrogram_mtm(x, n, overlap, nw, kmax)
+        got = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax)).run(torch_cuda.from_numpy(x).cuda()).cpu().numpy()
+        for f in range(frames):
+            assert np.abs(got[f] - want[f]).max() <= (2e-4 if big else TOL) * want[f].max(), (kmax, f)
+    x = synth(frames * n, fs=8000.0, seed=9)
+    got = lib.Spectrogram(lib.LmpParams(n=n, overlap=0.0, avg=3)).run(torch_cuda.from_numpy(x).cuda()).cpu().numpy()
+    want = oracle.spectrogram_lmp(x, n, 0.0, 3)
+    if big:     # the reference's transform is ~7e-5 off at this size and the statistic amplifies it: check the epilogue instead
+        P = lib.Spectrogram(lib.FftParams(n=n, window_type=lib.WINDOWS["rectangular"], overlap=0.0)).run(
+            torch_cuda.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
+        assert np.allclose(got, _lmp_numpy(P, 3), rtol=3e-7, atol=0)
+        assert np.all(_frame_err(got, want) < 5e-2)
+    else:
+        assert np.all(_frame_err(got, want) < (1e-2 if n < 64 else 1e-3))     # the statistic's conditioning, see test_lmp_vs_oracle
+
+
+def test_waterfall_device_tiles_equal_the_separate_stages(lib, torch_cuda):
+    """glfer_hip_waterfall_device (floor -> [average] -> levels -> map, tiles of 65536 rows) against the
+    three stages run over the whole batch: identical pixels, levbuf, statistics and carried state,
+    with and without averaging, across a tile boundary (70 000 rows of 513 bins)."""
+    torch = torch_cuda
+    rows, bins = 70000, 513
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    psd = (torch.rand((rows, bins), device="cuda", generator=g) ** 4 * 1e-3).contiguous()
+    stats = lib.compute_floor(psd)
+    for kw in (dict(scale_type=lib.SCALE_LOG, autoscale=1, overlap=0.5, palette=0),
+               dict(scale_type=lib.SCALE_LIN_MAX0, autoscale=0, max_level_db=-30.0, min_level_db=-80.0, thr_level=10.0, palette=5)):
+        for avg_mode, max0 in ((0, 0), (lib.AVG_PLAIN, 0), (lib.AVG_SUMEXTREME, 1)):
+            d1, d2 = lib.Display(**kw), lib.Display(**kw)
+            if avg_mode:
+                src, _ = lib.update_avg(avg_mode, psd, 4, 25, 500, max0=max0)
+            else:
+                src = psd
+            rgb_w, lev_w, _ = lib.display(d1, src, stats)
+            rgb, lev, st = lib.waterfall(d2, psd, avg_mode=avg_mode, depth=4, minbin=25, maxbin=500, max0=max0, want_stats=True)
+            assert torch.equal(st, stats)
+            if avg_mode == lib.AVG_SUMEXTREME:
+                # reduction order of the band statistics differs between a restart and the full run by ulps
+                assert (rgb != rgb_w).float().mean().item() < 1e-4 and (lev != lev_w).float().mean().item() < 1e-4
+            else:
+                assert torch.equal(rgb, rgb_w) and torch.equal(lev, lev_w), (kw["scale_type"], avg_mode)
+            assert (d1.first_buffer, d1.display_max_lvl, d1.display_min_lvl) == (d2.first_buffer, d2.display_max_lvl, d2.display_min_lvl)

@@ -24,3 +24,19 @@ for scale, auto in ((G.SCALE_LOG, 1), (G.SCALE_LOG, 0), (G.SCALE_LIN, 1)):
     d = G.Display(scale_type=scale, autoscale=auto, overlap=0.5)
     dt = timeit(lambda: G.display(G.Display(scale_type=scale, autoscale=auto, overlap=0.5), psd, stats))
     print("display scale=%d autoscale=%d: %.2f M rows/s  %.0f GB/s (read 4 B, write 5 B per bin)" % (scale, auto, rows / dt / 1e6, rows * bins * 9 / dt / 1e9))
+
+# the whole chain of main_window_draw for a batch: stage by stage over the whole batch (each stage
+# sweeps 1 GiB of rows from HBM) against glfer_hip_waterfall_device (tiles that stay on the die)
+def separate(avg):
+    st = G.compute_floor(psd)
+    if avg:
+        a, _ = G.update_avg(G.AVG_PLAIN, psd, 4, 25, 2000)
+        return G.display(G.Display(scale_type=G.SCALE_LOG, autoscale=1, overlap=0.5), a, st)
+    return G.display(G.Display(scale_type=G.SCALE_LOG, autoscale=1, overlap=0.5), psd, st)
+
+for avg in (0, 1):
+    dt1 = timeit(lambda: separate(avg), reps=3)
+    dt2 = timeit(lambda: G.waterfall(G.Display(scale_type=G.SCALE_LOG, autoscale=1, overlap=0.5), psd,
+                                     avg_mode=G.AVG_PLAIN if avg else 0, depth=4, minbin=25, maxbin=2000), reps=3)
+    print("floor%s + display, log autoscale: stage by stage %.2f M rows/s, tiled (glfer_hip_waterfall_device) %.2f M rows/s"
+          % (" + avg(plain,4)" if avg else "", rows / dt1 / 1e6, rows / dt2 / 1e6))
