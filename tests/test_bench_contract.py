@@ -6,7 +6,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ["r01_bench_line.json", "r01_bench_line_fft_c2.json", "r01_bench_line_hparma_c5.json"]
+LINES = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith(("r01_bench_line", "r02_bench_line")))
 
 
 @pytest.mark.parametrize("name", LINES)

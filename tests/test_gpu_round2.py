@@ -544,3 +544,24 @@ def test_waterfall_device_tiles_equal_the_separate_stages(lib, torch_cuda):
             else:
                 assert torch.equal(rgb, rgb_w) and torch.equal(lev, lev_w), (kw["scale_type"], avg_mode)
             assert (d1.first_buffer, d1.display_max_lvl, d1.display_min_lvl) == (d2.first_buffer, d2.display_max_lvl, d2.display_min_lvl)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver types it -- the parent starts the two ranks itself --
+    end to end on this box's one GPU (GLFER_BENCH_REHEARSE=1: both ranks on cuda:0, gloo for the
+    barrier and the max over ranks; a rehearsal of the launch path and the per-rank sharding, not a
+    measurement).  Two GPU processes, within the box's limit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GLFER_BENCH_REHEARSE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--frames", "8192", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["frames_per_gpu_per_step"] == 8192
+    assert abs(line["value"] - 2 * 8192 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]

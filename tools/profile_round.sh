@@ -19,3 +19,10 @@ for W in $WL; do
   find $D -name '*_kernel_trace.csv' -size +2M -delete
   echo "$W passes done"
 done
+# the per-column stages (floor / average / display): kernel stats of tools/aux_sweep.py
+if [ -z "$SKIP_AUX" ]; then
+  D=$R/gpurun_out/prof_aux; rm -rf $D; mkdir -p $D; cd $R
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 tools/aux_sweep.py > $D/stats.log 2>&1
+  find $D -name '*_kernel_trace.csv' -size +2M -delete
+  echo "aux pass done"
+fi

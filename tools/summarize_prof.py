@@ -19,7 +19,8 @@ os.makedirs(out, exist_ok=True)
 
 
 def one(pattern):
-    return sorted(glob.glob(os.path.join(prof, pattern)))[-1]
+    # the newest file: gpurun merges a call's files into what earlier calls left under gpurun_out/
+    return max(glob.glob(os.path.join(prof, pattern)), key=os.path.getmtime)
 
 
 rows = list(csv.DictReader(open(one("stats/*/*_kernel_stats.csv"))))
