@@ -370,7 +370,7 @@ def test_floor_statistics(lib, oracle, torch_cuda):
     assert np.allclose(got[:, 1], want[:, 1], rtol=2e-6, atol=1e-12)
 
 
-@pytest.mark.parametrize("bins", [129, 257, 513, 1025, 2049, 4097, 8193, 100, 2048, 3000])
+@pytest.mark.parametrize("bins", [129, 257, 513, 1025, 2049, 4097, 8193, 100, 2048, 3000, 5, 17, 65, 8257, 16385, 32769])
 def test_floor_statistics_row_shapes(lib, oracle, torch_cuda, bins):
     # every row length the estimator produces (one wavefront per row up to 2049 bins, one workgroup
     # per row above), lengths that do not fill the last lane group, and rows built to stress the
@@ -402,7 +402,8 @@ def test_floor_statistics_row_shapes(lib, oracle, torch_cuda, bins):
     assert np.array_equal(got[:, [0, 2, 3]], want[:, [0, 2, 3]])
     # the reference adds the m = 5 % smallest bins in float, in sorted order (fft.c:271-273); the kernels
     # add them in double: up to m/2 ulp apart (m = 410 at 8193 bins), inside the 1e-5 of the PSD itself
-    assert np.allclose(got[:, 1], want[:, 1], rtol=TOL, atol=1e-44)
+    m = bins - int(bins * 0.95)
+    assert np.allclose(got[:, 1], want[:, 1], rtol=max(TOL, 0.6 * m * 2.0 ** -24), atol=1e-44)    # m/2 ulp: 5e-5 at 32769 bins
 
 
 @pytest.mark.parametrize("mode_name,mode_id", [("plain", 2), ("sumextreme", 3), ("sumavg", 1)])

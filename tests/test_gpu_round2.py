@@ -565,3 +565,26 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["frames_per_gpu_per_step"] == 8192
     assert abs(line["value"] - 2 * 8192 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
+def test_per_column_stages_at_n32768(lib, oracle, torch_cuda):
+    """compute_floor, update_avg and the display map on 16385-bin rows (N = 32768): the floor's
+    workgroup-per-row form with > 64 KB of dynamic LDS at 32769 bins is covered by
+    test_floor_statistics_row_shapes; here the whole chain on real rows."""
+    n = 32768
+    x = synth(12 * n, fs=8000.0, seed=41)
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=7, overlap=0.0))
+    psd = sp.run(torch_cuda.from_numpy(x).cuda())
+    rows = psd.cpu().numpy()
+    stats = lib.compute_floor(psd).cpu().numpy().astype(np.float64)
+    want = np.array([oracle.floor_stats(r) for r in rows], np.float64)
+    assert np.array_equal(stats[:, [0, 2, 3]], want[:, [0, 2, 3]]) and np.allclose(stats[:, 1], want[:, 1], rtol=TOL)
+    avg, ret = lib.update_avg(lib.AVG_PLAIN, psd, 4, 100, 16000, n_out=n)
+    a = oracle.Averager(n, 4)
+    for f in range(rows.shape[0]):
+        r, av, peak, _ = a.update("plain", rows[f], 100, 16000, n=16385)
+        assert np.array_equal(avg[f, :16385].cpu().numpy(), av) and abs(ret[f, 0].item() / r - 1) < 1e-11 and int(ret[f, 1].item()) == peak
+    d = lib.Display(scale_type=lib.SCALE_LOG, autoscale=1, overlap=0.0, palette=3)
+    rgb, lev, _ = lib.display(d, psd, lib.compute_floor(psd))
+    rgb_w, lev_w, _, _ = oracle.display(rows, stats, palette_id=3, scale_log=True, autoscale=True, overlap=0.0)
+    assert np.array_equal(rgb.cpu().numpy(), rgb_w) and np.array_equal(lev.cpu().numpy(), lev_w)
