@@ -66,7 +66,9 @@ struct LaunchH {
 // folded in) applied in turn to the frame held in registers, |X|^2 summed per bin in 17 more
 // registers and stored after the last one.  Used where a frame's N-point exchange buffer would leave
 // one workgroup per CU (N >= 8192): the real-input form needs half of it.  VAR must be 1.
-template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0>
+// HIST = 1: history zeroed in every frame (history_mode ZERO_ALWAYS).  A template parameter because as
+// a run-time test the compiler turns the zeroing into 32 unconditional selects per frame.
+template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0>
 __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(SpectroParams p) {
   static_assert(MT == 0 || VAR == 1, "the multitaper form re-reads its window per taper");
   using L = LaunchH<LOGN>;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
         px[m].x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, lrel, (unsigned)(2 * T * m), 0));
       }
     });
-    if (p.history_mode) {        // history_mode 1: sample j = 2*(t + T*m) + e is kept iff j >= R.  Zeroed in
+    if constexpr (HIST != 0) {   // history_mode 1: sample j = 2*(t + T*m) + e is kept iff j >= R.  Zeroed in
       const int d = 2 * (int)t - p.R;                  // place (this waits for the loads; a rare mode)
       static_for<0, 16>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
@@ -217,11 +219,22 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     if constexpr (VAR == 1) load_window(j);
     v2f32 xs[16];
     static_for<0, 16>([&](auto mc) { xs[decltype(mc)::value] = sample_pair(mc); });
+    if constexpr (VAR == 2) {
+      // 16 ds_read_b64 with immediate offsets: left to the compiler they become ds_read2_b64 (half
+      // the rate) behind one address add each
+      v2f32 wv[16];
+      lds_read16_strided<T>(wl + t, wv);
 #pragma unroll
-    for (int m = 0; m < 16; m++) {
-      const v2f32 w = VAR == 2 ? wl[m * T + t] : wn[m];
-      zr[m] = xs[m].x * w.x;
-      zi[m] = xs[m].y * w.y;
+      for (int m = 0; m < 16; m++) {
+        zr[m] = xs[m].x * wv[m].x;
+        zi[m] = xs[m].y * wv[m].y;
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        zr[m] = xs[m].x * wn[m].x;
+        zi[m] = xs[m].y * wn[m].y;
+      }
     }
     if constexpr (GLFER16H_PREFETCH_TOP != 0 && !(GLFER_H_ABL & 2)) {
       if (has_next && last) prefetch_x(nfblk);         // px is free as soon as xs is formed
@@ -331,12 +344,14 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
 #if GLFER_LOGN >= 13
   if (p.htapers > 1) {
-    hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, 1, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    if (p.history_mode) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, 1, 1, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, 1, 1, 0>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
     return hipGetLastError();
   }
 #endif
   if (p.htapers > 1) return hipErrorInvalidValue;      // the multitaper form is built for N >= 8192 only
-  hipLaunchKernelGGL((spectro16h_kernel<L, FMT>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+  if (p.history_mode) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+  else hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 0>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   return hipGetLastError();
 }
 

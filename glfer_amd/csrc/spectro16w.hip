@@ -83,7 +83,9 @@ struct LaunchW {
 // before sample 0 read zeros, fft.c:103-108; integer pairs need no alignment), RA9MB / limiter
 // (fft.c:127-156) and the halfcomplex spectrum output of fft_do.  Used where no other kernel takes
 // those cases: N = 32768 (the packed form stops at N = 16384).
-template <int LOGN, int FMT, int MT, int VAR, int SETS, int WPS, int GEN = 0>
+// HIST = 1: history zeroed in every frame (a template parameter: as a run-time test the zeroing
+// becomes 32 unconditional selects per frame).
+template <int LOGN, int FMT, int MT, int VAR, int SETS, int WPS, int GEN = 0, int HIST = 0>
 __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(SpectroParams p) {
   using L = LaunchW<LOGN>;
   using C = Plan16<10>;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
         px[m].x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, lrel, off, 0));
       }
     });
-    if (p.history_mode) {        // sample j = 2n + e is kept iff j >= R (fft.c:103-108); a rare mode
+    if constexpr (HIST != 0) {   // sample j = 2n + e is kept iff j >= R (fft.c:103-108); a rare mode
       const int d = 2 * (int)(W * t + w) - p.R;
       static_for<0, 16>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
@@ -311,10 +313,12 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
     W_STAMP(sit, 0);                                       // S begins
     float zr[16], zi[16];
     if constexpr (VAR == 1 && GLFER16W_WPREFETCH == 0) load_window(sj);
+    v2f32 wv[VAR == 2 ? 16 : 1];
+    if constexpr (VAR == 2) lds_read16_strided<64>(wl + w * (16 * 64) + t, wv);   // plain ds_read_b64, immediate offsets
     static_for<0, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       v2f32 x = sample_pair(mc);
-      const v2f32 ww = VAR == 2 ? wl[(w * 16 + m) * 64 + t] : window_pair(mc) * (GEN ? 1.0f : kSampleScale);
+      const v2f32 ww = VAR == 2 ? wv[VAR == 2 ? m : 0] : window_pair(mc) * (GEN ? 1.0f : kSampleScale);
       if (GEN != 0 && p.nonlin) {
         // fft.c:127-156: RA9MB x/(a+x^2), window, then sign(y)|y|^0.1; the unit-power scale comes
         // afterwards (post_scale) because the limiter is not linear (the table holds the plain window)
@@ -572,10 +576,12 @@ static hipError_t launch16w_fmt(const SpectroParams &p, hipStream_t st) {
 #endif
   if (p.wtapers > 1) {                             // the multitaper form keeps its sums in registers: two waves per SIMD
     constexpr int WPS_MT = (WPS > 2 && L < 15) ? 2 : WPS;
-    hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    if (p.history_mode) hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT, 0, 0>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   } else {
     constexpr int VAR = (L <= 12) ? 2 : 1;         // the window in LDS where it costs no resident workgroup
-    hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 0, VAR, GLFER16W_SETS, WPS>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    if (p.history_mode) hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 0, VAR, GLFER16W_SETS, WPS, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 0, VAR, GLFER16W_SETS, WPS, 0, 0>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   }
   return hipGetLastError();
 }

@@ -235,12 +235,26 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
         }
       } else {
         const v2f32 *rbase = xb + t + (t >> xpad_shift(i));
-        static_for<0, 16>([&](auto mc) {
-          constexpr int m = decltype(mc)::value;
-          const v2f32 v = rbase[xpad_offset(i, m * T)];
-          zr[m] = v.x;
-          zi[m] = v.y;
-        });
+        // entry distance between a lane's reads: xpad_offset(i, m*T) = m * (T + T/32) when T is a
+        // multiple of 32 -- 16 plain ds_read_b64 with immediate offsets where they fit the 16-bit
+        // field (the compiler's own choice is ds_read2_b64 / ds_read2st64_b64: half the rate)
+        constexpr int STRIDE = xpad_offset(i, T);
+        if constexpr (GLFER16_X0_ROWS != 0 && T % 32 == 0 && i > 0 && 15 * STRIDE * 8 < 65536 && xpad_offset(i, 15 * T) == 15 * STRIDE) {
+          v2f32 v[16];
+          lds_read16_strided<STRIDE>(rbase, v);
+#pragma unroll
+          for (int m = 0; m < 16; m++) {
+            zr[m] = v[m].x;
+            zi[m] = v[m].y;
+          }
+        } else {
+          static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const v2f32 v = rbase[xpad_offset(i, m * T)];
+            zr[m] = v.x;
+            zi[m] = v.y;
+          });
+        }
       }
       // With the barrier here (the reads have landed: the barrier waits for lgkmcnt(0)) instead
       // of in front of the next writes, those writes are not fenced off from the butterflies
@@ -332,18 +346,32 @@ __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA
         }
       } else {
         const v2f32 *ra = xbA + t + (t >> xpad_shift(i)), *rb = xbB + t + (t >> xpad_shift(i));
-        static_for<0, 16>([&](auto mc) {
-          constexpr int m = decltype(mc)::value;
-          const v2f32 v = ra[xpad_offset(i, m * T)];
-          zrA[m] = v.x;
-          ziA[m] = v.y;
-        });
-        static_for<0, 16>([&](auto mc) {
-          constexpr int m = decltype(mc)::value;
-          const v2f32 v = rb[xpad_offset(i, m * T)];
-          zrB[m] = v.x;
-          ziB[m] = v.y;
-        });
+        constexpr int STRIDE = xpad_offset(i, T);
+        if constexpr (GLFER16_X0_ROWS != 0 && T % 32 == 0 && i > 0 && 15 * STRIDE * 8 < 65536 && xpad_offset(i, 15 * T) == 15 * STRIDE) {
+          v2f32 va[16], vb[16];                // plain ds_read_b64, immediate offsets (see stockham16_passes)
+          lds_read16_strided<STRIDE>(ra, va);
+          lds_read16_strided<STRIDE>(rb, vb);
+#pragma unroll
+          for (int m = 0; m < 16; m++) {
+            zrA[m] = va[m].x;
+            ziA[m] = va[m].y;
+            zrB[m] = vb[m].x;
+            ziB[m] = vb[m].y;
+          }
+        } else {
+          static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const v2f32 v = ra[xpad_offset(i, m * T)];
+            zrA[m] = v.x;
+            ziA[m] = v.y;
+          });
+          static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const v2f32 v = rb[xpad_offset(i, m * T)];
+            zrB[m] = v.x;
+            ziB[m] = v.y;
+          });
+        }
       }
       frame_sync<T>();                       // both buffers read: free for the next writes
       GLFER_STAMP(4 * i + 4);                // both streams' reads landed, through the barrier
