@@ -16,7 +16,9 @@ namespace glfer {
 // offset + immediates.  history_mode 1 (fft.c:103-108 with glfer.first_buffer stuck at TRUE) zeroes
 // the first R samples of every frame afterwards.  A frame slot past the last frame re-reads the
 // last one (its results are dropped).
-template <int FMT, int T>
+// HIST: -1 = test p.history_mode at run time (the compiler turns that into 16 unconditional
+// selects per frame); 0 / 1 = decided at compile time by the caller.
+template <int FMT, int T, int HIST = -1>
 __device__ __forceinline__ void load_frame16(const SpectroParams &p, unsigned t, unsigned fl, long long fblk, float (&dst)[16]) {
   constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
   const long long f = fblk + fl;
@@ -29,7 +31,7 @@ __device__ __forceinline__ void load_frame16(const SpectroParams &p, unsigned t,
     constexpr int m = decltype(mc)::value;
     dst[m] = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(T * m) * esz);
   });
-  if (p.history_mode) {
+  if (HIST == 1 || (HIST < 0 && p.history_mode)) {
     const int d = (int)t - p.R;
     static_for<0, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;

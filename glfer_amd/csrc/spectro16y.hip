@@ -25,7 +25,7 @@ struct LaunchY {
 };
 
 // ABL (tools/xbench timing ablations only; results are wrong): 1 = skip the shared round
-template <int FMT, int ABL = 0>
+template <int FMT, int ABL = 0, int HIST = 0>
 __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
   using C = Plan16<12>;
   using L = LaunchY;
@@ -67,7 +67,11 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
   const int NP = p.npairs - 1;                       // full (two-taper) rounds per frame
   const long long stride = (long long)gridDim.x * 2;
 
-  auto load_x = [&](float (&dst)[16], long long f) { load_frame16<FMT, T>(p, t, 0u, f, dst); };
+  // (loads are unconditional -- a frame index past the end re-reads the last frame -- so that the
+  // compiler has nothing to turn into selects; what such a slot computes is dropped)
+  auto load_x = [&](float (&dst)[16], long long f) {
+    load_frame16<FMT, T, HIST>(p, t, 0u, f < p.nframes ? f : (long long)p.nframes - 1, dst);
+  };
   v2f32 pt[16];          // full round: the next taper pair; shared round: pt[0..7] = the last taper
   auto prefetch_taps = [&](int pair) {
     const unsigned tap_p = (unsigned)pair * (N * 8u);
@@ -102,7 +106,6 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
   auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };   // register of bin t + T*m
 
   while (true) {                                     // one iteration: frames A = fA and B = fA + 1
-    const bool hasB = fA + 1 < p.nframes;            // block-uniform
     const long long nfA = fA + stride;
     const bool has_next = nfA < p.nframes;
     float psdA[8], psdB[8], nyqA, nyqB;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
     {
       float accA[16], accB[16];
 #pragma unroll
-      for (int r = 0; r < 16; r++) accA[r] = accB[r] = 0.0f;
+      for (int r = 0; r < 16; r++) accA[r] = accB[r] = 0.0f;     // (dead when NP >= 1: pair 0 overwrites)
       for (int pair = 0; pair < NP; pair++) {
         // ---- one full round of both frames: re = x*taper(2*pair), im = x*taper(2*pair+1)
         float zrA[16], ziA[16], zrB[16], ziB[16];
@@ -126,10 +129,18 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
           if (pair + 1 < NP) prefetch_taps(pair + 1);
           else prefetch_last();
         });
+        if (pair == 0) {                             // the first pair starts the sums (no zeroing pass)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          accA[r] = __builtin_fmaf(zrA[r], zrA[r], __builtin_fmaf(ziA[r], ziA[r], accA[r]));
-          accB[r] = __builtin_fmaf(zrB[r], zrB[r], __builtin_fmaf(ziB[r], ziB[r], accB[r]));
+          for (int r = 0; r < 16; r++) {
+            accA[r] = __builtin_fmaf(zrA[r], zrA[r], ziA[r] * ziA[r]);
+            accB[r] = __builtin_fmaf(zrB[r], zrB[r], ziB[r] * ziB[r]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            accA[r] = __builtin_fmaf(zrA[r], zrA[r], __builtin_fmaf(ziA[r], ziA[r], accA[r]));
+            accB[r] = __builtin_fmaf(zrB[r], zrB[r], __builtin_fmaf(ziB[r], ziB[r], accB[r]));
+          }
         }
         GLFER_STAMP(15);                             // dual round end
       }
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
       if (has_next) {
         prefetch_taps(0);
         load_x(xA, nfA);
-        if (nfA + 1 < p.nframes) load_x(xB, nfA + 1);
+        load_x(xB, nfA + 1);
       }
       if (t == 0) p.psd[(size_t)fA * (N / 2 + 1)] = psdA[0] + psdB[0] + nyqA + nyqB + (float)(hxA + hxB);
       if (!has_next) break;
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
       for (int m = 0; m < 16; m++) {
         const float v = (m & 1) ? pt[m / 2].y : pt[m / 2].x;
         zr[m] = (xA[m] * v) * sA;
-        zi[m] = hasB ? (xB[m] * v) * sB : 0.0f;
+        zi[m] = (xB[m] * v) * sB;                    // no frame B: xB is all zeros (set below)
       }
     }
     // the next iteration's samples and first taper pair go out after the first exchange's writes
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
       if (has_next) {
         prefetch_taps(0);
         load_x(xA, nfA);
-        if (nfA + 1 < p.nframes) load_x(xB, nfA + 1);
+        load_x(xB, nfA + 1);
       }
     });
     separate_and_store<12, 1>(p, zr, zi, xbA, t, 0u, fA, hxA, hxB,
@@ -235,11 +246,16 @@ static hipError_t launch16y_fmt(const SpectroParams &p, hipStream_t st) {
   const long long resident = 256LL * 2;
   unsigned grid = (unsigned)(work < 16 * resident ? work : 16 * resident);   // tools/xbench: 16x beats 4x by ~2 %
   if (grid >= 64) grid &= ~7u;                       // whole XCD slices: see xcd_block_index()
-  auto kern = spectro16y_kernel<FMT>;
   constexpr size_t shmem = (size_t)LaunchY::LDS_WORDS * 8;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, st, p);
+  static bool raised = false;                        // once per process and format, not per launch
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(spectro16y_kernel<FMT, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(spectro16y_kernel<FMT, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    raised = true;
+  }
+  if (p.history_mode) hipLaunchKernelGGL((spectro16y_kernel<FMT, 0, 1>), dim3(grid), dim3(256), shmem, st, p);
+  else hipLaunchKernelGGL((spectro16y_kernel<FMT, 0, 0>), dim3(grid), dim3(256), shmem, st, p);
   return hipGetLastError();
 }
 
