@@ -228,8 +228,9 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   *out = nullptr;
   const int n = cfg->n;
   // any power of two the user can type (g_options.c:386-387): 8 .. 128 through spectro_small.hip,
-  // 256 .. 16384 through the 16-points-per-lane kernels, 32768 through spectro16w.hip alone
-  if (!is_pow2(n) || n < 8 || n > 32768) return GLFER_E_ARG;
+  // 256 .. 16384 through the 16-points-per-lane kernels, 32768 through spectro16w.hip alone, 65536
+  // through spectro_big.hip (sub-transforms and combine as two kernels around a scratch in HBM)
+  if (!is_pow2(n) || n < 8 || n > 65536) return GLFER_E_ARG;
   if (cfg->mode == GLFER_MODE_HPARMA && (n < 256 || n > 16384)) return GLFER_E_ARG;
   const bool small = n < 256, huge = n > 16384;
   if (!(cfg->overlap >= 0.0f) || !(cfg->overlap < 1.0f)) return GLFER_E_ARG;   // g_options.c:1030
@@ -379,9 +380,9 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     p->wtapers = nwin;
     wtw.resize((size_t)2 * glfer::make_twiddles16(10, nullptr) * 64);
     glfer::make_twiddles16(10, wtw.data());
-    wcomb.resize((size_t)2 * IPL * W * LF);
+    wcomb.resize(n <= 32768 ? (size_t)2 * IPL * W * LF : 2);      // (N = 65536 computes its twiddles in the kernels)
     const double two_pi = 2.0 * 3.14159265358979323846;
-    for (int i = 0; i < IPL; i++)
+    for (int i = 0; i < IPL && n <= 32768; i++)
       for (int ww = 0; ww < W; ww++)
         for (int u = 0; u < LF; u++) {
           const long long k1 = u + (long long)LF * i;
@@ -564,6 +565,7 @@ int glfer_hip_make_dpss(int n, int kmax, double nw, double *tapers, double *sig)
 
 extern "C" hipError_t glfer_launch_spectro_small(const SpectroParams *p, int n, const float *staps, hipStream_t st);
 extern "C" hipError_t glfer_launch_spectro16w_n15(const SpectroParams *p, hipStream_t st);
+extern "C" hipError_t glfer_launch_spectro_big(const SpectroParams *p, int n, hipStream_t st);
 
 static hipError_t launch_packed(const SpectroParams &sp, int n, hipStream_t st) {
   if (n < 256) return glfer_launch_spectro_small(&sp, n, sp.taps, st);   // the same role below the 16-points-per-lane range
@@ -605,6 +607,7 @@ static hipError_t launch_wave_private(const SpectroParams &sp, int n, hipStream_
     case 8192: return glfer_launch_spectro16w_n13(&sp, st);
     case 16384: return glfer_launch_spectro16w_n14(&sp, st);
     case 32768: return glfer_launch_spectro16w_n15(&sp, st);
+    case 65536: return glfer_launch_spectro_big(&sp, n, st);
   }
   return hipErrorInvalidValue;
 }

@@ -54,7 +54,11 @@ template <int LOGN>
 struct LaunchH {
   using C = Plan16<LOGN - 1>;
   static constexpr int M = C::N, TH = C::T;
+#ifdef GLFER16H_FPB
+  static constexpr int FPB = GLFER16H_FPB;                 // A/B builds: frames per workgroup
+#else
   static constexpr int FPB = TH >= 256 ? 1 : 256 / TH;
+#endif
   static constexpr int BLOCK = TH * FPB;
   static constexpr int PADM = M + M / 16;
   static constexpr int LDS_WORDS = FPB * PADM + 16 * 17;
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
 
   {
     const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.htw);
-    if (tid < 256) {
-      const unsigned k = tid >> 4, q = tid & 15;
+    for (unsigned i = tid; i < 256; i += L::BLOCK) {
+      const unsigned k = i >> 4, q = i & 15;
       tw1[k * 17 + q] = q ? tw[(q - 1) * T + k] : v2f32{1.0f, 0.0f};
     }
   }

@@ -1,0 +1,198 @@
+// spectro_big.hip -- block sizes whose sub-transforms no longer fit one workgroup's LDS (N = 65536:
+// W = N/2048 = 32 wavefront-private 1024-point transforms per frame and taper, 256 KB of results).
+// The same decimation-in-time split as spectro16w.hip, cut into two kernels around a scratch buffer
+// in HBM:
+//   subfft_kernel  : one wavefront per (frame, taper, w): gather z[W j + w] = y[2n] + i y[2n+1],
+//                    window, the 1024-point transform (stockham16.hpp), times W_M^(w k1), out to
+//                    scratch[frame][taper][w][k1]
+//   combine_kernel : one lane per bin pair (k1, 1024 - k1): the radix-W butterflies, the real-input
+//                    split X[k] = (E + P)/2, |X|^2 summed over the tapers, PSD row out
+// General by construction: range-checked gather (zero history, any alignment), RA9MB / limiter,
+// periodogram and multitaper.  Very-slow-CW sizes; a correct path, not a tuned one.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "stockham16.hpp"
+
+namespace glfer {
+
+template <int FMT>
+__global__ __launch_bounds__(256) void subfft_kernel(SpectroParams p, int W, int ntap, long long f0, int nf,
+                                                     v2f32 *__restrict__ scratch) {
+  using C = Plan16<10>;
+  constexpr int TW1 = 15, NT = C::NTW - TW1, STRIP = 1024 + 64;
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  __shared__ v2f32 lds[4 * STRIP + 16 * 17];
+  const unsigned tid = threadIdx.x, t = tid & 63u, wv = tid >> 6;
+  v2f32 *tw1 = lds + 4 * STRIP;
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.wtw);
+    const unsigned k = tid >> 4, q = tid & 15;
+    tw1[k * 17 + q] = q ? tw[(q - 1) * 64 + k] : v2f32{1.0f, 0.0f};
+  }
+  float twr[NT], twi[NT];
+  {
+    const v2f32 *tw = reinterpret_cast<const v2f32 *>(p.wtw) + t;
+#pragma unroll
+    for (int e = 0; e < NT; e++) {
+      const v2f32 x = tw[(TW1 + e) * 64];
+      twr[e] = x.x;
+      twi[e] = x.y;
+    }
+  }
+  __syncthreads();
+  const v2f32 *tw1row = tw1 + (t & 15) * 17;
+  v2f32 *xb = lds + wv * STRIP;
+  const int M = 1024 * W;
+  // work item = (frame, taper, w), four consecutive w per workgroup
+  const long long items = (long long)nf * ntap * W;
+  for (long long it0 = (long long)blockIdx.x * 4; it0 < items; it0 += (long long)gridDim.x * 4) {
+    const long long it = it0 + wv;                          // W is a multiple of 4: the four wavefronts share frame and taper
+    const bool live = it < items;
+    const long long itc = live ? it : items - 1;
+    const int w = (int)(itc % W), j = (int)((itc / W) % ntap);
+    const long long fr = itc / ((long long)W * ntap);
+    const long long f = f0 + fr;
+    // ---- gather: sample index in the frame 2(W(t+64m)+w)+e, in the stream s0 + that
+    const long long s0 = (p.frame0 + f) * (long long)p.H - p.R;
+    const long long sbase = s0 > 0 ? s0 : 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sbase * (long long)esz, 0, 0x7fffffff, 0x00020000);
+    const int rel0 = (int)(s0 - sbase) + 2 * (W * (int)t + w);
+    typedef float v4f32 __attribute__((ext_vector_type(4)));
+    const v4f32 *ht = reinterpret_cast<const v4f32 *>(p.wtaps) + ((size_t)j * W + w) * (8 * 64) + t;
+    float zr[16], zi[16];
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const int off = 2 * W * 64 * m;
+      float xv[2];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int rel = rel0 + off + e, jfr = 2 * (W * (int)t + w) + off + e;
+        const bool ok = p.history_mode ? (jfr >= p.R) : (rel >= 0);
+        const float v = buf_sample<FMT>(rs, ok ? (unsigned)rel * esz : 0x80000000u, 0u);
+        xv[e] = ok ? v : 0.0f;
+      }
+      const v4f32 q = ht[64 * (m / 2)];
+      const float w0 = (m & 1) ? q.z : q.x, w1 = (m & 1) ? q.w : q.y;
+      if (p.nonlin) {                                       // fft.c:127-156 (the table holds the plain window)
+        if (p.a > 0.0f) {
+          xv[0] = xv[0] / (p.a + xv[0] * xv[0]);
+          xv[1] = xv[1] / (p.a + xv[1] * xv[1]);
+        }
+        float y0 = xv[0] * w0, y1 = xv[1] * w1;
+        if (p.limiter) {
+          const float m0 = __expf(0.1f * __logf(fabsf(y0))), m1 = __expf(0.1f * __logf(fabsf(y1)));
+          y0 = y0 > 0.0f ? m0 : -m0;
+          y1 = y1 > 0.0f ? m1 : -m1;
+        }
+        zr[m] = y0 * p.post_scale;
+        zi[m] = y1 * p.post_scale;
+      } else {
+        zr[m] = xv[0] * w0;
+        zi[m] = xv[1] * w1;
+      }
+    });
+    stockham16_passes<10, NT>(zr, zi, xb, t, tw1row, twr, twi, [] {});
+    // ---- A_w[k1] * W_M^(w k1) to the scratch; register rho_of(m) holds bin t + 64 m
+    if (live) {
+      v2f32 *o = scratch + (((size_t)fr * ntap + j) * W + w) * 1024;
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int r = (m % 4) + 4 * brev(m / 4, 4);
+        const int k1 = (int)t + 64 * m;
+        float sn, cs;
+        sincospif(-2.0f * (float)((long long)w * k1 % M) / (float)M, &sn, &cs);
+        o[k1] = v2f32{__builtin_fmaf(zr[r], cs, -zi[r] * sn), __builtin_fmaf(zr[r], sn, zi[r] * cs)};
+      });
+    }
+  }
+}
+
+// one lane per item k1 = 0..512 of a frame: bins k1 + 1024 k2 and their mirrors M - k
+template <int W>
+__global__ __launch_bounds__(64) void combine_kernel(SpectroParams p, int ntap, long long f0, int nf,
+                                                     const v2f32 *__restrict__ scratch) {
+  const int M = 1024 * W;
+  const long long fr = blockIdx.y;
+  const int k1 = blockIdx.x * 64 + threadIdx.x;
+  if (fr >= nf || k1 > 512) return;
+  const int k1m = (1024 - k1) & 1023;
+  float acc[2 * W];
+#pragma unroll
+  for (int i = 0; i < 2 * W; i++) acc[i] = 0.0f;
+  float c0, s0;                                            // (cos, sin)(2 pi k1 / N), N = 2M
+  {
+    float sn, cs;
+    sincospif((float)k1 / (float)M, &sn, &cs);
+    c0 = cs;
+    s0 = sn;
+  }
+  for (int j = 0; j < ntap; j++) {
+    const v2f32 *S = scratch + (((size_t)fr * ntap + j) * W) * 1024;
+    float ar[W], ai[W], br[W], bi[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+      const v2f32 a = S[(size_t)w * 1024 + k1], b = S[(size_t)w * 1024 + k1m];
+      ar[w] = a.x; ai[w] = a.y; br[w] = b.x; bi[w] = b.y;
+    }
+    dit<W, 1, 0, W>(ar, ai);                               // Z[k1 + 1024 k2] at index brev(k2)
+    dit<W, 1, 0, W>(br, bi);                               // Z[1024 - k1 + 1024 k2] at index brev(k2)
+    static_for<0, W>([&](auto kc) {
+      constexpr int k2 = decltype(kc)::value;
+      constexpr int ia = brev(k2, W), ib = brev(W - 1 - k2, W), ic = brev((W - k2) % W, W);
+      // mirror partner of k = k1 + 1024 k2: M - k = (1024 - k1) + 1024 (W-1-k2); for k1 = 0 it is 1024 (W - k2)
+      const float qr = k1 == 0 ? ar[ic] : br[ib], qi = k1 == 0 ? ai[ic] : bi[ib];
+      const float er = ar[ia] + qr, ei = ai[ia] - qi, orr = ar[ia] - qr, oi = ai[ia] + qi;
+      constexpr cplx64 uu = unit_root(k2, 2 * W);          // (cos, sin)(2 pi 1024 k2 / N)
+      constexpr float cm = (float)uu.c, sm = (float)uu.s;
+      const float c = __builtin_fmaf(c0, cm, -s0 * sm), s = __builtin_fmaf(s0, cm, c0 * sm);
+      const float pr = __builtin_fmaf(c, oi, -s * orr), pi = -__builtin_fmaf(c, orr, s * oi);
+      const float x1r = er + pr, x1i = ei + pi, x2r = er - pr, x2i = ei - pi;
+      acc[2 * k2] = __builtin_fmaf(x1r, x1r, __builtin_fmaf(x1i, x1i, acc[2 * k2]));
+      acc[2 * k2 + 1] = __builtin_fmaf(x2r, x2r, __builtin_fmaf(x2i, x2i, acc[2 * k2 + 1]));
+    });
+  }
+  float *o = p.psd + (size_t)(f0 + fr) * (M + 1);
+#pragma unroll
+  for (int k2 = 0; k2 < W; k2++) {
+    o[k1 + 1024 * k2] = acc[2 * k2];
+    o[M - k1 - 1024 * k2] = acc[2 * k2 + 1];               // (k1 = 0 and 512 write some bins twice, with equal values)
+  }
+}
+
+}  // namespace glfer
+
+using namespace glfer;
+
+// frames [p->frame0 .. +nframes) in groups that keep the scratch under ~512 MiB; p->psd is row 0 of the launch
+extern "C" hipError_t glfer_launch_spectro_big(const SpectroParams *p, int n, hipStream_t st) {
+  if (n != 65536 || !p->wtaps || !p->wtw || p->spec) return hipErrorInvalidValue;
+  if (p->nframes <= 0) return hipSuccess;
+  constexpr int W = 32;
+  const int ntap = p->wtapers > 0 ? p->wtapers : 1;
+  const size_t per_frame = (size_t)ntap * W * 1024 * sizeof(v2f32);
+  long long group = (long long)(((size_t)512 << 20) / per_frame);
+  if (group < 1) group = 1;
+  if (group > p->nframes) group = p->nframes;
+  v2f32 *scratch = nullptr;
+  hipError_t e = hipMallocAsync((void **)&scratch, (size_t)group * per_frame, st);
+  if (e != hipSuccess) return e;
+  for (long long f0 = 0; f0 < p->nframes && e == hipSuccess; f0 += group) {
+    const int nf = (int)((p->nframes - f0 < group) ? p->nframes - f0 : group);
+    const long long blocks = ((long long)nf * ntap * W + 3) / 4;
+    const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
+    switch (p->fmt) {
+      case GLFER_FMT_F32: hipLaunchKernelGGL(subfft_kernel<GLFER_FMT_F32>, dim3(grid), dim3(256), 0, st, *p, W, ntap, f0, nf, scratch); break;
+      case GLFER_FMT_S16: hipLaunchKernelGGL(subfft_kernel<GLFER_FMT_S16>, dim3(grid), dim3(256), 0, st, *p, W, ntap, f0, nf, scratch); break;
+      case GLFER_FMT_U8: hipLaunchKernelGGL(subfft_kernel<GLFER_FMT_U8>, dim3(grid), dim3(256), 0, st, *p, W, ntap, f0, nf, scratch); break;
+      default: e = hipErrorInvalidValue;
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(combine_kernel<W>, dim3(9, (unsigned)nf), dim3(64), 0, st, *p, ntap, f0, nf, scratch);
+      e = hipGetLastError();
+    }
+  }
+  (void)hipFreeAsync(scratch, st);
+  return e;
+}

@@ -444,7 +444,7 @@ def test_multitaper_forms_agree(lib, oracle, torch_cuda, n, overlap, kmax, nw, s
 
 
 # ---- block sizes outside 256 .. 16384 (the reference takes any power of two, g_options.c:386-387) ---------
-@pytest.mark.parametrize("n", [8, 16, 32, 64, 128, 32768])
+@pytest.mark.parametrize("n", [8, 16, 32, 64, 128, 32768, 65536])
 def test_block_sizes_outside_the_16_point_range(lib, oracle, torch_cuda, n):
     """N = 8..128 (spectro_small.hip) and N = 32768 (spectro16w.hip, W = 16, also its general form:
     zero-history frames, RA9MB / limiter, spectrum output, integer samples on odd hops): periodogram
@@ -476,14 +476,18 @@ def test_block_sizes_outside_the_16_point_range(lib, oracle, torch_cuda, n):
                 assert max(rel_err(got[f], want[f])) <= max(TOL, 1.1 * ref_err), (f, ref_err)
             continue
         if big:
-            tol = 2e-4                                             # the reference's own error at this size, see above
+            tol = 2e-4 if n == 32768 else 1e-3                     # the reference's own error at these sizes, see above
         assert max(max(rel_err(got[f], want[f])) for f in range(frames)) < tol, (window, kw)
+    if n > 32768:                      # no spectrum output from the two-kernel form (glfer_hip.h)
+        with pytest.raises(lib.GlferHipError):
+            lib.Spectrogram(lib.FftParams(n=n, window_type=0, overlap=0.0)).run(torch_cuda.zeros(n, device="cuda"), spectrum=True)
+        torch_cuda.cuda.synchronize()
     # halfcomplex spectrum (what fft_do leaves in outbuf)
     x = synth(5 * n, fs=8000.0, seed=3)
     sp = lib.Spectrogram(lib.FftParams(n=n, window_type=0, overlap=0.0))
-    psd, spec = sp.run(torch_cuda.from_numpy(x).cuda(), spectrum=True)
     w = oracle.window(0, n)
-    for f in range(5):
+    psd, spec = sp.run(torch_cuda.from_numpy(x).cuda(), spectrum=True) if n <= 32768 else (None, None)
+    for f in range(5 if n <= 32768 else 0):
         want = oracle.rfft_halfcomplex(w * x[f * n:(f + 1) * n])
         if big:                                                    # the reference transform is ~4e-5 off at this size: exact arithmetic instead
             X = np.fft.rfft((w * x[f * n:(f + 1) * n]).astype(np.float64))
@@ -494,7 +498,7 @@ def test_block_sizes_outside_the_16_point_range(lib, oracle, torch_cuda, n):
     sp = lib.Spectrogram(lib.FftParams(n=n, window_type=7, overlap=0.33, sample_format=lib.SAMPLES_S16))
     want = oracle.spectrogram_fft(oracle.pcm_s16_to_float(raw), n, 0.33, 7)
     got = sp.run(torch_cuda.from_numpy(raw).cuda()).cpu().numpy()
-    assert max(max(rel_err(got[f], want[f])) for f in range(want.shape[0])) < (2e-4 if big else TOL)
+    assert max(max(rel_err(got[f], want[f])) for f in range(want.shape[0])) < ((2e-4 if n == 32768 else 1e-3) if big else TOL)
     # multitaper, odd and even counts; LMP
     for kmax, nw, overlap in ((4, 2.5, 0.5), (3, 2.5, 0.0), (0, 1.0, 0.0)):
         if n < 16 and kmax > 1:
@@ -504,7 +508,7 @@ def test_block_sizes_outside_the_16_point_range(lib, oracle, torch_cuda, n):
         want = oracle.spectrogram_mtm(x, n, overlap, nw, kmax)
         got = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax)).run(torch_cuda.from_numpy(x).cuda()).cpu().numpy()
         for f in range(frames):
-            assert np.abs(got[f] - want[f]).max() <= (2e-4 if big else TOL) * want[f].max(), (kmax, f)
+            assert np.abs(got[f] - want[f]).max() <= ((2e-4 if n == 32768 else 1e-3) if big else TOL) * want[f].max(), (kmax, f)
     x = synth(frames * n, fs=8000.0, seed=9)
     got = lib.Spectrogram(lib.LmpParams(n=n, overlap=0.0, avg=3)).run(torch_cuda.from_numpy(x).cuda()).cpu().numpy()
     want = oracle.spectrogram_lmp(x, n, 0.0, 3)
@@ -512,7 +516,7 @@ def test_block_sizes_outside_the_16_point_range(lib, oracle, torch_cuda, n):
         P = lib.Spectrogram(lib.FftParams(n=n, window_type=lib.WINDOWS["rectangular"], overlap=0.0)).run(
             torch_cuda.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
         assert np.allclose(got, _lmp_numpy(P, 3), rtol=3e-7, atol=0)
-        assert np.all(_frame_err(got, want) < 5e-2)
+        assert np.all(_frame_err(got, want) < (5e-2 if n == 32768 else 0.25))      # the reference transform error, amplified
     else:
         assert np.all(_frame_err(got, want) < (1e-2 if n < 64 else 1e-3))     # the statistic's conditioning, see test_lmp_vs_oracle
 
