@@ -128,16 +128,29 @@ def self_launch(args, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()                                   # this exact child, by PID
-            p.wait()
-        rc = rc or p.returncode
+    # rank 0's stdout is read on a thread while every child is polled: a rank that dies (a bad device,
+    # an RCCL error) must not leave the others waiting at a barrier for ever
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            rc = failed[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                           # these exact children, by PID
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    for p in procs:
+        p.wait()
+    reader.join(timeout=10)
+    out = b"".join(c for c in chunks if c)
     for ln in out.decode(errors="replace").splitlines():       # the JSON line on stdout, anything else on stderr
         print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr)
     sys.stdout.flush()
@@ -149,6 +162,8 @@ def dry_run(args, world, rank):
     gloo, no GPU.  tests/test_bench_contract.py uses it to exercise `--gpus 2` as typed."""
     import torch
     import torch.distributed as dist
+    if os.environ.get("GLFER_BENCH_FAIL_RANK") == str(rank):      # test hook: this rank dies before the rendezvous
+        sys.exit(3)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)

@@ -68,3 +68,13 @@ def test_bench_under_a_launcher_is_one_rank():
     assert r.returncode == 0 and json.loads(r.stdout.strip())["n_gpus"] == 1
     r = _run_bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_parent_gives_up_when_a_rank_dies():
+    """A rank that exits before the rendezvous must not leave the others (and the driver) waiting:
+    the parent polls its children, ends the rest and exits with the failing rank's code."""
+    import time
+    t0 = time.time()
+    r = _run_bench("--gpus", "2", "--dry-run", env={"GLFER_BENCH_FAIL_RANK": "1"})
+    assert r.returncode == 3 and time.time() - t0 < 120
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
