@@ -38,6 +38,7 @@ EXPORTS = [
     "glfer_hip_frame_range", "glfer_hip_prepare_device", "glfer_hip_mtm_ftest_device", "glfer_hip_host_alloc",
     "glfer_hip_host_free", "glfer_hip_spectrogram_host_multi", "glfer_hip_spectrogram_wav_ex",
     "glfer_hip_avg_cum_device", "glfer_hip_waterfall_host", "glfer_hip_waterfall_device",
+    "glfer_hip_spectrogram_host_workers",
 ]
 
 
@@ -130,6 +131,7 @@ def lib():
     L.glfer_hip_host_free.argtypes = [vp]
     L.glfer_hip_host_free.restype = None
     L.glfer_hip_spectrogram_host_multi.argtypes = [C.POINTER(Config), C.c_uint, vp, sz, vp, C.POINTER(sz)]
+    L.glfer_hip_spectrogram_host_workers.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), C.c_int, vp, sz, vp, C.POINTER(sz)]
     L.glfer_hip_spectrogram_wav_ex.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz), sz, C.c_uint]
     L.glfer_hip_avg_cum_device.argtypes = [vp, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.glfer_hip_waterfall_device.argtypes = [C.POINTER(Display), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, C.c_int,
@@ -386,12 +388,17 @@ def spectrogram_host_multi(params, samples, devices, out=None):
     frames = samples.size // hop
     if out is None:
         out = np.empty((frames, params.n // 2 + 1), np.float32)
-    mask = 0
-    for d in devices:
-        mask |= 1 << d
     nf = C.c_size_t(0)
-    _check(lib().glfer_hip_spectrogram_host_multi(C.byref(cfg), mask, samples.ctypes.data, samples.size,
-                                                  out.ctypes.data, C.byref(nf)), "glfer_hip_spectrogram_host_multi")
+    if len(set(devices)) == len(devices):
+        mask = 0
+        for d in devices:
+            mask |= 1 << d
+        _check(lib().glfer_hip_spectrogram_host_multi(C.byref(cfg), mask, samples.ctypes.data, samples.size,
+                                                      out.ctypes.data, C.byref(nf)), "glfer_hip_spectrogram_host_multi")
+    else:                                   # workers sharing a GPU: glfer_hip_spectrogram_host_workers
+        devs = (C.c_int * len(devices))(*devices)
+        _check(lib().glfer_hip_spectrogram_host_workers(C.byref(cfg), devs, len(devices), samples.ctypes.data, samples.size,
+                                                        out.ctypes.data, C.byref(nf)), "glfer_hip_spectrogram_host_workers")
     return out[:nf.value]
 
 

@@ -339,17 +339,16 @@ int glfer_hip_waterfall_host(glfer_hip_plan *p, glfer_hip_display *disp, const v
 // node.  One host thread per GPU, each with its own plan, streams and pinned ring (run_job); the
 // ranges come from the same arithmetic as glfer_amd/shard.py; rows land in disjoint ranges of
 // h_psd; nothing is exchanged between GPUs.
-int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned device_mask, const void *h_stream,
-                                     size_t nsamples, float *h_psd, size_t *nframes_out) {
-  if (!cfg || !h_stream || !nframes_out || device_mask == 0) return GLFER_E_ARG;
+// One worker (host thread + plan + two streams + pinned ring) per entry of devices[]; an ordinal may
+// appear more than once -- several workers then share that GPU, which is how a one-GPU box exercises
+// the whole multi-worker path (frame offsets, halos from the middle of the stream, disjoint rows).
+int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *devices, int nworkers,
+                                       const void *h_stream, size_t nsamples, float *h_psd, size_t *nframes_out) {
+  if (!cfg || !devices || nworkers < 1 || nworkers > 64 || !h_stream || !nframes_out) return GLFER_E_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return hip_fail(hipGetLastError(), "hipGetDeviceCount");
-  std::vector<int> devs;
-  for (int d = 0; d < 32; d++)
-    if (device_mask & (1u << d)) {
-      if (d >= ndev) return GLFER_E_ARG;
-      devs.push_back(d);
-    }
+  for (int i = 0; i < nworkers; i++)
+    if (devices[i] < 0 || devices[i] >= ndev) return GLFER_E_ARG;
   // hop and bins as every plan will compute them (fft.c:70)
   const int hop = (int)(cfg->n * (1.0 - cfg->overlap));
   if (hop <= 0) return GLFER_E_ARG;
@@ -357,7 +356,7 @@ int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned devic
   *nframes_out = frames;
   if (frames == 0) return GLFER_OK;
   if (!h_psd) return GLFER_E_ARG;
-  const unsigned world = (unsigned)devs.size();
+  const unsigned world = (unsigned)nworkers;
   const size_t hop_bytes = (size_t)hop * sample_bytes(cfg->sample_format);
   std::vector<int> rcs(world, GLFER_OK);
   std::vector<std::string> msgs(world);
@@ -367,7 +366,7 @@ int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned devic
     frame_range(frames, r, world, &first, &count);
     if (count == 0) return;
     glfer_hip_config c = *cfg;
-    c.device = devs[r];
+    c.device = devices[r];
     glfer_hip_plan *plan = nullptr;
     int rc = glfer_hip_plan_create(&c, &plan);
     if (rc == GLFER_OK) {
@@ -400,6 +399,19 @@ int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned devic
       return rcs[r];
     }
   return GLFER_OK;
+}
+
+// ---- multi-GPU: source.c:130-158 over one stream, the frame range dealt out over the GPUs of the
+// node.  One host thread per GPU, each with its own plan, streams and pinned ring (run_job); the
+// ranges come from the same arithmetic as glfer_amd/shard.py; rows land in disjoint ranges of
+// h_psd; nothing is exchanged between GPUs.
+int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned device_mask, const void *h_stream,
+                                     size_t nsamples, float *h_psd, size_t *nframes_out) {
+  if (device_mask == 0) return GLFER_E_ARG;
+  int devs[32], n = 0;
+  for (int d = 0; d < 32; d++)
+    if (device_mask & (1u << d)) devs[n++] = d;
+  return glfer_hip_spectrogram_host_workers(cfg, devs, n, h_stream, nsamples, h_psd, nframes_out);
 }
 
 // ---- ingest (wav_fmt.c:45-121, source.c:118-128) ------------------------------------------

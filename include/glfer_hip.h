@@ -195,6 +195,12 @@ void glfer_hip_host_free(void *p);
 int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned device_mask,
                                      const void *h_stream, size_t nsamples, float *h_psd,
                                      size_t *nframes_out);
+/* The same with the workers listed: one host thread + plan + streams + pinned ring per entry of
+ * devices[0..nworkers); an ordinal may repeat (workers then share that GPU -- how a one-GPU machine
+ * runs, and tests, the multi-worker path).  _multi is this with the mask's devices, one worker each. */
+int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *devices, int nworkers,
+                                       const void *h_stream, size_t nsamples, float *h_psd,
+                                       size_t *nframes_out);
 
 /* ---- ingest: the file source of source.c:118-128 / wav_fmt.c:45-121 ------------------------
  * The canonical 44-byte RIFF/WAVE header of wav_fmt.h:34-52, read with fixed-width fields

@@ -342,6 +342,23 @@ def test_multi_gpu_entry_frame_ranges_on_one_device(lib, oracle, torch_cuda):
         assert cover == frames
     with pytest.raises(lib.GlferHipError, match="bad argument"):
         lib.spectrogram_host_multi(params, x, [ndev])          # a device the box does not have
+    # two and three workers on device 0: one host thread, plan, stream pair and pinned ring each; every
+    # worker but the first starts in the middle of the stream (frame offset, halo from the host array)
+    for workers in ([0, 0], [0, 0, 0]):
+        got = lib.spectrogram_host_multi(params, x, workers)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), workers
+    for p2, fr in ((lib.FftParams(n=1024, window_type=7, overlap=0.9, sub_mean=1), 70001),      # ragged history: 9.04 hops
+                   (lib.LmpParams(n=1024, overlap=0.5, avg=4), 40003),
+                   (lib.MtmParams(n=16384, overlap=0.5, w=4.5, kmax=8, sample_format=lib.SAMPLES_S16), 700)):
+        sp2 = lib.Spectrogram(p2)
+        raw = synth(fr * sp2.hop, seed=43)
+        if p2.sample_format == lib.SAMPLES_S16:
+            raw = np.round(raw * 30000).astype(np.int16)
+        one = sp2.run(torch_cuda.from_numpy(raw).cuda()).cpu().numpy()
+        two = lib.spectrogram_host_multi(p2, raw, [0, 0])
+        assert two.shape == one.shape
+        same = (two == one) | (np.isnan(two) & np.isnan(one))
+        assert same.all(), type(p2).__name__
 
 
 def test_waterfall_host_entry(lib, oracle, torch_cuda):
