@@ -316,6 +316,19 @@ def main():
         line["valu"] = {"lane_ops_per_frame": lane_ops, "achieved_Tops": frames * lane_ops / (kernel_ms * 1e-3) / 1e12,
                         "peak_Tops": VALU_PEAK_TOPS,
                         "frac": frames * lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}
+        if args.workload == "hparma":
+            # HP-ARMA is neither HBM- nor FP32-bound: a counted FP64 model of hparma_do (hparma.c:74-157 +
+            # compute_svd, util.c:261-386) at t = 128, p_e = 32: t lags x N double multiply-adds; the
+            # one-sided Jacobi SVD, >= 12 sweeps x 528 column pairs x (three length-t dot products + the
+            # rotation of two columns of the t x 33 matrix and of the 33 x 33 accumulator); Horner over
+            # N/2+1 bins x 33 coefficients, complex.  A LOWER bound (12 sweeps is the minimum the reference runs).
+            t_, ncol = 128, 33
+            flops = 2.0 * t_ * n + 12 * (ncol * (ncol - 1) / 2) * (3 * 2 * t_ + 6 * t_ + 6 * ncol) + (n / 2 + 1) * ncol * 8
+            line["valu"] = {"model": "counted FP64 flops of hparma_do, lower bound (12 Jacobi sweeps)", "flops_per_frame_f64": flops,
+                            "achieved_TFLOPs": frames * flops / (kernel_ms * 1e-3) / 1e12, "peak_TFLOPs": 78.6,
+                            "frac": frames * flops / (kernel_ms * 1e-3) / 1e12 / 78.6,
+                            "note": "latency-bound: one wavefront per frame walks the Jacobi rotations in the reference's order"}
+            line["roofline"]["note"] = "not HBM-bound (24.6 KB per frame of algorithmic traffic): see valu (FP64)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, n, overlap, nw, kmax, cpu_frames)
         print(json.dumps(line))
