@@ -628,14 +628,12 @@ static hipError_t launch_shared_odd(const SpectroParams &sp, int n, hipStream_t 
       case 512: return glfer_launch_spectro16xl_n9(&sp, st);
       case 1024: return glfer_launch_spectro16xl_n10(&sp, st);
       case 2048: return glfer_launch_spectro16xl_n11(&sp, st);
-      case 4096: return glfer_launch_spectro16xl_n12(&sp, st);
     }
   }
   switch (n) {
     case 256: return glfer_launch_spectro16x_n8(&sp, st);
     case 512: return glfer_launch_spectro16x_n9(&sp, st);
     case 1024: return glfer_launch_spectro16x_n10(&sp, st);
-    case 4096: return glfer_launch_spectro16x_n12(&sp, st);
   }
   return hipErrorInvalidValue;
 }

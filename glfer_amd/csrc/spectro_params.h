@@ -53,12 +53,10 @@ hipError_t glfer_launch_spectro16_n14(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16x_n8(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16x_n9(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16x_n10(const SpectroParams *p, hipStream_t st);
-hipError_t glfer_launch_spectro16x_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16xl_n8(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16xl_n9(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16xl_n10(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16xl_n11(const SpectroParams *p, hipStream_t st);
-hipError_t glfer_launch_spectro16xl_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16y_n12(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n9(const SpectroParams *p, hipStream_t st);
 hipError_t glfer_launch_spectro16h_n10(const SpectroParams *p, hipStream_t st);
