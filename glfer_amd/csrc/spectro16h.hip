@@ -44,6 +44,9 @@
 #ifndef GLFER16H_PREFETCH_TOP
 #define GLFER16H_PREFETCH_TOP 0    /* 1: next frame's samples requested at the top of the iteration, not after exchange 0's writes */
 #endif
+#ifndef GLFER16H_SHIFT_BUILDS
+#define GLFER16H_SHIFT_BUILDS 1    /* build the register-reuse forms for 75 % and 50 % overlap */
+#endif
 #ifndef GLFER16H_STORE_AUX
 #define GLFER16H_STORE_AUX (GLFER_LOGN_OR(12) >= 12 ? 2 : 0)   /* non-temporal from N = 4096 up (rows written once; +3 %, N = 8192 +25 %); below that a store covers only part of a line per frame and must merge in L2 (nt: -17 % at N = 1024, -40 % at N = 512) */
 #endif
@@ -72,8 +75,13 @@ struct LaunchH {
 // one workgroup per CU (N >= 8192): the real-input form needs half of it.  VAR must be 1.
 // HIST = 1: history zeroed in every frame (history_mode ZERO_ALWAYS).  A template parameter because as
 // a run-time test the compiler turns the zeroing into 32 unconditional selects per frame.
-template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0>
+// SHIFT = K > 0: the hop is K of a lane's 16 sample registers (H/2 = K * N/32 points), so a frame's
+// registers K..15 ARE its successor's registers 0..15-K: every frame slot of a workgroup walks
+// CONSECUTIVE frames, keeps those 16-K pairs and loads only the K new ones (75 % overlap: 4 loads
+// per lane and frame instead of 16).
+template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0, int SHIFT = 0>
 __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(SpectroParams p) {
+  static_assert(SHIFT == 0 || (MT == 0 && HIST == 0), "register reuse: periodogram, history from the stream");
   static_assert(MT == 0 || VAR == 1, "the multitaper form re-reads its window per taper");
   using L = LaunchH<LOGN>;
   using C = typename L::C;
@@ -142,16 +150,21 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   // ((frame0+f)*H >= R; the first ceil(R/H) frames of a stream go to spectro16.hip, which has the
   // zero-history gather), so every load is in range: one shared VGPR offset + immediates.
   // history_mode 1 zeroes the first R samples of every frame afterwards (fft.c:103-108).
-  auto prefetch_x = [&](long long fblk) {
-    const long long f = fblk + fl;
-    const unsigned flc = f < p.nframes ? fl : (unsigned)(p.nframes - 1 - fblk);
-    const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
+  // A workgroup walks the frames start .. start + per*FPB - 1; `rel` is a frame's index in that
+  // range, clamped to the launch's last frame (a slot past the end re-reads that frame; what it
+  // computes is dropped by the output descriptor's range check).
+  long long start = 0;                                   // first frame of the workgroup's range
+  auto load_pairs = [&](long long rel, auto fromc) {
+    constexpr int FROM = decltype(fromc)::value;         // registers FROM..15 are loaded
+    const long long last_rel = (long long)p.nframes - 1 - start;
+    const unsigned relc = (unsigned)(rel < last_rel ? rel : last_rel);
+    const long long sblk = (p.frame0 + start) * (long long)p.H - p.R;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
-    const unsigned lrel = flc * (unsigned)p.H + 2u * t;
+    const unsigned lrel = relc * (unsigned)p.H + 2u * t;
     // y[2n] and y[2n+1] are adjacent: ONE load per pair in every format (the launcher sends streams
     // whose pairs are not naturally aligned to spectro16.hip)
-    static_for<0, 16>([&](auto mc) {
+    static_for<FROM, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       if constexpr (FMT == GLFER_FMT_F32) {
         px[m] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, lrel * 4u, (unsigned)(2 * T * m) * 4u, 0));
@@ -161,6 +174,19 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
         px[m].x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, lrel, (unsigned)(2 * T * m), 0));
       }
     });
+  };
+  // the next frame of this slot: with SHIFT its first 16-SHIFT pairs are already here
+  auto prefetch_next = [&](long long rel) {
+    if constexpr (SHIFT > 0) {
+#pragma unroll
+      for (int m = 0; m < 16 - SHIFT; m++) px[m] = px[m + SHIFT];
+      load_pairs(rel, std::integral_constant<int, 16 - SHIFT>{});
+    } else {
+      load_pairs(rel, std::integral_constant<int, 0>{});
+    }
+  };
+  auto prefetch_x = [&](long long rel) {
+    load_pairs(rel, std::integral_constant<int, 0>{});
     if constexpr (HIST != 0) {   // history_mode 1: sample j = 2*(t + T*m) + e is kept iff j >= R.  Zeroed in
       const int d = 2 * (int)t - p.R;                  // place (this waits for the loads; a rare mode)
       static_for<0, 16>([&](auto mc) {
@@ -195,14 +221,17 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     return x;
   };
 
-  // Each block walks a CONTIGUOUS range of frame groups: with overlapped frames the samples a frame
-  // shares with its predecessor were read by this same block one iteration earlier (L1/L2 hits),
-  // whatever the other blocks are doing.  (Neighbouring ranges sit on the same XCD: xcd_block_index.)
-  const long long groups = (p.nframes + FPB - 1) / FPB, per = (groups + gridDim.x - 1) / gridDim.x;
-  long long fblk = (long long)xcd_block_index() * per * FPB;
-  const long long fend = (fblk + per * FPB < p.nframes) ? fblk + per * FPB : (long long)p.nframes;
-  if (fblk >= fend) return;
-  prefetch_x(fblk);
+  // Each workgroup walks a CONTIGUOUS range of frames: with overlapped frames the samples a frame
+  // shares with its predecessor were read by the same workgroup one iteration earlier (L1 hits),
+  // whatever the other workgroups are doing.  (Neighbouring ranges sit on the same XCD:
+  // xcd_block_index.)  Without SHIFT the FPB slots take adjacent frames each iteration (measured:
+  // 2 % better than a contiguous part per slot); with SHIFT each slot needs consecutive frames.
+  const long long per = ((long long)p.nframes + (long long)gridDim.x * FPB - 1) / ((long long)gridDim.x * FPB);   // frames per slot
+  start = (long long)xcd_block_index() * per * FPB;
+  if (start >= p.nframes) return;
+  auto rel_of = [&](long long i) { return SHIFT > 0 ? (long long)fl * per + i : i * FPB + (long long)fl; };
+  long long it = 0;                                        // frames done by every slot
+  prefetch_x(rel_of(0));
 
   constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
   // register holding bin t + T*m after the last pass
@@ -210,8 +239,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
 
   const int ntap = MT ? p.htapers : 1;
   while (true) {
-    const long long nfblk = fblk + FPB;
-    const bool has_next = nfblk < fend;
+    const bool has_next = it + 1 < per;
     float acc[MT ? 17 : 1];                            // MT: bins k = t + T*m (m < 8), M - k (8 + m), M/2 (16)
     if constexpr (MT != 0) {
 #pragma unroll
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       }
     }
     if constexpr (GLFER16H_PREFETCH_TOP != 0 && !(GLFER_H_ABL & 2)) {
-      if (has_next && last) prefetch_x(nfblk);         // px is free as soon as xs is formed
+      if (has_next && last) prefetch_next(rel_of(it + 1));   // px is free as soon as xs is formed
     }
 
     stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
@@ -249,7 +277,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
 #pragma unroll
         for (int m = 0; m < 16; m++) px[m] = px[m] * 0.999f;
       } else if constexpr (GLFER16H_PREFETCH_TOP == 0) {
-        if (has_next && last) prefetch_x(nfblk);       // the frame's last use of px is behind us
+        if (has_next && last) prefetch_next(rel_of(it + 1));   // the frame's last use of px is behind us
       }
     });
 
@@ -266,10 +294,13 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       // direction (bins k upwards, bins M-k downwards) plus scalar offsets, no address arithmetic,
       // and frame slots past the last frame fall outside num_records (their stores are dropped)
       constexpr unsigned ROWB = (unsigned)(M + 1) * 4u;
-      const long long left = p.nframes - fblk;
+      // a descriptor over the workgroup's rows: rows past the launch's last frame fall outside
+      // num_records and their stores are dropped
+      const long long left = p.nframes - start, span = per * FPB;
       const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-          p.psd + (size_t)fblk * (M + 1), 0, (unsigned)((left > FPB ? FPB : left) * (long long)ROWB), 0x00020000);
-      const unsigned vup = fl * ROWB + t * 4u, vdown = fl * ROWB + (unsigned)(M - 7 * T - (int)t) * 4u;
+          p.psd + (size_t)start * (M + 1), 0, (unsigned)((left > span ? span : left) * (long long)ROWB), 0x00020000);
+      const unsigned row = (unsigned)rel_of(it) * ROWB;
+      const unsigned vup = row + t * 4u, vdown = row + (unsigned)(M - 7 * T - (int)t) * 4u;
       auto put = [&](float v, unsigned voff, unsigned soff) {
         if constexpr (GLFER_H_ABL & 1) {               // timing ablation: arithmetic kept live, no store traffic
           if (v == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, voff, soff, GLFER16H_STORE_AUX);
@@ -321,7 +352,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();     // mirror entries read: buffer free
    }
     if (!has_next) break;
-    fblk = nfblk;
+    it++;
   }
 }
 
@@ -354,8 +385,24 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
   }
 #endif
   if (p.htapers > 1) return hipErrorInvalidValue;      // the multitaper form is built for N >= 8192 only
-  if (p.history_mode) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
-  else hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 0>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+  if (p.history_mode) {
+    hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    return hipGetLastError();
+  }
+#if GLFER16H_SHIFT_BUILDS
+  // overlap 87.5 / 75 / 50 %: the hop is 2 / 4 / 8 of a lane's 16 sample registers -- a slot that
+  // walks consecutive frames keeps the rest.  Worth it when a slot gets >= 4 frames and the
+  // launch still fills the chip.
+  const int shift = (16 * p.H) % (1 << L) == 0 ? (16 * p.H) >> L : 0;
+  if ((shift == 2 || shift == 4 || shift == 8) && work >= 4 * resident) {
+    unsigned g = (unsigned)(work / 4 < 8 * resident ? work / 4 : 8 * resident) & ~7u;
+    if (shift == 2) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 0, 2>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+    else if (shift == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 0, 4>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 0, 8>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+    return hipGetLastError();
+  }
+#endif
+  hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 0>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   return hipGetLastError();
 }
 

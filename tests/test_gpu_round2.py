@@ -441,6 +441,36 @@ def test_periodogram_forms_agree(lib, oracle, torch_cuda, n, overlap, fmt):
         os.environ.pop("GLFER_FORM", None)
 
 
+@pytest.mark.parametrize("n,overlap,fmt,frames", [(512, 0.75, "f32", 60001), (4096, 0.75, "f32", 20011), (4096, 0.5, "s16", 20002),
+                                                  (4096, 0.875, "u8", 20003), (2048, 0.5, "f32", 30000), (16384, 0.75, "f32", 4099),
+                                                  (1024, 0.875, "s16", 50001)])
+def test_periodogram_register_reuse_over_long_launches(lib, oracle, torch_cuda, n, overlap, fmt, frames):
+    """Launches long enough that spectro16h keeps the samples two overlapped frames share in
+    registers (hop = 2, 4 or 8 sixteenths of the block; every frame slot of a workgroup walks
+    consecutive frames): every row against the oracle, and a launch that starts elsewhere in the
+    stream (other slot boundaries, ragged last workgroup) must give the same rows bit for bit."""
+    h = oracle.hop(n, overlap)
+    x = synth(frames * h + 3, seed=n + frames) + np.float32(0.01)
+    if fmt == "s16":
+        raw = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16)
+        xf, sf = oracle.pcm_s16_to_float(raw), lib.SAMPLES_S16
+    elif fmt == "u8":
+        raw = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8)
+        xf, sf = oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
+    else:
+        raw, xf, sf = x, x, lib.SAMPLES_F32
+    want = oracle.spectrogram_fft(xf, n, overlap, 7)
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=7, overlap=overlap, sample_format=sf))
+    dx = torch_cuda.from_numpy(raw).cuda()
+    got = sp.run(dx).cpu().numpy()
+    assert got.shape == want.shape
+    peak = np.abs(want).max(axis=1, keepdims=True)
+    worst = (np.abs(got - want) / peak).max()
+    assert worst < TOL, worst
+    part = sp.run(dx, first_frame=13, nframes=frames - 20).cpu().numpy()
+    assert np.array_equal(part, got[13:frames - 7])
+
+
 @pytest.mark.parametrize("n,overlap,kmax,nw,sub_mean", [(2048, 0.25, 4, 2.5, 0), (4096, 0.0, 4, 2.5, 0), (4096, 0.75, 7, 4.0, 1),
                                                        (8192, 0.5, 4, 2.5, 0), (16384, 0.0, 8, 4.5, 0), (16384, 0.75, 1, 1.5, 1)])
 def test_multitaper_forms_agree(lib, oracle, torch_cuda, n, overlap, kmax, nw, sub_mean):
