@@ -154,8 +154,11 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   // range, clamped to the launch's last frame (a slot past the end re-reads that frame; what it
   // computes is dropped by the output descriptor's range check).
   long long start = 0;                                   // first frame of the workgroup's range
-  auto load_pairs = [&](long long rel, auto fromc) {
-    constexpr int FROM = decltype(fromc)::value;         // registers FROM..15 are loaded
+  // Pair m of the frame at rotation ROT lives in px[(m + ROT) & 15] (ROT != 0 only with SHIFT 4 / 8,
+  // where the frame loop is unrolled over the rotations instead of moving registers).
+  auto load_pairs = [&](long long rel, auto fromc, auto rotc) {
+    constexpr int FROM = decltype(fromc)::value;         // pairs FROM..15 are loaded
+    constexpr int ROT = decltype(rotc)::value;
     const long long last_rel = (long long)p.nframes - 1 - start;
     const unsigned relc = (unsigned)(rel < last_rel ? rel : last_rel);
     const long long sblk = (p.frame0 + start) * (long long)p.H - p.R;
@@ -165,28 +168,32 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     // y[2n] and y[2n+1] are adjacent: ONE load per pair in every format (the launcher sends streams
     // whose pairs are not naturally aligned to spectro16.hip)
     static_for<FROM, 16>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
+      constexpr int m = decltype(mc)::value, q = (m + ROT) & 15;
       if constexpr (FMT == GLFER_FMT_F32) {
-        px[m] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, lrel * 4u, (unsigned)(2 * T * m) * 4u, 0));
+        px[q] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, lrel * 4u, (unsigned)(2 * T * m) * 4u, 0));
       } else if constexpr (FMT == GLFER_FMT_S16) {
-        px[m].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, lrel * 2u, (unsigned)(2 * T * m) * 2u, 0));
+        px[q].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, lrel * 2u, (unsigned)(2 * T * m) * 2u, 0));
       } else {
-        px[m].x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, lrel, (unsigned)(2 * T * m), 0));
+        px[q].x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, lrel, (unsigned)(2 * T * m), 0));
       }
     });
   };
   // the next frame of this slot: with SHIFT its first 16-SHIFT pairs are already here
-  auto prefetch_next = [&](long long rel) {
-    if constexpr (SHIFT > 0) {
+  constexpr bool UNROLL = SHIFT == 4 || SHIFT == 8;      // 16/SHIFT copies of the frame loop's body
+  auto prefetch_next = [&](long long rel, auto rotc) {
+    constexpr int ROT = decltype(rotc)::value;             // the rotation of the frame in flight
+    if constexpr (UNROLL) {
+      load_pairs(rel, std::integral_constant<int, 16 - SHIFT>{}, std::integral_constant<int, (ROT + SHIFT) & 15>{});
+    } else if constexpr (SHIFT > 0) {
 #pragma unroll
       for (int m = 0; m < 16 - SHIFT; m++) px[m] = px[m + SHIFT];
-      load_pairs(rel, std::integral_constant<int, 16 - SHIFT>{});
+      load_pairs(rel, std::integral_constant<int, 16 - SHIFT>{}, rotc);
     } else {
-      load_pairs(rel, std::integral_constant<int, 0>{});
+      load_pairs(rel, std::integral_constant<int, 0>{}, rotc);
     }
   };
   auto prefetch_x = [&](long long rel) {
-    load_pairs(rel, std::integral_constant<int, 0>{});
+    load_pairs(rel, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     if constexpr (HIST != 0) {   // history_mode 1: sample j = 2*(t + T*m) + e is kept iff j >= R.  Zeroed in
       const int d = 2 * (int)t - p.R;                  // place (this waits for the loads; a rare mode)
       static_for<0, 16>([&](auto mc) {
@@ -206,8 +213,8 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     }
   };
   // the pair as floats (integer formats: unscaled, see kSampleScale)
-  auto sample_pair = [&](auto mc) -> v2f32 {
-    constexpr int m = decltype(mc)::value;
+  auto sample_pair = [&](auto mc, auto rotc) -> v2f32 {
+    constexpr int m = (decltype(mc)::value + decltype(rotc)::value) & 15;
     v2f32 x;
     if constexpr (FMT == GLFER_FMT_F32) {
       x = px[m];
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };
 
   const int ntap = MT ? p.htapers : 1;
-  while (true) {
+  auto frame_body = [&](auto rotc) -> bool {
     const bool has_next = it + 1 < per;
     float acc[MT ? 17 : 1];                            // MT: bins k = t + T*m (m < 8), M - k (8 + m), M/2 (16)
     if constexpr (MT != 0) {
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     float zr[16], zi[16];
     if constexpr (VAR == 1) load_window(j);
     v2f32 xs[16];
-    static_for<0, 16>([&](auto mc) { xs[decltype(mc)::value] = sample_pair(mc); });
+    static_for<0, 16>([&](auto mc) { xs[decltype(mc)::value] = sample_pair(mc, rotc); });
     if constexpr (VAR == 2) {
       // 16 ds_read_b64 with immediate offsets: left to the compiler they become ds_read2_b64 (half
       // the rate) behind one address add each
@@ -258,6 +265,9 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       lds_read16_strided<T>(wl + t, wv);
 #pragma unroll
       for (int m = 0; m < 16; m++) {
+        // the products are rounded on their own in every copy of the loop body (left free, some
+        // copies fuse them into the first butterfly's adds and a frame's bits depend on its slot)
+#pragma clang fp contract(off)
         zr[m] = xs[m].x * wv[m].x;
         zi[m] = xs[m].y * wv[m].y;
       }
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       }
     }
     if constexpr (GLFER16H_PREFETCH_TOP != 0 && !(GLFER_H_ABL & 2)) {
-      if (has_next && last) prefetch_next(rel_of(it + 1));   // px is free as soon as xs is formed
+      if (has_next && last) prefetch_next(rel_of(it + 1), rotc);   // px is free as soon as xs is formed
     }
 
     stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
 #pragma unroll
         for (int m = 0; m < 16; m++) px[m] = px[m] * 0.999f;
       } else if constexpr (GLFER16H_PREFETCH_TOP == 0) {
-        if (has_next && last) prefetch_next(rel_of(it + 1));   // the frame's last use of px is behind us
+        if (has_next && last) prefetch_next(rel_of(it + 1), rotc);   // the frame's last use of px is behind us
       }
     });
 
@@ -351,8 +361,16 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     }
     if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();     // mirror entries read: buffer free
    }
-    if (!has_next) break;
     it++;
+    return has_next;
+  };
+  if constexpr (SHIFT == 4) {
+    while (frame_body(std::integral_constant<int, 0>{}) && frame_body(std::integral_constant<int, 4>{}) &&
+           frame_body(std::integral_constant<int, 8>{}) && frame_body(std::integral_constant<int, 12>{})) {}
+  } else if constexpr (SHIFT == 8) {
+    while (frame_body(std::integral_constant<int, 0>{}) && frame_body(std::integral_constant<int, 8>{})) {}
+  } else {
+    while (frame_body(std::integral_constant<int, 0>{})) {}
   }
 }
 
