@@ -242,6 +242,7 @@ class Spectrogram:
     def __init__(self, params, device=0):
         cfg = make_config(params, device)
         self._h = C.c_void_p()
+        self._destroy = lib().glfer_hip_plan_destroy     # held here: module globals are gone by the time __del__ runs at exit
         _check(lib().glfer_hip_plan_create(C.byref(cfg), C.byref(self._h)), "glfer_hip_plan_create")
         self.params, self.device = params, device
         self.n = params.n
@@ -251,8 +252,8 @@ class Spectrogram:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            lib().glfer_hip_plan_destroy(self._h)
-            self._h = C.c_void_p()
+            self._destroy(self._h)
+            self._h.value = None
 
     __del__ = close
 
