@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -401,10 +402,7 @@ int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *d
   return GLFER_OK;
 }
 
-// ---- multi-GPU: source.c:130-158 over one stream, the frame range dealt out over the GPUs of the
-// node.  One host thread per GPU, each with its own plan, streams and pinned ring (run_job); the
-// ranges come from the same arithmetic as glfer_amd/shard.py; rows land in disjoint ranges of
-// h_psd; nothing is exchanged between GPUs.
+// The GPUs named by a bit mask, one worker each.
 int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned device_mask, const void *h_stream,
                                      size_t nsamples, float *h_psd, size_t *nframes_out) {
   if (device_mask == 0) return GLFER_E_ARG;
