@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TOPS = 78.6        # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-instructions/s
+# what a stream of independent v_fma_f32 / v_add_f32 actually issues on this chip (tools/kbench,
+# profiles/r01_kbench_ablation.txt): 62.6 T lane-results/s at 8 wavefronts per SIMD, 54.4 at 2, 44.4 at 3
+VALU_STREAM_TOPS = 62.6
 
 # workload -> (name, n, overlap, nw, kmax, default frames per GPU per step, frames of the CPU sample stream)
 WORKLOADS = {
@@ -315,7 +318,9 @@ def main():
             lane_ops = (ntap / 2.0) * (3 * n * math.log2(n) + 4 * (n - n // 64) + 2 * n + 2 * n)
         line["valu"] = {"lane_ops_per_frame": lane_ops, "achieved_Tops": frames * lane_ops / (kernel_ms * 1e-3) / 1e12,
                         "peak_Tops": VALU_PEAK_TOPS,
-                        "frac": frames * lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}
+                        "frac": frames * lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                        "measured_stream_Tops": VALU_STREAM_TOPS,
+                        "frac_of_measured_stream": frames * lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_STREAM_TOPS}
         if args.workload == "hparma":
             # HP-ARMA is neither HBM- nor FP32-bound: a counted FP64 model of hparma_do (hparma.c:74-157 +
             # compute_svd, util.c:261-386) at t = 128, p_e = 32: t lags x N double multiply-adds; the

@@ -232,49 +232,71 @@ __device__ __forceinline__ double sum_below(const uint32_t (&key)[NK], uint32_t 
 // pivot does not cut enough (many ties) take the search over the whole row.
 constexpr int FLOOR_CAP = 8;
 
-template <int EPL>
+// EXACT: bins == 64 (EPL-1) + 1, the N/2+1 bins of a power-of-two block -- every group of 64 bins but
+// the last is whole and needs no range test.
+//
+// The load loop is what the kernel's time is made of (the selection after it runs on ~100-400
+// compacted keys): per bin one buffer load (range-checked by the descriptor: no exec masking, no
+// 64-bit address arithmetic), three integer ops for the key, one v_max_f32 for the peak and
+// v_med3 + v_min for the lane's two smallest keys.  The peak's INDEX is found afterwards, by
+// ballots over the keys in ascending group order (33 compares at worst instead of 66 selects).
+template <int EPL, bool EXACT>
 __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict__ psd, long long nframes, int bins, int m,
                                                          float *__restrict__ stats) {
   constexpr bool kCompact = EPL >= 17 && EPL <= 33;    // (at 9 keys per lane the detour costs what it saves)
   __shared__ uint32_t strip[kCompact ? 4 : 1][kCompact ? 64 * FLOOR_CAP : 1];
   const int lane = threadIdx.x & 63;
-  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (r >= nframes) return;                      // wavefront-uniform
-  const float *src = psd + (size_t)r * bins;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(psd + (size_t)r * bins), 0, bins * 4, 0x00020000);   // reads past the row's end return 0
   uint32_t key[EPL];                             // the row as keys only: fkey_inv() gives the value back
-  float best = 0.0f;
-  int besti = 0;
-  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu;   // s1 <= s2: the lane's two smallest keys
+  float best = 0.0f;                             // strict > scan from 0.0 (fft.c:284-291): NaNs and bins <= 0 never win
+  uint32_t kmin = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu;   // s1 <= s2: the lane's two smallest keys
+  const unsigned voff = (unsigned)lane * 4u;
 #pragma unroll
   for (int j = 0; j < EPL; j++) {
-    const int i = lane + 64 * j;
-    const bool in = i < bins;
-    const float v = in ? src[i] : 0.0f;
-    key[j] = in ? fkey(v) : 0xFFFFFFFFu;         // padding sorts last: never among the m <= bins smallest
-    if (in && v > best) { best = v; besti = i; }         // ascending i: the lane's lowest index of its maximum
-    if (in) kmax = key[j] > kmax ? key[j] : kmax;
+    const uint32_t b = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)j * 256u, 0);
+    best = fmaxf(best, __uint_as_float(b));      // (a read past the end is 0.0: no effect)
+    uint32_t k = b ^ ((uint32_t)((int)b >> 31) | 0x80000000u);      // fkey()
+    if (!EXACT || j == EPL - 1) k = (lane + 64 * j < bins) ? k : 0xFFFFFFFFu;   // padding sorts last: never among the m <= bins smallest
+    key[j] = k;
     if constexpr (kCompact) {
-      const uint32_t hi = key[j] > s1 ? key[j] : s1;
-      s1 = key[j] < s1 ? key[j] : s1;
-      s2 = hi < s2 ? hi : s2;
+      asm("v_med3_u32 %0, %1, %2, %0" : "+v"(s2) : "v"(k), "v"(s1));   // second smallest of {k, s1 <= s2} (no builtin; not matched from min/max)
+      s1 = k < s1 ? k : s1;
     } else {
-      kmin = key[j] < kmin ? key[j] : kmin;      // (padding is the largest key)
+      kmin = k < kmin ? k : kmin;
     }
   }
   if constexpr (kCompact) kmin = s1;
-  // largest bin and its first index (strict > scan from 0.0, fft.c:284-291): bins are >= 0, so the
-  // float order is the order of the bit patterns
-  const uint32_t peak_bits = wave_max_u32(__float_as_uint(best > 0.0f ? best : 0.0f));
+  // largest bin and its first index: bins that can win are > 0, so the float order is the order of
+  // the bit patterns, and the first index is in the first group of 64 that holds the peak's key
+  const uint32_t peak_bits = wave_max_u32(__float_as_uint(best));
   const float peak = __uint_as_float(peak_bits);
-  const uint32_t first = wave_min_u32((best == peak && peak > 0.0f) ? (uint32_t)besti : 0xFFFFFFFFu);
-  const int peak_i = peak > 0.0f ? (int)first : 0;
+  int peak_i = 0;
+  if (peak > 0.0f) {
+    const uint32_t pk = peak_bits | 0x80000000u;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < EPL; j++) {
+      if (!found) {
+        const unsigned long long hit = __ballot(key[j] == pk);
+        if (hit) {
+          peak_i = 64 * j + __builtin_ctzll(hit);
+          found = true;
+        }
+      }
+    }
+  }
 
   // key of the m-th smallest bin, the number of keys below it, the sum of those
   kmin = wave_min_u32(kmin);
-  kmax = wave_max_u32(kmax);
   uint32_t P = 0, below = 0;
   double s = 0.0;
   bool done = false;
+#ifdef GLFER_FLOOR_ABL                              /* timing ablation: loads and the peak only */
+  P = kmin; s = (double)kmax; done = true;
+#endif
   if constexpr (kCompact) {
     const int cth = (m + 63) >> 6;               // every lane's cth smallest: 64*cth >= m keys at or below the pivot
     const uint32_t pivot = cth <= 2 ? wave_max_u32(cth == 1 ? s1 : s2) : 0xFFFFFFFFu;
@@ -305,6 +327,11 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
     }
   }
   if (!done) {
+    uint32_t kmax = 0u;                          // largest real key (the padding is 0xFFFFFFFF)
+#pragma unroll
+    for (int j = 0; j < EPL; j++) kmax = (key[j] != 0xFFFFFFFFu && key[j] > kmax) ? key[j] : kmax;
+    kmax = wave_max_u32(kmax);
+    if (kmax < kmin) kmax = kmin;                // a row of NaN patterns only
     select_mth<EPL>(key, (uint32_t)bins, (uint32_t)m, kmin, kmax, P, below);
     s = sum_below<EPL>(key, P);
   }
@@ -596,13 +623,19 @@ extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int b
   if (m < 1 || m > bins) return hipErrorInvalidValue;
   const unsigned wgrid = (unsigned)((nframes + 3) / 4);          // one wavefront per row, four rows per block
   const long long nf = (long long)nframes;
-  if (bins <= 64 * 3) hipLaunchKernelGGL(floor_wave_kernel<3>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
-  else if (bins <= 64 * 5) hipLaunchKernelGGL(floor_wave_kernel<5>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
-  else if (bins <= 64 * 9) hipLaunchKernelGGL(floor_wave_kernel<9>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
-  else if (bins <= 64 * 17) hipLaunchKernelGGL(floor_wave_kernel<17>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
-  else if (bins <= 64 * 33) hipLaunchKernelGGL(floor_wave_kernel<33>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
-  else if (bins <= 64 * 65) hipLaunchKernelGGL(floor_wave_kernel<65>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
-  else if (bins <= 64 * 129) hipLaunchKernelGGL(floor_wave_kernel<129>, dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats);
+#define GLFER_FLOOR_WAVE(E)                                                                                        \
+  do {                                                                                                             \
+    if (bins == 64 * (E - 1) + 1) hipLaunchKernelGGL((floor_wave_kernel<E, true>), dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats); \
+    else hipLaunchKernelGGL((floor_wave_kernel<E, false>), dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats); \
+  } while (0)
+  if (bins <= 64 * 3) GLFER_FLOOR_WAVE(3);
+  else if (bins <= 64 * 5) GLFER_FLOOR_WAVE(5);
+  else if (bins <= 64 * 9) GLFER_FLOOR_WAVE(9);
+  else if (bins <= 64 * 17) GLFER_FLOOR_WAVE(17);
+  else if (bins <= 64 * 33) GLFER_FLOOR_WAVE(33);
+  else if (bins <= 64 * 65) GLFER_FLOOR_WAVE(65);
+  else if (bins <= 64 * 129) GLFER_FLOOR_WAVE(129);
+#undef GLFER_FLOOR_WAVE
   else {                                         // longer rows than any block size gives: one workgroup per row, the row in LDS
     const size_t shmem = (size_t)bins * sizeof(float) + 256 * sizeof(uint32_t);
     static size_t allowed = 0;               // raised once per process and size class, not per launch
