@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void floor_kernel(const float *__restrict__ ps
 // K6, rows of up to 64*EPL bins: ONE WAVEFRONT per row, the row in registers (lane l holds bins
 // l + 64 j), no LDS and no barriers.  The m-th smallest key is found bit by bit: with the prefix P
 // decided so far, T = P | bit; if fewer than m keys are below T the answer has that bit set.  A
-// step is EPL compare+add pairs per lane and one DPP sum over the wavefront; bits above the first
-// one in which the row's smallest and largest key differ are skipped.  (The histogram form above
+// step is one compare per key (a ballot) and the population counts added on the scalar unit; bits
+// above the first one in which the row's smallest and largest key differ are skipped.  (The histogram form above
 // serialises on LDS atomics -- a PSD row's keys share their leading digits, so a whole wavefront
 // adds to one bucket -- and needs ~34 workgroup barriers per row.)
 __device__ __forceinline__ float fkey_inv(uint32_t k) {
@@ -135,7 +135,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // same walk; lanes shifted in from outside read 0
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // lanes shifted in from outside read 0
   auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
   v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
   v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
@@ -175,17 +175,30 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
   return v;
 }
 
-// number of keys below T, over the wavefront
+// Number of keys below T, over the wavefront.  Up to GLFER_FLOOR_BALLOT_MAX keys per lane: one compare
+// per key into an SGPR pair (a ballot), the population counts added on the scalar unit -- no
+// per-lane counters, no DPP sum (+4..10 % at 129 and 513 bins).  More keys per lane: per-lane
+// counters (compare + add-with-carry) and one DPP sum -- there the scalar chain of the ballot form
+// is the longer one (-6 % at 2049 bins, -22 % at 8193).
+#ifndef GLFER_FLOOR_BALLOT_MAX
+#define GLFER_FLOOR_BALLOT_MAX 9
+#endif
 template <int NK>
 __device__ __forceinline__ uint32_t count_below(const uint32_t (&key)[NK], uint32_t T) {
   uint32_t c = 0, Tv;
   asm("v_mov_b32 %0, %1" : "=v"(Tv) : "s"(T));              // compares against a VGPR: an SGPR operand halves the VALU rate (tools/pkbench3)
-  constexpr int G = NK >= 4 ? (NK / 4) * 4 : 0;
+  if constexpr (NK <= GLFER_FLOOR_BALLOT_MAX) {
 #pragma unroll
-  for (int j = 0; j < G; j += 4) count_below4(c, key[j], key[j + 1], key[j + 2], key[j + 3], Tv);
+    for (int j = 0; j < NK; j++) c += (uint32_t)__builtin_popcountll(__ballot(key[j] < Tv));
+    return c;
+  } else {
+    constexpr int G = (NK / 4) * 4;
 #pragma unroll
-  for (int j = G; j < NK; j++) c += key[j] < Tv ? 1u : 0u;
-  return wave_sum_u32(c);
+    for (int j = 0; j < G; j += 4) count_below4(c, key[j], key[j + 1], key[j + 2], key[j + 3], Tv);
+#pragma unroll
+    for (int j = G; j < NK; j++) c += key[j] < Tv ? 1u : 0u;
+    return wave_sum_u32(c);
+  }
 }
 
 // P = the m-th smallest of the wavefront's `total` real keys (the arrays are padded with 0xFFFFFFFF),
@@ -224,13 +237,16 @@ __device__ __forceinline__ double sum_below(const uint32_t (&key)[NK], uint32_t 
   return s;
 }
 
-// Rows of 577..2049 bins first shrink the problem: with c = ceil(m/64) <= 2, the largest of the lanes'
-// c-th smallest keys is a pivot with at least 64 c >= m keys at or below it -- the m smallest are all
-// among them -- and on a typical row only a few hundred keys are.  Those are compacted through a
-// wavefront-private LDS strip (a DPP prefix sum gives each lane its offset) into FLOOR_CAP keys per
-// lane, and the bitwise search runs on them: 8 compares per step instead of 33.  Rows on which the
-// pivot does not cut enough (many ties) take the search over the whole row.
-constexpr int FLOOR_CAP = 8;
+// Rows of 577 bins and more first shrink the problem.  The lane's keys are dealt into G groups
+// (j mod G) and the two smallest of every group are tracked (v_med3 + v_min per key): the largest
+// of all lanes' and groups' second-smallest keys is a pivot with at least 2*64*G keys at or below
+// it (64*G for the groups' smallest) -- the m smallest are all among them when m <= 128 G -- and on
+// a typical row a fifth of the keys are.  Those are compacted through a wavefront-private LDS strip
+// (a DPP prefix sum gives each lane its offset) into 8 G keys per lane (48 for G = 4), and the bitwise
+// search runs on them: 8..48 compares per step instead of 33..129.  Rows on which the pivot does not cut
+// enough (many ties) take the search over the whole row.  G = 1 up to 2049 bins (m = 103), 2 for
+// 4097 (m = 205), 4 for 8193 (m = 410).
+constexpr int floor_groups(int epl) { return epl <= 33 ? 1 : (epl <= 65 ? 2 : 4); }
 
 // EXACT: bins == 64 (EPL-1) + 1, the N/2+1 bins of a power-of-two block -- every group of 64 bins but
 // the last is whole and needs no range test.
@@ -243,8 +259,9 @@ constexpr int FLOOR_CAP = 8;
 template <int EPL, bool EXACT>
 __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict__ psd, long long nframes, int bins, int m,
                                                          float *__restrict__ stats) {
-  constexpr bool kCompact = EPL >= 17 && EPL <= 33;    // (at 9 keys per lane the detour costs what it saves)
-  __shared__ uint32_t strip[kCompact ? 4 : 1][kCompact ? 64 * FLOOR_CAP : 1];
+  constexpr bool kCompact = EPL >= 17;           // (at 9 keys per lane the detour costs what it saves)
+  constexpr int G = floor_groups(EPL), CAP = G == 4 ? 48 : 8 * G;   // (8193 bins: a quarter of the rows pass 32 keys per lane)
+  __shared__ uint32_t strip[kCompact ? 4 : 1][kCompact ? 64 * CAP : 1];
   const int lane = threadIdx.x & 63;
   const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (r >= nframes) return;                      // wavefront-uniform
@@ -252,7 +269,9 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
       const_cast<float *>(psd + (size_t)r * bins), 0, bins * 4, 0x00020000);   // reads past the row's end return 0
   uint32_t key[EPL];                             // the row as keys only: fkey_inv() gives the value back
   float best = 0.0f;                             // strict > scan from 0.0 (fft.c:284-291): NaNs and bins <= 0 never win
-  uint32_t kmin = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu;   // s1 <= s2: the lane's two smallest keys
+  uint32_t kmin = 0xFFFFFFFFu, s1[G], s2[G];     // s1 <= s2: the two smallest keys of the lane's group g (keys j = g mod G)
+#pragma unroll
+  for (int g = 0; g < G; g++) s1[g] = s2[g] = 0xFFFFFFFFu;
   const unsigned voff = (unsigned)lane * 4u;
 #pragma unroll
   for (int j = 0; j < EPL; j++) {
@@ -262,13 +281,21 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
     if (!EXACT || j == EPL - 1) k = (lane + 64 * j < bins) ? k : 0xFFFFFFFFu;   // padding sorts last: never among the m <= bins smallest
     key[j] = k;
     if constexpr (kCompact) {
-      asm("v_med3_u32 %0, %1, %2, %0" : "+v"(s2) : "v"(k), "v"(s1));   // second smallest of {k, s1 <= s2} (no builtin; not matched from min/max)
-      s1 = k < s1 ? k : s1;
+      asm("v_med3_u32 %0, %1, %2, %0" : "+v"(s2[j % G]) : "v"(k), "v"(s1[j % G]));   // second smallest of {k, s1 <= s2} (no builtin; not matched from min/max)
+      s1[j % G] = k < s1[j % G] ? k : s1[j % G];
     } else {
       kmin = k < kmin ? k : kmin;
     }
   }
-  if constexpr (kCompact) kmin = s1;
+  uint32_t g1 = 0u, g2 = 0u;                     // the largest of the lane's groups' smallest / second smallest
+  if constexpr (kCompact) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      kmin = s1[g] < kmin ? s1[g] : kmin;
+      g1 = s1[g] > g1 ? s1[g] : g1;
+      g2 = s2[g] > g2 ? s2[g] : g2;
+    }
+  }
   // largest bin and its first index: bins that can win are > 0, so the float order is the order of
   // the bit patterns, and the first index is in the first group of 64 that holds the peak's key
   const uint32_t peak_bits = wave_max_u32(__float_as_uint(best));
@@ -298,15 +325,15 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
   P = kmin; s = (double)kmax; done = true;
 #endif
   if constexpr (kCompact) {
-    const int cth = (m + 63) >> 6;               // every lane's cth smallest: 64*cth >= m keys at or below the pivot
-    const uint32_t pivot = cth <= 2 ? wave_max_u32(cth == 1 ? s1 : s2) : 0xFFFFFFFFu;
+    // 64 G (128 G) keys are at or below the largest smallest (second smallest) key of a group
+    const uint32_t pivot = m <= 64 * G ? wave_max_u32(g1) : (m <= 128 * G ? wave_max_u32(g2) : 0xFFFFFFFFu);
     if (pivot != 0xFFFFFFFFu) {
       uint32_t n = 0;
 #pragma unroll
       for (int j = 0; j < EPL; j++) n += key[j] <= pivot ? 1u : 0u;
       const uint32_t incl = wave_scan_u32(n);
       const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-      if (C <= 64u * FLOOR_CAP) {                // wavefront-uniform
+      if (C <= 64u * CAP) {                // wavefront-uniform
         uint32_t *mine = strip[threadIdx.x >> 6];
         uint32_t off = incl - n;
 #pragma unroll
@@ -317,11 +344,11 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        uint32_t cand[FLOOR_CAP];
+        uint32_t cand[CAP];
 #pragma unroll
-        for (int q = 0; q < FLOOR_CAP; q++) cand[q] = (uint32_t)(lane + 64 * q) < C ? mine[lane + 64 * q] : 0xFFFFFFFFu;
-        select_mth<FLOOR_CAP>(cand, C, (uint32_t)m, kmin, pivot, P, below);
-        s = sum_below<FLOOR_CAP>(cand, P);
+        for (int q = 0; q < CAP; q++) cand[q] = (uint32_t)(lane + 64 * q) < C ? mine[lane + 64 * q] : 0xFFFFFFFFu;
+        select_mth<CAP>(cand, C, (uint32_t)m, kmin, pivot, P, below);
+        s = sum_below<CAP>(cand, P);
         done = true;
       }
     }

@@ -7,7 +7,7 @@ import glfer_amd.api as A
 if os.environ.get("GLFER_LIB_PATH"):
     A.LIB_PATH = os.environ["GLFER_LIB_PATH"]
 for bins in (129, 513, 1025, 2049, 4097, 8193):
-    rows = (256 << 20) // (bins * 4)
+    rows = (1 << 30) // (bins * 4)              # 1 GiB: well past the 256 MiB Infinity Cache, kernel time well past the call overhead
     psd = (torch.rand((rows, bins), device='cuda') ** 4).contiguous()
     G.compute_floor(psd); torch.cuda.synchronize()
     t0 = time.perf_counter()
