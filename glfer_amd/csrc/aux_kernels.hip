@@ -515,12 +515,78 @@ __global__ __launch_bounds__(256) void avg_norm_kernel(const float *__restrict__
 // one barrier; the partials alternate between two LDS slots, so no second barrier), normalises and
 // stores the row: 4 B read (+4 B of the row leaving the window, an L2 hit for small depths) and
 // 8 B written per bin.  The next frame's samples are requested before the current one is reduced.
-template <int BPT>
+// ---- double-precision wavefront reductions by DPP: row_shr 1,2,4,8 leave a row's result in its lane
+// 15, row_bcast 15 / 31 carry it to lane 63, readlane broadcasts it.  A lane without a source takes
+// `ZERO ? 0 : itself` -- the identity of a sum / of a maximum or minimum.  (Six ds_bpermute rounds
+// per value, as __shfl_xor does it, cost an LDS round trip each.)
+template <int CTRL, int ROWMASK, bool ZERO>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
+  const unsigned rl = (unsigned)__builtin_amdgcn_update_dpp(ZERO ? 0 : lo, lo, CTRL, ROWMASK, 0xf, false);
+  const unsigned rh = (unsigned)__builtin_amdgcn_update_dpp(ZERO ? 0 : hi, hi, CTRL, ROWMASK, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)rh << 32) | rl));
+}
+__device__ __forceinline__ double lane63_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// over the wavefront: the sum of s, the maximum of mx with the LOWEST index mi among equals, the minimum of mn
+__device__ __forceinline__ void wave_sum_max_min(double &s, double &mx, int &mi, double &mn) {
+  auto step = [&](auto ctrl, auto rowmask) {
+    constexpr int CT = decltype(ctrl)::value, RM = decltype(rowmask)::value;
+    const double os = dpp_f64<CT, RM, true>(s), om = dpp_f64<CT, RM, false>(mx), on = dpp_f64<CT, RM, false>(mn);
+    const int oi = __builtin_amdgcn_update_dpp(mi, mi, CT, RM, 0xf, false);
+    s += os;
+    if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+    mn = on < mn ? on : mn;
+  };
+  step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+  step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  s = lane63_f64(s);
+  mx = lane63_f64(mx);
+  mn = lane63_f64(mn);
+  mi = __builtin_amdgcn_readlane(mi, 63);
+}
+
+// a / d for many a and one d, correctly rounded: with y = RN(1/d) (one true division),
+// q0 = RN(a y), r = a - d q0 (exact in an fma), q = RN(q0 + r y) is RN(a/d) (Markstein) as long as
+// nothing over- or underflows on the way -- so only for 1e-100 < |d| < 1e100 (the operands here
+// are sums of float32 bins: below 1e40, and a quotient of 1e-45/1e100 is still a normal double);
+// any other divisor (0, inf, NaN, denormal) takes the division itself.
+struct Divisor {
+  double d, y;
+  bool fast;
+  __device__ __forceinline__ explicit Divisor(double dd) : d(dd), y(1.0 / dd) {
+    const double a = dd < 0 ? -dd : dd;
+    fast = __builtin_amdgcn_readfirstlane((a > 1e-100 && a < 1e100) ? 1 : 0) != 0;   // d is the same in every lane
+  }
+  __device__ __forceinline__ double operator()(double a) const {
+    if (!fast) return a / d;
+    const double q0 = a * y;
+    const double r = __builtin_fma(-d, q0, a);
+    return __builtin_fma(r, y, q0);
+  }
+};
+
+// RING: the last `depth` rows of the block's bins are kept in LDS (hist[f mod depth][j][tid], every
+// thread its own words: no synchronisation), so the row that leaves the sliding sum is not read from
+// memory a second time -- measured without it: 16 161 B read per 8 196-B row (rocprofv3 FETCH_SIZE),
+// the second read comes from HBM, not L2 (1024 blocks x depth rows do not stay there beside the
+// 16 KB/row write stream).  The launcher uses it while depth x BPT KB fit the 64 KB dynamic limit.
+template <int BPT, bool RING>
 __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict__ psd, long long nframes, int chunk, int bins,
                                                         int n_out, int depth, int minbin, int maxbin, int mode, int max0,
                                                         double *__restrict__ avg, double *__restrict__ ret) {
   __shared__ double p_sum[2][4], p_max[2][4], p_min[2][4], p_var[2][4];
   __shared__ int p_idx[2][4], p_cnt[2][4];
+  extern __shared__ float hist[];                // RING: [depth][BPT][256]
   const int tid = threadIdx.x, wave = tid >> 6;
   const long long f0 = (long long)blockIdx.x * chunk;
   const long long f1 = f0 + chunk < nframes ? f0 + chunk : nframes;
@@ -530,9 +596,14 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
   for (int j = 0; j < BPT; j++) cum[j] = 0.0;
   for (long long g = f0 > depth ? f0 - depth : 0; g < f0; g++) {
     const float *r = psd + (size_t)g * bins;
+    float *h = hist + ((size_t)(g % depth) * BPT) * 256 + tid;
 #pragma unroll
     for (int j = 0; j < BPT; j++)
-      if (b0 + 256 * j < maxbin) cum[j] += (double)r[b0 + 256 * j];
+      if (b0 + 256 * j < maxbin) {
+        const float x = r[b0 + 256 * j];
+        cum[j] += (double)x;
+        if constexpr (RING) h[256 * j] = x;
+      }
   }
   float v[BPT], old[BPT];
   auto fetch = [&](long long f) {
@@ -542,7 +613,7 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
     for (int j = 0; j < BPT; j++) {
       const bool in = b0 + 256 * j < maxbin;
       v[j] = in ? r[b0 + 256 * j] : 0.0f;
-      old[j] = (in && f >= depth) ? ro[b0 + 256 * j] : 0.0f;
+      if constexpr (!RING) old[j] = (in && f >= depth) ? ro[b0 + 256 * j] : 0.0f;
     }
   };
   fetch(f0);
@@ -553,6 +624,15 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
     const double init = (double)psd[(size_t)f * bins + minbin];
     double s = 0.0, mx = -1.0e300, mn = 1.0e300;
     int mi = 0x7fffffff;
+    if constexpr (RING) {                                      // row f - depth leaves the sum, row f takes its slot
+      float *h = hist + ((size_t)(f % depth) * BPT) * 256 + tid;
+#pragma unroll
+      for (int j = 0; j < BPT; j++)
+        if (b0 + 256 * j < maxbin) {
+          old[j] = h[256 * j];
+          h[256 * j] = v[j];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < BPT; j++) {
       if (b0 + 256 * j < maxbin) {
@@ -565,15 +645,7 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
       }
     }
     if (f + 1 < f1) fetch(f + 1);                              // in flight under the reduction
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      s += __shfl_xor(s, o);
-      const double om = __shfl_xor(mx, o);
-      const int oi = __shfl_xor(mi, o);
-      if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
-      const double on = __shfl_xor(mn, o);
-      if (on < mn) mn = on;
-    }
+    wave_sum_max_min(s, mx, mi, mn);
     if ((tid & 63) == 0) { p_sum[par][wave] = s; p_max[par][wave] = mx; p_min[par][wave] = mn; p_idx[par][wave] = mi; }
     __syncthreads();
     double r_sum = p_sum[par][0], r_max = p_max[par][0], r_min = p_min[par][0];
@@ -596,6 +668,8 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
     double *row = avg + (size_t)f * n_out;
     double var = 0.0;
     int cnt = 0;
+    // the frame's divisors (the same in every lane)
+    const Divisor by_depth((double)(eff + 1)), by_spec(spec), by_range(mode == 3 ? top - low : top - spec);
 #pragma unroll
     for (int j = 0; j < BPT; j++) {
       const int b = b0 + 256 * j;
@@ -603,13 +677,14 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
         const double c = cum[j];
         double out;
         if (mode == 2) {
-          out = c / (double)(eff + 1);                                    // avg.c:155
+          out = by_depth(c);                                              // avg.c:155
         } else if (mode == 3) {
-          out = max0 ? (c - low) / (top - low) : c / spec;                // avg.c:209-212
+          out = max0 ? by_range(c - low) : by_spec(c);                    // avg.c:209-212
         } else {
           if (c - spec > 0) {                                             // avg.c:272-284
-            out = max0 ? (c - spec) / (top - spec) : c / spec;
-            if (b != peak) { var += (c / spec) * (c / spec); cnt++; }
+            const double q = by_spec(c);
+            out = max0 ? by_range(c - spec) : q;
+            if (b != peak) { var += q * q; cnt++; }
           } else {
             out = 1e-15;
           }
@@ -617,8 +692,9 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
         row[b] = out;
       }
     }
-    for (int b = tid; b < n_out; b += 256)
-      if (b < minbin || b >= maxbin) row[b] = 1e-15;
+    // the columns outside the band (avg.c:150-153): usually a few dozen
+    for (int b = tid; b < minbin; b += 256) row[b] = 1e-15;
+    for (int b = maxbin + tid; b < n_out; b += 256) row[b] = 1e-15;
     if (mode == 1) {
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -676,6 +752,8 @@ extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int b
   return hipGetLastError();
 }
 
+static int bpt_of(int bpt) { return bpt <= 3 ? bpt : (bpt <= 5 ? 5 : (bpt <= 9 ? 9 : (bpt <= 17 ? 17 : 33))); }   // the BPT the fused kernel is built for
+
 extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframes, int bins, int n_out,
                                        int depth, int minbin, int maxbin, int max0, double *avg,
                                        double *ret, hipStream_t st) {
@@ -692,9 +770,13 @@ extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframe
   const int bpt = (band + 255) / 256;
   if (bpt <= 33 && depth <= 2 * chunk) {
     const unsigned blocks = (unsigned)((nf + chunk - 1) / chunk);
+    const size_t ring_bytes = (size_t)depth * bpt_of(bpt) * 256 * sizeof(float);
+    const bool ring = ring_bytes <= 60 * 1024;                 // beside the kernel's static words, under the 64 KB limit
 #define GLFER_AVG_FUSED(B)                                                                                              \
-  hipLaunchKernelGGL(avg_fused_kernel<B>, dim3(blocks), dim3(256), 0, st, psd, nf, chunk, bins, n_out, depth, minbin, maxbin, \
-                     mode, max0, avg, ret)
+  do {                                                                                                                  \
+    if (ring) hipLaunchKernelGGL((avg_fused_kernel<B, true>), dim3(blocks), dim3(256), ring_bytes, st, psd, nf, chunk, bins, n_out, depth, minbin, maxbin, mode, max0, avg, ret); \
+    else hipLaunchKernelGGL((avg_fused_kernel<B, false>), dim3(blocks), dim3(256), 0, st, psd, nf, chunk, bins, n_out, depth, minbin, maxbin, mode, max0, avg, ret); \
+  } while (0)
     if (bpt <= 1) GLFER_AVG_FUSED(1);
     else if (bpt <= 2) GLFER_AVG_FUSED(2);
     else if (bpt <= 3) GLFER_AVG_FUSED(3);
