@@ -11,6 +11,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef GLFER_MAP_GUARD
+#define GLFER_MAP_GUARD 2.5e-4f    /* the float logarithm is within 8e-5 of 10 log10 x (1 ulp of v_log_f32 at |log2 x| <= 128, the product, the constant) */
+#endif
+
 namespace glfer {
 
 // double -> int32 the way the reference's implicit double->short / double->unsigned char
@@ -68,19 +72,33 @@ __device__ __forceinline__ void levels_walk(const float *__restrict__ stats, lon
       float x[64];
 #pragma unroll
       for (int j = 0; j < 64; j++) x[j] = sx[lane][j];
+      if (cnt == 64 && !first) {
+        // a whole batch in steady state -- nearly every batch: nothing but the recurrence on the
+        // chain (one conversion, one multiply, one add, one conversion per frame); the products
+        // (1.0 - 0.99) * x do not depend on it
+        double xs[64];
 #pragma unroll
-      for (int j = 0; j < 64; j++) {
-        if (j < cnt) {
-          if (first) {                                     // g_main.c:1112-1120
-            float x0 = x[j];
-            if (overlap > 0.0) x0 /= overlap;
-            lvl = x0;
-            first = false;
-          } else {                                         // g_main.c:1122-1123
-            lvl = (float)((1.0 - 0.99) * (double)x[j] + 0.99 * (double)lvl);
-          }
+        for (int j = 0; j < 64; j++) xs[j] = (1.0 - 0.99) * (double)x[j];
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+          lvl = (float)(xs[j] + 0.99 * (double)lvl);       // g_main.c:1122-1123
+          x[j] = lvl;
         }
-        x[j] = lvl;
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < 64; j++) {
+          if (j < cnt) {
+            if (first) {                                   // g_main.c:1112-1120
+              float x0 = x[j];
+              if (overlap > 0.0) x0 /= overlap;
+              lvl = x0;
+              first = false;
+            } else {                                       // g_main.c:1122-1123
+              lvl = (float)((1.0 - 0.99) * (double)x[j] + 0.99 * (double)lvl);
+            }
+          }
+          x[j] = lvl;
+        }
       }
 #pragma unroll
       for (int j = 0; j < 64; j++) sy[lane][j] = x[j];
@@ -162,22 +180,56 @@ __global__ __launch_bounds__(256) void levels_fixed_kernel(long long nframes, fl
 // One bin of one column: the dB short and the 0..255 colour index (g_main.c:1186-1226).
 //   levbuf = (short)(10 log10 x)  [double log10, truncated]       colour = (uchar)((f - thr255) / one_m_thr)
 // Both truncate a double: the value only matters next to an integer.  So the logarithm is taken in
-// float (v_log_f32) and the quotient as a product with the reciprocal, and only a result within a
-// guard band of an integer -- 2e-3 for the float logarithm (its error is < 1e-4 over |y| <= 400),
-// 1e-9 for the product (a few double ulp of at most 255) -- is recomputed the reference's way:
-// the same integers as the all-double form, at a fraction of the instructions.
+// float (v_log_f32: error < 1e-4 over |y| <= 400) and a result further than GLFER_MAP_GUARD from an
+// integer is truncated as it is; a result inside the guard band (0.05 % of the bins; a wavefront
+// takes the branch when ANY of its lanes does, 3 % of the time -- with the 2e-3 band and a double
+// log10 behind it, round 1's form, that was 23 % and a third of the kernel) is decided by ONE comparison with the
+// point where the reference's own 10.0*log10(x) crosses that integer (log_thr: host_tables.cpp
+// log_thresholds(), built with the host libm the reference itself would run on), not by a double
+// log10 on the device.  The quotient is a product with the reciprocal, recomputed the reference's
+// way only within 1e-9 of an integer (a few double ulp of at most 255).  Same integers as the
+// all-double form, at a fraction of the instructions.
+constexpr int kLogThrK = 400;                              // host_tables.h
+struct RowScale {                                          // per column: display_min and 1/(display_max - display_min)
+  float display_min, span, inv_span;
+  bool fast;                                               // the reciprocal form of x / span is exact (see fdiv)
+};
+// a / span, correctly rounded, for many a and one span: y = RN(1/span), q0 = RN(a y),
+// r = a - span q0 (exact in an fma), RN(q0 + r y) = RN(a / span) (Markstein) while nothing over- or
+// underflows: |span| and |a| within 2^-60 .. 2^59; anything else (0 included) takes the division.
+__device__ __forceinline__ float fdiv(float a, const RowScale &rs) {
+  const unsigned e = (__float_as_uint(a) >> 23) & 0xffu;   // biased exponent
+  if (rs.fast && e - 67u < 120u) {
+    const float q0 = a * rs.inv_span;
+    const float r = __builtin_fmaf(-rs.span, q0, a);
+    return __builtin_fmaf(r, rs.inv_span, q0);
+  }
+  return a / rs.span;
+}
+
 template <typename SRC>
-__device__ __forceinline__ void map_bin(SRC s, int scale_log, float display_min, float span, double thr255,
-                                        double one_m_thr, double inv_one_m_thr, short &l, unsigned &v) {
+__device__ __forceinline__ void map_bin(SRC s, int scale_log, const RowScale &rs, double thr255,
+                                        double one_m_thr, double inv_one_m_thr, const double *__restrict__ log_thr,
+                                        short &l, unsigned &v) {
   const float sf = (float)s;                               // the linear scale maps (float)s, and logs that
   const double sd = scale_log ? (double)s : (double)sf;
   const float y = __builtin_amdgcn_logf(sf) * 3.010299956639812f;         // 10 log10 = log2 * 10 log10(2)
+  const float yr = __builtin_rintf(y);
   int li;
-  if (sf > 1e-30f && sf < 1e30f && __builtin_fabsf(y - __builtin_rintf(y)) > 2e-3f) li = (int)y;   // (a double source rounded to float moves y by 3e-7)
-  else li = x86_d2i(10.0 * log10(sd));
+  if (sf > 1e-37f && sf < 3e38f) {                         // normal floats (a double source rounded to float moves y by 3e-7)
+    if (__builtin_fabsf(y - yr) > GLFER_MAP_GUARD) {
+      li = (int)y;
+    } else {                                               // 10 log10(sd) is within the guard band of k: k, or the integer before it
+      const int k = (int)yr;
+      const double t = log_thr[kLogThrK + k];
+      li = k > 0 ? (sd >= t ? k : k - 1) : (k < 0 ? (sd <= t ? k : k + 1) : 0);
+    }
+  } else {
+    li = x86_d2i(10.0 * log10(sd));
+  }
   l = (short)li;
   const float sig_level = scale_log ? (float)l : sf;
-  const float f = 255.0f * ((sig_level - display_min) / span);
+  const float f = 255.0f * fdiv(sig_level - rs.display_min, rs);
   if ((double)f < thr255) {
     v = 0;
   } else if (f > 255.0f) {
@@ -198,6 +250,7 @@ __global__ __launch_bounds__(256) void map_kernel(const SRC *__restrict__ src, i
                                                   double thr255, double one_m_thr,
                                                   const float *__restrict__ levels,
                                                   const unsigned char *__restrict__ colortab,
+                                                  const double *__restrict__ log_thr,
                                                   unsigned char *__restrict__ rgb, short *__restrict__ lev) {
   __shared__ unsigned tab[256];
   {
@@ -209,7 +262,14 @@ __global__ __launch_bounds__(256) void map_kernel(const SRC *__restrict__ src, i
   const SRC *row = src + fr * (size_t)n;
   const float display_max = levels[fr * 4 + 0];
   const float display_min = levels[fr * 4 + 1];
-  const float span = display_max - display_min;
+  RowScale rs;
+  rs.display_min = display_min;
+  rs.span = display_max - display_min;
+  rs.inv_span = 1.0f / rs.span;
+  {
+    const unsigned e = (__float_as_uint(rs.span) >> 23) & 0xffu;
+    rs.fast = e - 67u < 120u;
+  }
   const double inv = 1.0 / one_m_thr;
   unsigned char *orow = rgb + fr * (size_t)n * 3;
   short *lrow = lev ? lev + fr * (size_t)n : nullptr;
@@ -222,7 +282,7 @@ __global__ __launch_bounds__(256) void map_kernel(const SRC *__restrict__ src, i
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       unsigned v;
-      map_bin<SRC>(q[3 - u], scale_log, display_min, span, thr255, one_m_thr, inv, l[u], v);
+      map_bin<SRC>(q[3 - u], scale_log, rs, thr255, one_m_thr, inv, log_thr, l[u], v);
       c[u] = tab[v];
     }
     const unsigned w[3] = {c[0] | (c[1] << 24), (c[1] >> 8) | (c[2] << 16), (c[2] >> 16) | (c[3] << 8)};
@@ -232,7 +292,7 @@ __global__ __launch_bounds__(256) void map_kernel(const SRC *__restrict__ src, i
   for (int i = n4 + (int)threadIdx.x; i < n; i += 256) {              // the last n mod 4 pixels
     short l;
     unsigned v;
-    map_bin<SRC>(row[n - i - 1], scale_log, display_min, span, thr255, one_m_thr, inv, l, v);
+    map_bin<SRC>(row[n - i - 1], scale_log, rs, thr255, one_m_thr, inv, log_thr, l, v);
     const unsigned c = tab[v];
     orow[3 * i] = (unsigned char)c;
     orow[3 * i + 1] = (unsigned char)(c >> 8);
@@ -272,14 +332,14 @@ extern "C" hipError_t glfer_launch_levels_fixed(size_t nframes, float dmax, floa
 
 extern "C" hipError_t glfer_launch_map(const float *psd, const double *avg, size_t nframes, int n,
                                        int scale_log, double thr255, double one_m_thr, const float *levels,
-                                       const unsigned char *colortab, unsigned char *rgb, short *lev,
-                                       hipStream_t st) {
+                                       const unsigned char *colortab, const double *log_thr, unsigned char *rgb,
+                                       short *lev, hipStream_t st) {
   if (nframes == 0) return hipSuccess;
   if (avg)
     hipLaunchKernelGGL(map_kernel<double>, dim3((unsigned)nframes), dim3(256), 0, st, avg, n, scale_log,
-                       thr255, one_m_thr, levels, colortab, rgb, lev);
+                       thr255, one_m_thr, levels, colortab, log_thr, rgb, lev);
   else
     hipLaunchKernelGGL(map_kernel<float>, dim3((unsigned)nframes), dim3(256), 0, st, psd, n, scale_log,
-                       thr255, one_m_thr, levels, colortab, rgb, lev);
+                       thr255, one_m_thr, levels, colortab, log_thr, rgb, lev);
   return hipGetLastError();
 }

@@ -102,13 +102,15 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
   HIP_TRY(guard.error());
   const int scale_log = d->scale_type == GLFER_SCALE_LOG || d->scale_type == GLFER_SCALE_LOG_MAX0;
 
-  // one stream-ordered allocation: the palette, the levels rows (when the caller does not want
-  // them) and the chunk states of the autoscale walk
+  // one stream-ordered allocation: the palette, the table of the dB steps, the levels rows (when
+  // the caller does not want them) and the chunk states of the autoscale walk
   const size_t lev_floats = d_levels ? 0 : nframes * 4, st_floats = d->autoscale ? glfer_levels_scratch_floats(nframes) : 0;
+  const size_t thr_bytes = (2 * glfer::kLogThrK + 1) * sizeof(double);
   unsigned char *scratch = nullptr;
-  HIP_TRY(hipMallocAsync((void **)&scratch, 768 + (lev_floats + st_floats) * sizeof(float), st));
+  HIP_TRY(hipMallocAsync((void **)&scratch, 768 + thr_bytes + (lev_floats + st_floats) * sizeof(float), st));
   unsigned char *d_tab = scratch;
-  float *fs = reinterpret_cast<float *>(scratch + 768);
+  double *d_thr = reinterpret_cast<double *>(scratch + 768);
+  float *fs = reinterpret_cast<float *>(scratch + 768 + thr_bytes);
   float *levels = d_levels ? d_levels : fs;
   float *chunk_state = st_floats ? fs + lev_floats : nullptr;
   int rc = GLFER_OK;
@@ -117,6 +119,7 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
   glfer::make_palette(d->palette, tab);
   // pageable source: hipMemcpyAsync stages it before returning, so `tab` may go out of scope
   hipError_t e = hipMemcpyAsync(d_tab, tab, 768, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_thr, glfer::log_thresholds(), thr_bytes, hipMemcpyHostToDevice, st);
   if (e != hipSuccess) fail(e);
 
   if (rc == GLFER_OK) {
@@ -136,7 +139,7 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
   if (rc == GLFER_OK) {
     const float thr_level = d->thr_level / 100.0;                              // g_main.c:1099
     e = glfer_launch_map(d_psd, d_avg, nframes, bins, scale_log, 255.0 * thr_level, 1.0 - thr_level, levels,
-                         d_tab, d_rgb, d_lev, st);
+                         d_tab, d_thr, d_rgb, d_lev, st);
     if (e != hipSuccess) fail(e);
   }
   float last[4] = {0, 0, 0, 0};

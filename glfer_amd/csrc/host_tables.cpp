@@ -7,6 +7,9 @@
 //     the sinc kernel, Thomson 1982 App. A               (gl_dpss, g-l_dpss.c:288-347)
 // They run once per plan; cost is O(32*N*T) sines (milliseconds), so they stay on the CPU.
 #include "host_tables.h"
+#include <mutex>
+#include <cstring>
+#include <cstdint>
 
 #include <cmath>
 #include <vector>
@@ -290,6 +293,39 @@ void make_ftest_tables(int n, int kmax, const double *tapers, double *U0, float 
     hn[i] = h / total;
   }
   *sum_U0_sqr = total;
+}
+
+// levbuf = (short)(10.0 * log10(x)) (g_main.c:1192-1196) truncates a double: which integer comes out is
+// a comparison of x with the point where the reference's own expression -- this libm's log10, this
+// multiplication -- crosses an integer.  thr[K + k], k = 1..K: the smallest double x with
+// 10.0*log10(x) >= k; k = -K..-1: the largest double x with 10.0*log10(x) <= k (the conversion
+// truncates towards zero).  Found by bisection over the bit patterns (log10 is monotonic there).
+const double *log_thresholds() {
+  static double thr[2 * kLogThrK + 1];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    auto bits = [](double d) { uint64_t u; memcpy(&u, &d, 8); return u; };
+    auto dbl = [](uint64_t u) { double d; memcpy(&d, &u, 8); return d; };
+    thr[kLogThrK] = 1.0;
+    for (int k = 1; k <= kLogThrK; k++) {
+      // first x with 10 log10 x >= k, between 10^((k-1)/10) and 10^((k+1)/10)
+      uint64_t lo = bits(pow(10.0, (k - 1) / 10.0)), hi = bits(pow(10.0, (k + 1) / 10.0));   // f(lo) false, f(hi) true
+      while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (10.0 * log10(dbl(mid)) >= (double)k) hi = mid; else lo = mid;
+      }
+      thr[kLogThrK + k] = dbl(hi);
+      // last x with 10 log10 x <= -k
+      lo = bits(pow(10.0, (-k - 1) / 10.0));                                                  // f(lo) true
+      hi = bits(pow(10.0, (-k + 1) / 10.0));                                                  // f(hi) false
+      while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (10.0 * log10(dbl(mid)) <= (double)-k) lo = mid; else hi = mid;
+      }
+      thr[kLogThrK - k] = dbl(lo);
+    }
+  });
+  return thr;
 }
 
 }  // namespace glfer

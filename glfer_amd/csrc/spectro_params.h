@@ -76,7 +76,8 @@ hipError_t glfer_launch_levels_fixed(size_t nframes, float dmax, float dmin, flo
                                      float *levels, hipStream_t st);
 hipError_t glfer_launch_map(const float *psd, const double *avg, size_t nframes, int n, int scale_log,
                             double thr255, double one_m_thr, const float *levels,
-                            const unsigned char *colortab, unsigned char *rgb, short *lev, hipStream_t st);
+                            const unsigned char *colortab, const double *log_thr, unsigned char *rgb, short *lev,
+                            hipStream_t st);
 hipError_t glfer_launch_submean(const void *in, float *out, int H, long long nhops, int fmt,
                                 hipStream_t st);
 #ifdef __cplusplus
