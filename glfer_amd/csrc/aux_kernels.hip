@@ -515,6 +515,21 @@ __global__ __launch_bounds__(256) void avg_norm_kernel(const float *__restrict__
 // one barrier; the partials alternate between two LDS slots, so no second barrier), normalises and
 // stores the row: 4 B read (+4 B of the row leaving the window, an L2 hit for small depths) and
 // 8 B written per bin.  The next frame's samples are requested before the current one is reduced.
+#ifndef GLFER_AVG_NT
+#define GLFER_AVG_NT 1    /* +1..3 % */
+#endif
+#ifndef GLFER_AVG_ABL
+#define GLFER_AVG_ABL 0    /* timing ablations (results wrong): 1 no row stores, 2 no wavefront reduction, 4 no barrier, 8 no quotients */
+#endif
+#if GLFER_AVG_ABL & 1
+#define GLFER_AVG_STORE(dst, val) do { const double v_ = (val); if (v_ == 1.2345e-300) (dst) = v_; } while (0)
+#else
+#if GLFER_AVG_NT
+#define GLFER_AVG_STORE(dst, val) __builtin_nontemporal_store((double)(val), &(dst))   /* rows are written once and not read by this kernel */
+#else
+#define GLFER_AVG_STORE(dst, val) (dst) = (val)
+#endif
+#endif
 // ---- double-precision wavefront reductions by DPP: row_shr 1,2,4,8 leave a row's result in its lane
 // 15, row_bcast 15 / 31 carry it to lane 63, readlane broadcasts it.  A lane without a source takes
 // `ZERO ? 0 : itself` -- the identity of a sum / of a maximum or minimum.  (Six ds_bpermute rounds
@@ -568,6 +583,9 @@ struct Divisor {
     fast = __builtin_amdgcn_readfirstlane((a > 1e-100 && a < 1e100) ? 1 : 0) != 0;   // d is the same in every lane
   }
   __device__ __forceinline__ double operator()(double a) const {
+#if GLFER_AVG_ABL & 8
+    return a + y;
+#endif
     if (!fast) return a / d;
     const double q0 = a * y;
     const double r = __builtin_fma(-d, q0, a);
@@ -645,9 +663,13 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
       }
     }
     if (f + 1 < f1) fetch(f + 1);                              // in flight under the reduction
+#if !(GLFER_AVG_ABL & 2)
     wave_sum_max_min(s, mx, mi, mn);
+#endif
     if ((tid & 63) == 0) { p_sum[par][wave] = s; p_max[par][wave] = mx; p_min[par][wave] = mn; p_idx[par][wave] = mi; }
+#if !(GLFER_AVG_ABL & 4)
     __syncthreads();
+#endif
     double r_sum = p_sum[par][0], r_max = p_max[par][0], r_min = p_min[par][0];
     int r_idx = p_idx[par][0];
 #pragma unroll
@@ -668,28 +690,37 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
     double *row = avg + (size_t)f * n_out;
     double var = 0.0;
     int cnt = 0;
-    // the frame's divisors (the same in every lane)
-    const Divisor by_depth((double)(eff + 1)), by_spec(spec), by_range(mode == 3 ? top - low : top - spec);
+    // the frame's divisors (the same in every lane); one loop per mode, so that a bin's code is its
+    // mode's alone (left inside the loop, the mode tests came out as ~130 branches per frame)
+    if (mode == 2) {
+      const Divisor by_depth((double)(eff + 1));
 #pragma unroll
-    for (int j = 0; j < BPT; j++) {
-      const int b = b0 + 256 * j;
-      if (b < maxbin) {
-        const double c = cum[j];
-        double out;
-        if (mode == 2) {
-          out = by_depth(c);                                              // avg.c:155
-        } else if (mode == 3) {
-          out = max0 ? by_range(c - low) : by_spec(c);                    // avg.c:209-212
-        } else {
+      for (int j = 0; j < BPT; j++) {
+        const int b = b0 + 256 * j;
+        if (b < maxbin) GLFER_AVG_STORE(row[b], by_depth(cum[j]));                        // avg.c:155
+      }
+    } else if (mode == 3) {
+      const Divisor by_spec(spec), by_range(top - low);
+#pragma unroll
+      for (int j = 0; j < BPT; j++) {
+        const int b = b0 + 256 * j;
+        if (b < maxbin) GLFER_AVG_STORE(row[b], max0 ? by_range(cum[j] - low) : by_spec(cum[j]));   // avg.c:209-212
+      }
+    } else {
+      const Divisor by_spec(spec), by_range(top - spec);
+#pragma unroll
+      for (int j = 0; j < BPT; j++) {
+        const int b = b0 + 256 * j;
+        if (b < maxbin) {
+          const double c = cum[j];
+          double out = 1e-15;
           if (c - spec > 0) {                                             // avg.c:272-284
             const double q = by_spec(c);
             out = max0 ? by_range(c - spec) : q;
             if (b != peak) { var += q * q; cnt++; }
-          } else {
-            out = 1e-15;
           }
+          GLFER_AVG_STORE(row[b], out);
         }
-        row[b] = out;
       }
     }
     // the columns outside the band (avg.c:150-153): usually a few dozen
