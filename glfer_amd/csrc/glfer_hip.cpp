@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "host_tables.h"
@@ -57,6 +58,24 @@ int device_of(const void *d_ptr) {
   }
   return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged ? at.device : -1;
 }
+hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st) {
+  static std::mutex mu;
+  static bool raised[64] = {false};
+  int dev = -1;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!raised[dev]) {
+      raised[dev] = true;
+      hipMemPool_t pool = nullptr;
+      uint64_t keep = (uint64_t)8 << 30;
+      if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess ||
+          hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess)
+        (void)hipGetLastError();                 // the pool keeps its default: slower, not wrong
+    }
+  }
+  return hipMallocAsync(p, bytes, st);
+}
+
 }  // namespace glfer
 using glfer::DeviceGuard;
 using glfer::hip_fail;
@@ -107,7 +126,7 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
   const size_t lev_floats = d_levels ? 0 : nframes * 4, st_floats = d->autoscale ? glfer_levels_scratch_floats(nframes) : 0;
   const size_t thr_bytes = (2 * glfer::kLogThrK + 1) * sizeof(double);
   unsigned char *scratch = nullptr;
-  HIP_TRY(hipMallocAsync((void **)&scratch, 768 + thr_bytes + (lev_floats + st_floats) * sizeof(float), st));
+  HIP_TRY(glfer::scratch_malloc((void **)&scratch, 768 + thr_bytes + (lev_floats + st_floats) * sizeof(float), st));
   unsigned char *d_tab = scratch;
   double *d_thr = reinterpret_cast<double *>(scratch + 768);
   float *fs = reinterpret_cast<float *>(scratch + 768 + thr_bytes);
@@ -166,7 +185,7 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
 // Cache-sized tiles (rows still in the 256 MiB Infinity Cache when the map reads them) were
 // measured: 15 M rows/s against 117 M stage by stage over the whole batch
 // (profiles/r02_aux_sweep.txt) -- the chain's latency per tile swamps the saved HBM read.  So the
-// stages run over tiles of up to 65536 rows, which only bounds the scratch (averaged rows: 8 B/bin).
+// stages run over tiles that only bound the scratch (averaged rows: 8 B/bin, 4 GiB per tile).
 int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, int minbin, int maxbin, int max0,
                                const float *d_psd, size_t nframes, int bins, unsigned char *d_rgb, short *d_lev,
                                float *d_stats, void *hip_stream) {
@@ -179,15 +198,25 @@ int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, in
   hipStream_t st = (hipStream_t)hip_stream;
   DeviceGuard guard(data_device(d_psd));
   HIP_TRY(guard.error());
-  size_t tile = std::min<size_t>(nframes, 65536);
+  // Tiles only bound the scratch: the level walk costs its ~0.13 ms of latency per display call
+  // however few columns it gets, so fewer, larger tiles are faster (two 65536-row tiles: 116 M rows/s
+  // against 147 M stage by stage).  Averaged rows are 8 B per bin: 4 GiB of them per tile; without
+  // averaging only the 16 B of statistics per row are scratch.
+  size_t tile = averaging ? std::max<size_t>(16384, ((size_t)4 << 30) / ((size_t)bins * sizeof(double))) : (size_t)1 << 22;
+  if (const char *e = getenv("GLFER_WATERFALL_TILE")) {    // rows per tile, for tests of the tile seams and for tuning
+    const long v = atol(e);
+    if (v >= 64) tile = (size_t)v;
+  }
+  tile = std::min(tile, nframes);
+  tile = (nframes + (nframes + tile - 1) / tile - 1) / ((nframes + tile - 1) / tile);   // equal tiles: no short last one
   const size_t back = averaging ? (size_t)depth : 0;       // rows re-read in front of a tile to restart the sliding sums
   float *stats = d_stats;
   double *avg = nullptr, *ret = nullptr;
-  if (!stats) HIP_TRY(hipMallocAsync((void **)&stats, tile * 4 * sizeof(float), st));
+  if (!stats) HIP_TRY(glfer::scratch_malloc((void **)&stats, tile * 4 * sizeof(float), st));
   int rc = GLFER_OK;
   if (averaging) {
-    hipError_t e = hipMallocAsync((void **)&avg, (tile + back) * (size_t)bins * sizeof(double), st);
-    if (e == hipSuccess) e = hipMallocAsync((void **)&ret, (tile + back) * 4 * sizeof(double), st);
+    hipError_t e = glfer::scratch_malloc((void **)&avg, (tile + back) * (size_t)bins * sizeof(double), st);
+    if (e == hipSuccess) e = glfer::scratch_malloc((void **)&ret, (tile + back) * 4 * sizeof(double), st);
     if (e != hipSuccess) rc = hip_fail(e, "hipMallocAsync(waterfall tile)");
   }
   for (size_t f0 = 0; rc == GLFER_OK && f0 < nframes; f0 += tile) {
@@ -753,7 +782,7 @@ static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t fi
   if (tail_fresh >= 0 && last > 0 && hop_lo > last - 1) hop_lo = last - 1;   // the stale part needs the hop before
   const size_t nhops = first + nframes - hop_lo;
   float *scratch = nullptr;
-  HIP_TRY(hipMallocAsync((void **)&scratch, nhops * (size_t)p->hop * sizeof(float), st));
+  HIP_TRY(glfer::scratch_malloc((void **)&scratch, nhops * (size_t)p->hop * sizeof(float), st));
   const size_t esz = sp.fmt == GLFER_FMT_F32 ? 4 : (sp.fmt == GLFER_FMT_S16 ? 2 : 1);
   const char *src = (const char *)sp.stream + hop_lo * (size_t)p->hop * esz;
   hipError_t e = glfer_launch_submean(src, scratch, p->hop, (long long)nhops, sp.fmt, st);
@@ -797,7 +826,7 @@ int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, s
     // (lmp_av - 1 frames before `first`, recomputed rather than carried), then the statistic
     const size_t back = std::min<size_t>((size_t)p->lmp_av - 1, first);
     const size_t nrows = nframes + back;
-    hipError_t e = hipMallocAsync((void **)&rows, nrows * (size_t)p->bins * sizeof(float), st);
+    hipError_t e = glfer::scratch_malloc((void **)&rows, nrows * (size_t)p->bins * sizeof(float), st);
     if (e != hipSuccess) rc = hip_fail(e, "hipMallocAsync(lmp rows)");
     if (rc == GLFER_OK && back && p->cfg.sub_mean) {
       // the extra frames reach further back than the hops corrected above
@@ -925,8 +954,8 @@ int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t n
   float *spec = nullptr, *dummy = nullptr;
   if (rc == GLFER_OK) {
     const size_t g = std::min(group, nframes);
-    hipError_t e = hipMallocAsync((void **)&spec, (size_t)(T + 1) * g * n * sizeof(float), st);
-    if (e == hipSuccess) e = hipMallocAsync((void **)&dummy, g * (size_t)p->bins * sizeof(float), st);
+    hipError_t e = glfer::scratch_malloc((void **)&spec, (size_t)(T + 1) * g * n * sizeof(float), st);
+    if (e == hipSuccess) e = glfer::scratch_malloc((void **)&dummy, g * (size_t)p->bins * sizeof(float), st);
     if (e != hipSuccess) rc = hip_fail(e, "hipMallocAsync(ftest spectra)");
   }
   for (size_t done = 0; rc == GLFER_OK && done < nframes; done += group) {

@@ -40,6 +40,12 @@ class DeviceGuard {
 // the device a device pointer belongs to (-1: not a device pointer HIP knows)
 int device_of(const void *d_ptr);
 
+// Stream-ordered scratch (hipMallocAsync on the current device).  The first call on a device raises
+// its default memory pool's release threshold to 8 GiB: by default the pool hands everything back at
+// the next synchronisation, and a call that takes its gigabyte of scratch again every time pays
+// for the mapping every time.
+hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st);
+
 }  // namespace glfer
 
 #define HIP_TRY(call)                                          \

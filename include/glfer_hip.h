@@ -300,7 +300,8 @@ int glfer_hip_display_device(glfer_hip_display *disp, const float *d_psd, const 
                              short *d_lev, float *d_levels, void *hip_stream);
 
 /* compute_floor + update_avg_* + the mapping for a batch of PSD rows in one call (statistics,
- * [moving average], level tracking, pixel map; scratch for at most 65536 rows at a time).  A single
+ * [moving average], level tracking, pixel map; averaged rows are scratch, at most 4 GiB at a time:
+ * the batch is walked in tiles of that many rows, GLFER_WATERFALL_TILE=<rows> overrides).  A single
  * pass over a row is not possible: the level tracking is a chain over the columns fed by every
  * column's statistics, so a row is read once for those and once to be mapped.  avg_mode 0 =
  * NO_AVG (the PSD rows are mapped), else GLFER_AVG_* with depth/minbin/maxbin/max0 as

@@ -569,10 +569,11 @@ def test_block_sizes_outside_the_16_point_range(lib, oracle, torch_cuda, n):
 
 
 def test_waterfall_device_tiles_equal_the_separate_stages(lib, torch_cuda):
-    """glfer_hip_waterfall_device (floor -> [average] -> levels -> map, tiles of 65536 rows) against the
-    three stages run over the whole batch: identical pixels, levbuf, statistics and carried state,
-    with and without averaging, across a tile boundary (70 000 rows of 513 bins)."""
+    """glfer_hip_waterfall_device (floor -> [average] -> levels -> map, in tiles) against the three
+    stages run over the whole batch: identical pixels, levbuf, statistics and carried state, with
+    and without averaging, across tile boundaries (70 000 rows of 513 bins in tiles of 30 000)."""
     torch = torch_cuda
+    os.environ["GLFER_WATERFALL_TILE"] = "30000"
     rows, bins = 70000, 513
     g = torch.Generator(device="cuda")
     g.manual_seed(5)
@@ -595,6 +596,7 @@ def test_waterfall_device_tiles_equal_the_separate_stages(lib, torch_cuda):
             else:
                 assert torch.equal(rgb, rgb_w) and torch.equal(lev, lev_w), (kw["scale_type"], avg_mode)
             assert (d1.first_buffer, d1.display_max_lvl, d1.display_min_lvl) == (d2.first_buffer, d2.display_max_lvl, d2.display_min_lvl)
+    os.environ.pop("GLFER_WATERFALL_TILE", None)
 
 
 def test_bench_two_ranks_on_one_gpu():
