@@ -266,6 +266,59 @@ __global__ __launch_bounds__(256) void submean_kernel(const void *in, float *out
   for (int i = threadIdx.x; i < H; i += 256) dst[i] = cvt_sample<FMT>(src, (unsigned)i) - mean;
 }
 
+// The same, with a hop's samples held in registers between the sum and the subtraction (one read of
+// the stream, no second pass), the loads range-checked by a buffer descriptor and issued together,
+// and the sum by DPP instead of an LDS tree with eight barriers -- the per-hop form above ran at
+// 0.7 TB/s, and mean removal is the reference's DEFAULT (opt.autoscale = 1, glfer.c:275 ->
+// fft.c:186).  GROUP lanes share a hop: 64 (a wavefront per hop, four hops per workgroup, no barrier)
+// or 256 (a workgroup per hop, one barrier); lane l holds samples l + GROUP j, j < EPL.
+// (The mean is accumulated in another order than the reference's sequential float loop,
+// fft.c:88-92 -- as in the form above: a rounding-level difference in a value that is subtracted.)
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  auto dpp = [](float x, auto ctrl, auto rowmask) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rowmask)::value, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int FMT, int GROUP, int EPL>
+__global__ __launch_bounds__(256) void submean_reg_kernel(const void *in, float *out, int H, long long nhops) {
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  __shared__ float part[4];
+  const unsigned l = GROUP == 64 ? (threadIdx.x & 63u) : threadIdx.x;
+  const long long hop = GROUP == 64 ? (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))
+                                    : (long long)blockIdx.x;
+  if (hop >= nhops) return;                        // (GROUP 64: wavefront-uniform; GROUP 256: the whole workgroup)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(in)) + hop * (long long)H * esz, 0, (unsigned)H * esz, 0x00020000);
+  float x[EPL];
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < EPL; j++) {
+    const float v = buf_sample<FMT>(rs, l * esz, (unsigned)(GROUP * j) * esz);
+    x[j] = (int)(l + GROUP * j) < H ? v : 0.0f;    // (past the hop's end the descriptor returns raw 0: a sample of -1 in the u8 format)
+  }
+#pragma unroll
+  for (int j = 0; j < EPL; j++) s += x[j];
+  s = wave_sum_f32(s);
+  if constexpr (GROUP == 256) {
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = (part[0] + part[1]) + (part[2] + part[3]);
+  }
+  const float mean = s / (float)H;
+  const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(out + hop * (long long)H, 0, (unsigned)H * 4u, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < EPL; j++)                    // (stores past the hop's end are dropped by the descriptor)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x[j] - mean), ws, l * 4u, (unsigned)(GROUP * j) * 4u, 0);
+}
+
 // The file source's trailing partial block (wav_fmt.c:102-119): `fresh` new samples over the stale
 // tail of the reader's buffer, which holds the PREVIOUS block as prepare_audio left it -- mean
 // removed in place (fft.c:93-95); prev = that corrected hop (NULL: the buffer was never filled,
@@ -334,6 +387,25 @@ extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16_n, GLFER_LOGN)(const Spec
 extern "C" hipError_t glfer_launch_submean(const void *in, float *out, int H, long long nhops, int fmt,
                                            hipStream_t st) {
   if (nhops <= 0) return hipSuccess;
+  if (fmt != GLFER_FMT_F32 && fmt != GLFER_FMT_S16 && fmt != GLFER_FMT_U8) return hipErrorInvalidValue;
+  // hops up to 16384 samples: held in registers (a wavefront per hop up to 1024 samples, a workgroup above)
+#define GLFER_SUBMEAN_REG(G, E)                                                                                     \
+  do {                                                                                                              \
+    const unsigned grid = G == 64 ? (unsigned)((nhops + 3) / 4) : (unsigned)nhops;                                  \
+    if (fmt == GLFER_FMT_F32) hipLaunchKernelGGL((submean_reg_kernel<GLFER_FMT_F32, G, E>), dim3(grid), dim3(256), 0, st, in, out, H, nhops); \
+    else if (fmt == GLFER_FMT_S16) hipLaunchKernelGGL((submean_reg_kernel<GLFER_FMT_S16, G, E>), dim3(grid), dim3(256), 0, st, in, out, H, nhops); \
+    else hipLaunchKernelGGL((submean_reg_kernel<GLFER_FMT_U8, G, E>), dim3(grid), dim3(256), 0, st, in, out, H, nhops); \
+    return hipGetLastError();                                                                                       \
+  } while (0)
+  if (H <= 64 * 2) GLFER_SUBMEAN_REG(64, 2);
+  if (H <= 64 * 4) GLFER_SUBMEAN_REG(64, 4);
+  if (H <= 64 * 8) GLFER_SUBMEAN_REG(64, 8);
+  if (H <= 64 * 16) GLFER_SUBMEAN_REG(64, 16);
+  if (H <= 256 * 8) GLFER_SUBMEAN_REG(256, 8);
+  if (H <= 256 * 16) GLFER_SUBMEAN_REG(256, 16);
+  if (H <= 256 * 32) GLFER_SUBMEAN_REG(256, 32);
+  if (H <= 256 * 64) GLFER_SUBMEAN_REG(256, 64);
+#undef GLFER_SUBMEAN_REG
   switch (fmt) {
     case GLFER_FMT_F32: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_F32>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
     case GLFER_FMT_S16: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_S16>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
