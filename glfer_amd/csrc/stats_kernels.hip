@@ -6,45 +6,99 @@
 //   ftest_kernel    mtm.c:203-210, 222-233   harmonic F statistic from the tapered spectra and mu
 //   prepare_kernel  fft.c:98-156    what prepare_audio leaves in inbuf_fft, for a batch of frames
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
+#include <type_traits>
 #include "spectro_params.h"
 
 namespace glfer {
+
+// a / d for many a and one d, correctly rounded: with y = RN(1/d) (one true division), q0 = RN(a y),
+// r = a - d q0 (exact in an fma), RN(q0 + r y) = RN(a/d) (Markstein) -- the divisors here are the
+// small integers nl and nl - 1, the dividends sums of a few float32 bins: nothing over- or underflows.
+struct SmallDivisor {
+  double d, y;
+  __device__ __forceinline__ explicit SmallDivisor(double dd) : d(dd), y(1.0 / dd) {}
+  __device__ __forceinline__ double operator()(double a) const {
+    const double q0 = a * y;
+    return __builtin_fma(__builtin_fma(-d, q0, a), y, q0);
+  }
+};
 
 // One thread per (frame, bin).  rows: periodograms of frames [row0, row0 + nrows) (global frame
 // indices), [nrows][bins]; out: frames [first, first + nframes).  The reference keeps the last nl
 // periodograms in a ring written round-robin (slot = frame mod nl, zero before its first write)
 // and sums over the SLOTS in slot order; slot j of frame f holds frame f - ((f - j) mod nl).
+// first_mod = first mod nl; c_neg = -sqrt(nl / 2.0) and c_den = 2.0 * sqrt(2.0 * nl) are the
+// expression's constants (lmp.c:156), evaluated once on the host (IEEE sqrt: the same doubles).
+// (Round 2's first form took f % nl in 64 bits and (jl - j + nl) % nl per term, two f64 square
+// roots of constants and three f64 divisions per bin: 7x the time of the periodograms under it.)
+// NL > 0: nl is that constant -- the ring's rows are loaded once into registers and the two sums are
+// straight-line code, one copy per rotation of the ring (f mod nl is the same for the whole
+// workgroup); NL = 0: any nl, by loops.
+template <int NL>
 __global__ __launch_bounds__(256) void lmp_kernel(const float *__restrict__ rows, long long row0, long long first,
-                                                  long long nframes, int bins, int nl, float *__restrict__ out) {
-  const long long fi = blockIdx.y;
+                                                  long long nframes, int bins, int nl_arg, int first_mod, double c_neg,
+                                                  double c_den, float *__restrict__ out) {
+  const int nl = NL > 0 ? NL : nl_arg;
+  const unsigned fi = blockIdx.y;                                  // < 65535
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (fi >= nframes || i >= bins) return;
+  if ((long long)fi >= nframes || i >= bins) return;
   const long long f = first + fi;
   float *o = out + (size_t)fi * bins;
   if (i == 0) {                                                    // lmp.c:160
     o[0] = 1e-3;
     return;
   }
-  const int jl = (int)(f % nl);
-  double my = 0.0;                                                 // lmp.c:134-140
-  for (int j = 0; j < nl; j++) {
-    const long long g = f - (long long)((jl - j + nl) % nl);
-    const float v = g >= 0 ? rows[(size_t)(g - row0) * bins + i] : 0.0f;
-    my += v;
+  const int jl = (int)(((unsigned)first_mod + fi % (unsigned)nl) % (unsigned)nl);   // f mod nl
+  const float *col = rows + (size_t)(f - row0) * bins + i;         // this frame's row; frame f - d is d rows up
+  const SmallDivisor by_nl((double)nl), by_nl1((double)(nl - 1));
+  double my = 0.0, sy = 0.0;
+  if constexpr (NL > 0) {
+    float v[NL];                                                   // v[d]: bin i of frame f - d (zero before the first frame)
+#pragma unroll
+    for (int d = 0; d < NL; d++) v[d] = (long long)d <= f ? *(col - (size_t)d * bins) : 0.0f;
+    // slot j holds frame f - ((jl - j) mod nl); the sums run over the slots in slot order
+    auto sums = [&](auto rc) {
+      constexpr int R = decltype(rc)::value;
+#pragma unroll
+      for (int j = 0; j < NL; j++) my += v[(R - j + NL) % NL];     // lmp.c:134-140
+      my = by_nl(my);
+#pragma unroll
+      for (int j = 0; j < NL; j++) {                               // lmp.c:143-149
+        const double t = v[(R - j + NL) % NL] - my;
+        sy += t * t;
+      }
+    };
+    if (jl == 0) sums(std::integral_constant<int, 0>{});
+    if constexpr (NL > 1) { if (jl == 1) sums(std::integral_constant<int, 1 % (NL > 0 ? NL : 1)>{}); }
+    if constexpr (NL > 2) { if (jl == 2) sums(std::integral_constant<int, 2 % (NL > 0 ? NL : 1)>{}); }
+    if constexpr (NL > 3) { if (jl == 3) sums(std::integral_constant<int, 3 % (NL > 0 ? NL : 1)>{}); }
+    if constexpr (NL > 4) { if (jl == 4) sums(std::integral_constant<int, 4 % (NL > 0 ? NL : 1)>{}); }
+    if constexpr (NL > 5) { if (jl == 5) sums(std::integral_constant<int, 5 % (NL > 0 ? NL : 1)>{}); }
+    if constexpr (NL > 6) { if (jl == 6) sums(std::integral_constant<int, 6 % (NL > 0 ? NL : 1)>{}); }
+    if constexpr (NL > 7) { if (jl == 7) sums(std::integral_constant<int, 7 % (NL > 0 ? NL : 1)>{}); }
+    static_assert(NL <= 8, "rotations are spelled out up to 8");
+  } else {
+    int d = jl;                                                    // slot j holds frame f - ((jl - j) mod nl)
+    for (int j = 0; j < nl; j++) {                                 // lmp.c:134-140
+      const float v = (long long)d <= f ? *(col - (size_t)d * bins) : 0.0f;
+      my += v;
+      d = d == 0 ? nl - 1 : d - 1;
+    }
+    my = by_nl(my);
+    d = jl;
+    for (int j = 0; j < nl; j++) {                                 // lmp.c:143-149
+      const float v = (long long)d <= f ? *(col - (size_t)d * bins) : 0.0f;
+      sy += (v - my) * (v - my);
+      d = d == 0 ? nl - 1 : d - 1;
+    }
   }
-  my /= nl;
-  double sy = 0.0;                                                 // lmp.c:143-149
-  for (int j = 0; j < nl; j++) {
-    const long long g = f - (long long)((jl - j + nl) % nl);
-    const float v = g >= 0 ? rows[(size_t)(g - row0) * bins + i] : 0.0f;
-    sy += (v - my) * (v - my);
-  }
-  sy /= (nl - 1);
+  sy = by_nl1(sy);
   double v_hat = my * my - sy;                                     // lmp.c:153-159
   if (v_hat < 0.0) v_hat = 0.0;
   v_hat = 0.5 * (my - sqrt(v_hat));
-  float r = -sqrt(nl / 2.0) + (nl * my) / (2.0 * sqrt(2.0 * nl) * v_hat);
+  float r = c_neg + (nl * my) / (c_den * v_hat);
   if (r <= 1.0e-3) r = 1e-3;
   o[i] = r;
 }
@@ -130,8 +184,19 @@ extern "C" hipError_t glfer_launch_lmp(const float *rows, long long row0, long l
   // blockIdx.y carries the frame: at most 65535 per launch
   for (size_t done = 0; done < nframes; done += 65535) {
     const size_t nf = nframes - done < 65535 ? nframes - done : 65535;
-    hipLaunchKernelGGL(lmp_kernel, dim3((unsigned)((bins + 255) / 256), (unsigned)nf), dim3(256), 0, st, rows, row0,
-                       first + (long long)done, (long long)nf, bins, nl, out + done * (size_t)bins);
+    const long long f0 = first + (long long)done;
+    const dim3 grid((unsigned)((bins + 255) / 256), (unsigned)nf);
+#define GLFER_LMP(NLC)                                                                                       \
+  hipLaunchKernelGGL(lmp_kernel<NLC>, grid, dim3(256), 0, st, rows, row0, f0, (long long)nf, bins, nl, (int)(f0 % nl), \
+                     -sqrt(nl / 2.0), 2.0 * sqrt(2.0 * nl), out + done * (size_t)bins)
+    switch (nl) {
+      case 2: GLFER_LMP(2); break;
+      case 3: GLFER_LMP(3); break;
+      case 4: GLFER_LMP(4); break;                                   // the reference's default (glfer.c:252)
+      case 8: GLFER_LMP(8); break;
+      default: GLFER_LMP(0); break;
+    }
+#undef GLFER_LMP
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
