@@ -776,8 +776,12 @@ static void fill_params(const glfer_hip_plan *p, SpectroParams &sp) {
 static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t first, size_t nframes, hipStream_t st,
                            float **scratch_out, long tail_fresh = -1) {
   const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop);
-  size_t hop_lo = first;
-  if (!sp.history_mode) hop_lo = (first > hops_back) ? first - hops_back : 0;
+  // ZERO_ALWAYS frames use only their own hop -- but the kernels that take frames lying wholly inside
+  // the stream LOAD a frame's history before they zero it (spectro16h/x/xl/y: unconditional loads,
+  // masked afterwards), so the copy reaches back over the history hops in that mode too: a copy that
+  // began at the frame's own hop had them read below the allocation (a fault, or not, with the
+  // allocator's mood: found by the 600-case fuzz sweep once the pool kept its memory).
+  size_t hop_lo = (first > hops_back) ? first - hops_back : 0;
   const size_t last = first + nframes - 1;
   if (tail_fresh >= 0 && last > 0 && hop_lo > last - 1) hop_lo = last - 1;   // the stale part needs the hop before
   const size_t nhops = first + nframes - hop_lo;

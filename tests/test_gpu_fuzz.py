@@ -29,6 +29,13 @@ def _cases():
         history_mode = int(rng.random() < 0.25)
         frames = int(rng.integers(1, 90 if n <= 1024 else 30))
         out.append((i, mode, n, overlap, kmax, nw, window, fmt, sub_mean, history_mode, frames))
+    # cases a wider sweep once failed on, kept for good:
+    #   162 of the 600-case sweep: mean removal + history zeroed every frame -- the kernels that take the
+    #   frames inside the stream load a frame's history before zeroing it, and the mean-corrected copy
+    #   began at the frame's own hop (a read below the allocation: a GPU fault on an unlucky address)
+    out.append((162, "mtm", 8192, 0.33, 1, 2.0, 3, "f32", 1, 1, 24))
+    out.append((9162, "fft", 4096, 0.75, 1, 2.0, 7, "s16", 1, 1, 40))
+    out.append((9163, "mtm", 4096, 0.5, 4, 2.5, 0, "f32", 1, 1, 21))
     return out
 
 
