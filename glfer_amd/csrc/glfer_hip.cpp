@@ -696,8 +696,11 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   if (force == 'h') wave_private = false;
   if (force == 'x') wave_private = real_input = false;
   if (wave_private) real_input = true, shared_odd = false;
+  if (sp.mean_inkernel && !(real_input && !wave_private && sp.npairs == 1 && sp.htapers <= 1 && !sp.spec && !sp.nonlin))
+    return hipErrorInvalidValue;                   // only spectro16h.hip's periodogram form removes the hop means itself
   if (sp.spec || sp.nonlin || !(real_input || shared_odd)) return launch_packed(sp, n, st);
   const long long first_inside = ((long long)sp.R + sp.H - 1) / sp.H;          // first frame f with f*H >= R
+  if (sp.mean_inkernel && sp.frame0 < first_inside) return hipErrorInvalidValue;   // (the caller sends the head frames another way)
   // spectro16x.hip works on groups of G consecutive frames (frame f shares its last transform with
   // frame f + G/2).  Groups are aligned to GLOBAL frame indices and only whole groups go to it, so a
   // frame's result does not depend on how the stream was cut into launches, chunks or shards, as
@@ -803,6 +806,60 @@ static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t fi
   return GLFER_OK;
 }
 
+// Can spectro16h.hip take the hop means out itself for this plan and call?  The periodogram (one
+// window, PSD only, no RA9MB/limiter), history from the stream, a hop of 2, 4, 8 or all 16 of a
+// lane's 16 sample registers (overlap 87.5 / 75 / 50 / 0 %), samples it can fetch in pairs, no
+// trailing partial block, and the form not forced elsewhere (GLFER_FORM).  GLFER_MEAN_PREPASS=1
+// keeps the pre-pass (A/B runs, and the tests that compare the two).
+static bool mean_inkernel_ok(const glfer_hip_plan *p, const SpectroParams &sp, const float *d_spec, long tail_fresh) {
+  if ((p->cfg.mode != GLFER_MODE_FFT && p->cfg.mode != GLFER_MODE_LMP) || p->nonlin || d_spec || tail_fresh >= 0 || sp.history_mode)
+    return false;
+  if (p->n < 512 || p->n > 16384 || !sp.htaps || sp.htapers > 1 || sp.npairs != 1) return false;
+  if ((16 * p->hop) % p->n) return false;
+  const int k16 = 16 * p->hop / p->n;
+  if (k16 != 2 && k16 != 4 && k16 != 8 && k16 != 16) return false;
+  const unsigned esz = sp.fmt == GLFER_FMT_F32 ? 4u : (sp.fmt == GLFER_FMT_S16 ? 2u : 1u);
+  if (sp.fmt != GLFER_FMT_F32 && ((sp.H & 1) || (reinterpret_cast<uintptr_t>(sp.stream) & (2u * esz - 1u)))) return false;
+  if (form_override() == 'w' || form_override() == 'x') return false;
+  const char *e = getenv("GLFER_MEAN_PREPASS");
+  return !(e && *e == '1');
+}
+
+// Periodograms of frames [first, first + nframes) with the mean removal (fft.c:86-96) done inside the
+// periodogram kernel: the frames that lie inside the stream read the RAW stream and no corrected
+// copy is written for them; the first ceil(R/H) frames of a stream (zero history: the packed
+// kernel) keep the copy, a few hops long.  sp: fill_params + the raw stream.
+static int launch_mean_inkernel(const glfer_hip_plan *p, const SpectroParams &sp, size_t first, size_t nframes, float *d_psd,
+                                hipStream_t st) {
+  const size_t first_inside = (size_t)((p->keep + p->hop - 1) / p->hop);
+  const size_t head = first < first_inside ? std::min(nframes, first_inside - first) : 0;
+  int rc = GLFER_OK;
+  if (head) {
+    SpectroParams hs = sp;
+    hs.frame0 = (long long)first;
+    hs.nframes = (int)head;
+    hs.psd = d_psd;
+    float *scratch = nullptr;
+    rc = submean_scratch(p, hs, first, head, st, &scratch);
+    if (rc == GLFER_OK) {
+      hipError_t e = launch_by_n(hs, p->n, st);
+      if (e != hipSuccess) rc = hip_fail(e, "estimator launch (head frames)");
+    }
+    if (scratch) (void)hipFreeAsync(scratch, st);
+  }
+  if (rc == GLFER_OK && nframes > head) {
+    SpectroParams bs = sp;
+    bs.frame0 = (long long)(first + head);
+    bs.nframes = (int)(nframes - head);
+    bs.psd = d_psd + head * (size_t)p->bins;
+    bs.spec = nullptr;
+    bs.mean_inkernel = 1;
+    hipError_t e = launch_by_n(bs, p->n, st);
+    if (e != hipSuccess) rc = hip_fail(e, "estimator launch (mean removal in the kernel)");
+  }
+  return rc;
+}
+
 int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first, size_t nframes,
                      float *d_psd, float *d_spec, hipStream_t st, long tail_fresh) {
   if (!p || !d_stream || (!d_psd && nframes)) return GLFER_E_ARG;
@@ -824,7 +881,9 @@ int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, s
   float *scratch = nullptr, *rows = nullptr;
   int rc = GLFER_OK;
   if (tail_fresh >= 0 && (tail_fresh >= (long)p->hop || p->cfg.mode == GLFER_MODE_LMP)) return GLFER_E_ARG;
-  if (p->cfg.sub_mean) rc = submean_scratch(p, sp, first, nframes, st, &scratch, tail_fresh);
+  const bool inkernel = p->cfg.sub_mean && mean_inkernel_ok(p, sp, d_spec, tail_fresh);
+  if (inkernel && p->cfg.mode == GLFER_MODE_FFT) return launch_mean_inkernel(p, sp, first, nframes, d_psd, st);
+  if (p->cfg.sub_mean && !inkernel) rc = submean_scratch(p, sp, first, nframes, st, &scratch, tail_fresh);
   if (rc == GLFER_OK && p->cfg.mode == GLFER_MODE_LMP) {
     // lmp.c:101-181: periodograms of the frames the ring holds when frame first+nframes-1 is done
     // (lmp_av - 1 frames before `first`, recomputed rather than carried), then the statistic
@@ -832,6 +891,15 @@ int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, s
     const size_t nrows = nframes + back;
     hipError_t e = glfer::scratch_malloc((void **)&rows, nrows * (size_t)p->bins * sizeof(float), st);
     if (e != hipSuccess) rc = hip_fail(e, "hipMallocAsync(lmp rows)");
+    if (rc == GLFER_OK && inkernel) {
+      rc = launch_mean_inkernel(p, sp, first - back, nrows, rows, st);
+      if (rc == GLFER_OK) {
+        e = glfer_launch_lmp(rows, (long long)(first - back), (long long)first, nframes, p->bins, p->lmp_av, d_psd, st);
+        if (e != hipSuccess) rc = hip_fail(e, "lmp launch");
+      }
+      (void)hipFreeAsync(rows, st);
+      return rc;
+    }
     if (rc == GLFER_OK && back && p->cfg.sub_mean) {
       // the extra frames reach further back than the hops corrected above
       (void)hipFreeAsync(scratch, st);

@@ -79,9 +79,22 @@ struct LaunchH {
 // registers K..15 ARE its successor's registers 0..15-K: every frame slot of a workgroup walks
 // CONSECUTIVE frames, keeps those 16-K pairs and loads only the K new ones (75 % overlap: 4 loads
 // per lane and frame instead of 16).
-template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0, int SHIFT = 0>
+//
+// MEAN = 1: per-hop mean removal (fft.c:86-96, sub_mean = opt.autoscale: the reference's default) done HERE
+// instead of by a pre-pass that writes a corrected copy of the stream.  The hop is KM = SHIFT (or 16:
+// overlap 0) of a lane's 16 sample registers, so a frame spans NH = 16/KM hops, each a fixed group of
+// registers, and a sample is corrected by the mean of the hop it arrived in: xs[m] - mu[m / KM].
+// The mean of the NEWEST hop is summed from the next frame's prefetched samples at the end of an
+// iteration (lane partial over its KM pairs in register order, butterfly over the wavefront, the
+// frame's wavefronts combined through LDS across the iteration's last barrier -- no extra barrier);
+// the older hops' means move down with the frames a slot walks.  Wherever and whenever a hop's
+// mean is formed, it is formed from the same lanes' same registers in the same order: one value.
+template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0, int SHIFT = 0, int MEAN = 0>
 __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(SpectroParams p) {
   static_assert(SHIFT == 0 || (MT == 0 && HIST == 0), "register reuse: periodogram, history from the stream");
+  static_assert(MEAN == 0 || (MT == 0 && HIST == 0 && GLFER16_BARRIER_AFTER_READS != 0), "in-kernel mean removal: periodogram, history from the stream");
+  constexpr int KM = SHIFT > 0 ? SHIFT : 16;             // MEAN: register pairs per hop
+  constexpr int NH = 16 / KM;                            //       hops per frame
   static_assert(MT == 0 || VAR == 1, "the multitaper form re-reads its window per taper");
   using L = LaunchH<LOGN>;
   using C = typename L::C;
@@ -95,6 +108,8 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   // the window -- (x/32768)*w and x*(w/32768) are the same float
   constexpr float kSampleScale = FMT == GLFER_FMT_F32 ? 1.0f : (FMT == GLFER_FMT_S16 ? 1.0f / 32768.0f : 1.0f / 128.0f);
   __shared__ v2f32 lds[L::LDS_WORDS + (VAR == 2 ? M : 0)];
+  constexpr int WPF = T > 64 ? T / 64 : 1;               // wavefronts per frame
+  __shared__ float mred[MEAN ? FPB * WPF * NH : 1];      // MEAN: the frame's wavefronts' partial sums
 
   const unsigned tid = threadIdx.x;
   const unsigned t = tid % T;
@@ -240,6 +255,47 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   long long it = 0;                                        // frames done by every slot
   prefetch_x(rel_of(0));
 
+  // ---- MEAN: sums over the hop held in registers [q KM, (q+1) KM) of the frame at rotation ROT
+  float mu[MEAN ? NH : 1];                               // the frame's hop means, oldest first (unscaled sample units)
+  auto hop_partial = [&](auto qc, auto rotc) -> float {  // this lane's share, then the wavefront's (T < 64: the frame's lanes')
+    constexpr int q = decltype(qc)::value;
+    float sm = 0.0f;
+    static_for<q * KM, (q + 1) * KM>([&](auto mc) {
+      const v2f32 x = sample_pair(mc, rotc);
+      sm += x.x;
+      sm += x.y;
+    });
+#pragma unroll
+    for (int o = 1; o < (T < 64 ? T : 64); o <<= 1) sm += __shfl_xor(sm, o);
+    return sm;
+  };
+  // the frame's total from its wavefronts' partials (call between two frame_sync: the writer side is publish())
+  auto publish = [&](float sm, int q) {
+    if constexpr (WPF > 1) {
+      if ((t & 63u) == 0) mred[(fl * WPF + (t >> 6)) * NH + q] = sm;
+    }
+  };
+  auto collect = [&](float sm, int q) -> float {
+    if constexpr (WPF > 1) {
+      float tot = mred[(fl * WPF) * NH + q];
+#pragma unroll
+      for (int w = 1; w < WPF; w++) tot += mred[(fl * WPF + w) * NH + q];
+      return tot / (float)p.H;                           // fft.c:91
+    } else {
+      return sm / (float)p.H;
+    }
+  };
+  if constexpr (MEAN != 0) {
+    float part[NH];
+    static_for<0, NH>([&](auto qc) {
+      part[decltype(qc)::value] = hop_partial(qc, std::integral_constant<int, 0>{});
+      publish(part[decltype(qc)::value], decltype(qc)::value);
+    });
+    frame_sync<T>();
+    static_for<0, NH>([&](auto qc) { mu[decltype(qc)::value] = collect(part[decltype(qc)::value], decltype(qc)::value); });
+    frame_sync<T>();                                     // mred is free again
+  }
+
   constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
   // register holding bin t + T*m after the last pass
   auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };
@@ -257,7 +313,15 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     float zr[16], zi[16];
     if constexpr (VAR == 1) load_window(j);
     v2f32 xs[16];
-    static_for<0, 16>([&](auto mc) { xs[decltype(mc)::value] = sample_pair(mc, rotc); });
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      xs[m] = sample_pair(mc, rotc);
+      if constexpr (MEAN != 0) {                       // fft.c:93-95 (the subtraction is rounded on its own: no contraction into the window product)
+#pragma clang fp contract(off)
+        xs[m].x = xs[m].x - mu[m / KM];
+        xs[m].y = xs[m].y - mu[m / KM];
+      }
+    });
     if constexpr (VAR == 2) {
       // 16 ds_read_b64 with immediate offsets: left to the compiler they become ds_read2_b64 (half
       // the rate) behind one address add each
@@ -359,7 +423,25 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
         }
       }
     }
+    float next_part = 0.0f;
+    if constexpr (MEAN != 0) {
+      // the next frame's newest hop is in px by now (requested during this frame's passes): its sum
+      // crosses the frame's wavefronts over the barrier that ends the iteration
+      if (has_next) {
+        constexpr int ROTN = (SHIFT == 4 || SHIFT == 8) ? ((decltype(rotc)::value + SHIFT) & 15) : 0;
+        next_part = hop_partial(std::integral_constant<int, NH - 1>{}, std::integral_constant<int, ROTN>{});
+        publish(next_part, NH - 1);
+      }
+    }
     if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();     // mirror entries read: buffer free
+    if constexpr (MEAN != 0) {
+      if (has_next) {
+        const float mn = collect(next_part, NH - 1);
+#pragma unroll
+        for (int h = 0; h + 1 < NH; h++) mu[h] = mu[h + 1];
+        mu[NH - 1] = mn;
+      }
+    }
    }
     it++;
     return has_next;
@@ -397,6 +479,7 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
 #if GLFER_LOGN >= 13
   if (p.htapers > 1) {
+    if (p.mean_inkernel) return hipErrorInvalidValue;
     if (p.history_mode) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, 1, 1, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
     else hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, 1, 1, 0>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
     return hipGetLastError();
@@ -404,9 +487,30 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
 #endif
   if (p.htapers > 1) return hipErrorInvalidValue;      // the multitaper form is built for N >= 8192 only
   if (p.history_mode) {
+    if (p.mean_inkernel) return hipErrorInvalidValue;
     hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
     return hipGetLastError();
   }
+#if GLFER16H_SHIFT_BUILDS
+  if (p.mean_inkernel) {
+    // mean removal inside the kernel: the hop must be 2, 4, 8 or all 16 of a lane's sample registers
+    // (overlap 87.5 / 75 / 50 / 0 %); a slot walks consecutive frames whatever the launch's length
+    // (two wavefronts per SIMD: at three the hop means and their sums push the loop into spills, and the
+    // periodogram runs as fast at two -- profiles/r02_register_reuse_ab.txt)
+    constexpr int kMeanWps = GLFER16H_WAVES_PER_SIMD > 2 ? 2 : GLFER16H_WAVES_PER_SIMD;
+    const int k16 = (16 * p.H) % (1 << L) == 0 ? (16 * p.H) >> L : 0;
+    unsigned g = (unsigned)(work / 4 < 8 * resident ? (work / 4 ? work / 4 : 1) : 8 * resident);
+    if (g >= 64) g &= ~7u;
+    if (k16 == 16) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, kMeanWps, GLFER16H_VAR, 0, 0, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    else if (k16 == 2) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, kMeanWps, GLFER16H_VAR, 0, 0, 2, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+    else if (k16 == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, kMeanWps, GLFER16H_VAR, 0, 0, 4, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+    else if (k16 == 8) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, kMeanWps, GLFER16H_VAR, 0, 0, 8, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
+#else
+  if (p.mean_inkernel) return hipErrorInvalidValue;
+#endif
 #if GLFER16H_SHIFT_BUILDS
   // overlap 87.5 / 75 / 50 %: the hop is 2 / 4 / 8 of a lane's 16 sample registers -- a slot that
   // walks consecutive frames keeps the rest.  Worth it when a slot gets >= 4 frames and the

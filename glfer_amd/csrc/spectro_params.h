@@ -38,6 +38,8 @@ struct SpectroParams {
   const float *ltaps;      /* device: [npairs-1][8][N/16][2] pair halves, then [8][N/16] the last taper */
   float *psd;              /* device: [nframes][N/2+1]                                       */
   float *spec;             /* device, optional: [nframes][N] halfcomplex spectrum            */
+  int mean_inkernel;       /* per-hop mean removal (fft.c:86-96) inside spectro16h.hip: the stream is the RAW one;
+                              only where the hop is 2, 4, 8 or 16 sixteenths of N               */
 };
 
 #ifdef __cplusplus

@@ -471,6 +471,43 @@ def test_periodogram_register_reuse_over_long_launches(lib, oracle, torch_cuda, 
     assert np.array_equal(part, got[13:frames - 7])
 
 
+@pytest.mark.parametrize("n,overlap,fmt,frames", [(4096, 0.75, "f32", 20011), (4096, 0.0, "f32", 3001), (1024, 0.5, "s16", 50001),
+                                                  (512, 0.875, "u8", 30001), (2048, 0.75, "f32", 57), (16384, 0.5, "f32", 2049),
+                                                  (8192, 0.0, "s16", 300)])
+def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, overlap, fmt, frames):
+    """Per-hop mean removal (the reference's default) done inside spectro16h (hops of 2/4/8/16
+    sixteenths of the block): against the oracle, against the pre-pass form (GLFER_MEAN_PREPASS=1:
+    the hop means are summed in another order there -- rounding-level agreement), and the same rows
+    bit for bit from a launch that starts elsewhere (other slots, other register rotations)."""
+    h = oracle.hop(n, overlap)
+    x = synth(frames * h + 3, seed=n + frames) + np.float32(0.3)       # a DC offset worth removing
+    if fmt == "s16":
+        raw = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16)
+        xf, sf = oracle.pcm_s16_to_float(raw), lib.SAMPLES_S16
+    elif fmt == "u8":
+        raw = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8)
+        xf, sf = oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
+    else:
+        raw, xf, sf = x, x, lib.SAMPLES_F32
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=7, overlap=overlap, sub_mean=1, sample_format=sf))
+    dx = torch_cuda.from_numpy(raw).cuda()
+    got = sp.run(dx).cpu().numpy()
+    nchk = min(frames, 600)                                             # the oracle on the first and last frames
+    want_head = oracle.spectrogram_fft(xf[:nchk * h].copy(), n, overlap, 7, 0.0, 0, 1, 0)
+    peak = np.abs(want_head).max(axis=1, keepdims=True)
+    assert (np.abs(got[:nchk] - want_head) / peak).max() < TOL
+    try:
+        os.environ["GLFER_MEAN_PREPASS"] = "1"
+        pre = sp.run(dx).cpu().numpy()
+    finally:
+        os.environ.pop("GLFER_MEAN_PREPASS", None)
+    rowpeak = np.abs(pre).max(axis=1, keepdims=True)
+    assert (np.abs(got - pre) / rowpeak).max() < 2e-6
+    if frames > 40:
+        part = sp.run(dx, first_frame=13, nframes=frames - 20).cpu().numpy()
+        assert np.array_equal(part, got[13:frames - 7])
+
+
 @pytest.mark.parametrize("n,overlap,kmax,nw,sub_mean", [(2048, 0.25, 4, 2.5, 0), (4096, 0.0, 4, 2.5, 0), (4096, 0.75, 7, 4.0, 1),
                                                        (8192, 0.5, 4, 2.5, 0), (16384, 0.0, 8, 4.5, 0), (16384, 0.75, 1, 1.5, 1)])
 def test_multitaper_forms_agree(lib, oracle, torch_cuda, n, overlap, kmax, nw, sub_mean):
