@@ -696,8 +696,10 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   if (force == 'h') wave_private = false;
   if (force == 'x') wave_private = real_input = false;
   if (wave_private) real_input = true, shared_odd = false;
-  if (sp.mean_inkernel && !(real_input && !wave_private && sp.npairs == 1 && sp.htapers <= 1 && !sp.spec && !sp.nonlin))
-    return hipErrorInvalidValue;                   // only spectro16h.hip's periodogram form removes the hop means itself
+  // only spectro16h.hip's periodogram form and spectro16y.hip remove the hop means themselves
+  if (sp.mean_inkernel && (sp.spec || sp.nonlin || wave_private ||
+                           !((real_input && sp.npairs == 1 && sp.htapers <= 1) || (!real_input && shared_odd && n == 4096))))
+    return hipErrorInvalidValue;
   if (sp.spec || sp.nonlin || !(real_input || shared_odd)) return launch_packed(sp, n, st);
   const long long first_inside = ((long long)sp.R + sp.H - 1) / sp.H;          // first frame f with f*H >= R
   if (sp.mean_inkernel && sp.frame0 < first_inside) return hipErrorInvalidValue;   // (the caller sends the head frames another way)
@@ -711,6 +713,7 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   long long b0 = lo > first_inside ? lo : first_inside;
   b0 = (b0 + G - 1) / G * G;
   long long b1 = hi / G * G;
+  if (sp.mean_inkernel && (b0 != lo || b1 != hi)) return hipErrorInvalidValue;   // (the caller cuts at the frame groups)
   if (b0 >= b1) return launch_packed(sp, n, st);
   auto sub = [&](long long from, long long to) {
     SpectroParams q = sp;
@@ -812,17 +815,23 @@ static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t fi
 // trailing partial block, and the form not forced elsewhere (GLFER_FORM).  GLFER_MEAN_PREPASS=1
 // keeps the pre-pass (A/B runs, and the tests that compare the two).
 static bool mean_inkernel_ok(const glfer_hip_plan *p, const SpectroParams &sp, const float *d_spec, long tail_fresh) {
-  if ((p->cfg.mode != GLFER_MODE_FFT && p->cfg.mode != GLFER_MODE_LMP) || p->nonlin || d_spec || tail_fresh >= 0 || sp.history_mode)
-    return false;
+  if (p->nonlin || d_spec || tail_fresh >= 0 || sp.history_mode) return false;
+  const char *e = getenv("GLFER_MEAN_PREPASS");
+  if (e && *e == '1') return false;
+  const int force = form_override();
+  if (p->cfg.mode == GLFER_MODE_MTM) {
+    // spectro16y.hip: N = 4096, an odd taper count >= 3, a hop of 4, 8 or 16 of a lane's 16 registers (75 / 50 / 0 %)
+    if (p->n != 4096 || !sp.xtaps || sp.npairs < 2 || force == 'w' || force == 'h') return false;
+    return p->hop == 4096 || p->hop == 2048 || p->hop == 1024;
+  }
+  if (p->cfg.mode != GLFER_MODE_FFT && p->cfg.mode != GLFER_MODE_LMP) return false;
   if (p->n < 512 || p->n > 16384 || !sp.htaps || sp.htapers > 1 || sp.npairs != 1) return false;
   if ((16 * p->hop) % p->n) return false;
   const int k16 = 16 * p->hop / p->n;
   if (k16 != 2 && k16 != 4 && k16 != 8 && k16 != 16) return false;
   const unsigned esz = sp.fmt == GLFER_FMT_F32 ? 4u : (sp.fmt == GLFER_FMT_S16 ? 2u : 1u);
   if (sp.fmt != GLFER_FMT_F32 && ((sp.H & 1) || (reinterpret_cast<uintptr_t>(sp.stream) & (2u * esz - 1u)))) return false;
-  if (form_override() == 'w' || form_override() == 'x') return false;
-  const char *e = getenv("GLFER_MEAN_PREPASS");
-  return !(e && *e == '1');
+  return force != 'w' && force != 'x';
 }
 
 // Periodograms of frames [first, first + nframes) with the mean removal (fft.c:86-96) done inside the
@@ -832,31 +841,40 @@ static bool mean_inkernel_ok(const glfer_hip_plan *p, const SpectroParams &sp, c
 static int launch_mean_inkernel(const glfer_hip_plan *p, const SpectroParams &sp, size_t first, size_t nframes, float *d_psd,
                                 hipStream_t st) {
   const size_t first_inside = (size_t)((p->keep + p->hop - 1) / p->hop);
-  const size_t head = first < first_inside ? std::min(nframes, first_inside - first) : 0;
+  const size_t G = p->cfg.mode == GLFER_MODE_MTM ? 2 : 1;        // spectro16y.hip takes whole pairs of frames (launch_by_n)
+  const size_t end = first + nframes;
+  size_t b0 = std::max(first, first_inside);
+  b0 = (b0 + G - 1) / G * G;
+  size_t b1 = end / G * G;
+  if (b0 >= b1) b0 = b1 = end;                                   // no body: everything through the copy
   int rc = GLFER_OK;
-  if (head) {
+  // frames [from, to) through the corrected copy (the stream's first frames, a lone frame off the pair grid)
+  auto by_copy = [&](size_t from, size_t to) {
+    if (rc != GLFER_OK || from >= to) return;
     SpectroParams hs = sp;
-    hs.frame0 = (long long)first;
-    hs.nframes = (int)head;
-    hs.psd = d_psd;
+    hs.frame0 = (long long)from;
+    hs.nframes = (int)(to - from);
+    hs.psd = d_psd + (from - first) * (size_t)p->bins;
     float *scratch = nullptr;
-    rc = submean_scratch(p, hs, first, head, st, &scratch);
+    rc = submean_scratch(p, hs, from, to - from, st, &scratch);
     if (rc == GLFER_OK) {
       hipError_t e = launch_by_n(hs, p->n, st);
-      if (e != hipSuccess) rc = hip_fail(e, "estimator launch (head frames)");
+      if (e != hipSuccess) rc = hip_fail(e, "estimator launch (frames through the corrected copy)");
     }
     if (scratch) (void)hipFreeAsync(scratch, st);
-  }
-  if (rc == GLFER_OK && nframes > head) {
+  };
+  by_copy(first, std::min(b0, end));
+  if (rc == GLFER_OK && b1 > b0) {
     SpectroParams bs = sp;
-    bs.frame0 = (long long)(first + head);
-    bs.nframes = (int)(nframes - head);
-    bs.psd = d_psd + head * (size_t)p->bins;
+    bs.frame0 = (long long)b0;
+    bs.nframes = (int)(b1 - b0);
+    bs.psd = d_psd + (b0 - first) * (size_t)p->bins;
     bs.spec = nullptr;
     bs.mean_inkernel = 1;
     hipError_t e = launch_by_n(bs, p->n, st);
     if (e != hipSuccess) rc = hip_fail(e, "estimator launch (mean removal in the kernel)");
   }
+  by_copy(std::max(b1, std::min(b0, end)), end);
   return rc;
 }
 
@@ -882,7 +900,7 @@ int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, s
   int rc = GLFER_OK;
   if (tail_fresh >= 0 && (tail_fresh >= (long)p->hop || p->cfg.mode == GLFER_MODE_LMP)) return GLFER_E_ARG;
   const bool inkernel = p->cfg.sub_mean && mean_inkernel_ok(p, sp, d_spec, tail_fresh);
-  if (inkernel && p->cfg.mode == GLFER_MODE_FFT) return launch_mean_inkernel(p, sp, first, nframes, d_psd, st);
+  if (inkernel && p->cfg.mode != GLFER_MODE_LMP) return launch_mean_inkernel(p, sp, first, nframes, d_psd, st);
   if (p->cfg.sub_mean && !inkernel) rc = submean_scratch(p, sp, first, nframes, st, &scratch, tail_fresh);
   if (rc == GLFER_OK && p->cfg.mode == GLFER_MODE_LMP) {
     // lmp.c:101-181: periodograms of the frames the ring holds when frame first+nframes-1 is done

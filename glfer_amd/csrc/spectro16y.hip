@@ -25,8 +25,18 @@ struct LaunchY {
 };
 
 // ABL (tools/xbench timing ablations only; results are wrong): 1 = skip the shared round
-template <int FMT, int ABL = 0, int HIST = 0>
+// KM > 0: per-hop mean removal (fft.c:86-96, the reference's default) inside the kernel, for a hop of
+// KM of a lane's 16 sample registers (KM = 16, 8, 4: overlap 0, 50, 75 %).  A frame spans NH = 16/KM
+// hops, each a fixed group of registers; frames A and A+1 share all but one.  The sums are taken from
+// the NEXT iteration's samples once they are in registers (lane partial in register order, a
+// butterfly over the wavefront, the four wavefronts through LDS across the barriers that end the
+// shared round), and x - mu is formed once, before the frames' first round.  A hop's mean comes from
+// the same lanes' same registers in the same order whichever frame it is seen in.
+template <int FMT, int ABL = 0, int HIST = 0, int KM = 0>
 __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
+  static_assert(KM == 0 || (HIST == 0 && (KM == 16 || KM == 8 || KM == 4)), "in-kernel mean removal: history from the stream");
+  constexpr int NH = KM > 0 ? 16 / KM : 1;
+  __shared__ float mred[KM > 0 ? 4 * (NH + 1) : 1];
   using C = Plan16<12>;
   using L = LaunchY;
   constexpr int N = L::N, T = L::T, PADN = L::PADN, NPASS = C::NPASS;
@@ -101,6 +111,43 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
     for (int m = 0; m < 16; m++) xB[m] = 0.0f;
   }
   prefetch_taps(0);
+
+  // ---- KM: the hop sums of frames A (NH hops) and B (its newest hop), wavefront-reduced, into mred
+  auto publish_hop_sums = [&] {
+    static_for<0, NH + 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      float sm = 0.0f;
+      static_for<0, KM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        sm += q < NH ? xA[q * KM + m] : xB[(NH - 1) * KM + m];
+      });
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) sm += __shfl_xor(sm, o);
+      if ((t & 63u) == 0) mred[(t >> 6) * (NH + 1) + q] = sm;
+    });
+  };
+  // (after a barrier) x - mu for both frames: frame B's hops are frame A's moved down by one
+  auto subtract_hop_means = [&] {
+    float mu[NH + 1];
+#pragma unroll
+    for (int q = 0; q <= NH; q++)
+      mu[q] = ((mred[q] + mred[(NH + 1) + q]) + (mred[2 * (NH + 1) + q] + mred[3 * (NH + 1) + q])) / (float)p.H;   // fft.c:91
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      xA[m] = xA[m] - mu[m / KM];
+      xB[m] = xB[m] - mu[m / KM + 1];
+    }
+  };
+  if constexpr (KM > 0) {
+    publish_hop_sums();
+    __syncthreads();
+    subtract_hop_means();
+    __syncthreads();                                 // mred is free again
+    if (fA + 1 >= p.nframes) {
+#pragma unroll
+      for (int m = 0; m < 16; m++) xB[m] = 0.0f;
+    }
+  }
 
   constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
   auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };   // register of bin t + T*m
@@ -221,10 +268,16 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
         load_x(xB, nfA + 1);
       }
     });
+    if constexpr (KM > 0) {
+      if (has_next) publish_hop_sums();              // the next iteration's samples are in registers (requested during the passes above)
+    }
     separate_and_store<12, 1>(p, zr, zi, xbA, t, 0u, fA, hxA, hxB,
                               [&](auto mc) { if constexpr (decltype(mc)::value == 8) return nyqA; else return psdA[decltype(mc)::value]; },
                               [&](auto mc) { if constexpr (decltype(mc)::value == 8) return nyqB; else return psdB[decltype(mc)::value]; });
     GLFER_STAMP(15);                                 // shared round end (separated, stored)
+    if constexpr (KM > 0) {
+      if (has_next) subtract_hop_means();            // (separate_and_store's barriers lie between the sums and this)
+    }
     if (!has_next) break;
     fA = nfA;
     if (fA + 1 >= p.nframes) {
@@ -253,6 +306,26 @@ static hipError_t launch16y_fmt(const SpectroParams &p, hipStream_t st) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(spectro16y_kernel<FMT, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     raised = true;
+  }
+  if (p.mean_inkernel) {
+    if (p.history_mode) return hipErrorInvalidValue;
+    const int km = p.H % 256 == 0 ? p.H / 256 : 0;
+#define GLFER_Y_MEAN(K)                                                                                              \
+  do {                                                                                                               \
+    static bool up = false;                                                                                          \
+    if (!up) {                                                                                                       \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(spectro16y_kernel<FMT, 0, 0, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      if (e != hipSuccess) return e;                                                                                 \
+      up = true;                                                                                                     \
+    }                                                                                                                \
+    hipLaunchKernelGGL((spectro16y_kernel<FMT, 0, 0, K>), dim3(grid), dim3(256), shmem, st, p);                     \
+    return hipGetLastError();                                                                                        \
+  } while (0)
+    if (km == 16) GLFER_Y_MEAN(16);
+    if (km == 8) GLFER_Y_MEAN(8);
+    if (km == 4) GLFER_Y_MEAN(4);
+#undef GLFER_Y_MEAN
+    return hipErrorInvalidValue;
   }
   if (p.history_mode) hipLaunchKernelGGL((spectro16y_kernel<FMT, 0, 1>), dim3(grid), dim3(256), shmem, st, p);
   else hipLaunchKernelGGL((spectro16y_kernel<FMT, 0, 0>), dim3(grid), dim3(256), shmem, st, p);

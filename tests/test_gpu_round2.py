@@ -508,6 +508,44 @@ def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, 
         assert np.array_equal(part, got[13:frames - 7])
 
 
+@pytest.mark.parametrize("overlap,kmax,fmt,frames", [(0.0, 4, "f32", 4001), (0.5, 2, "s16", 3000), (0.75, 6, "f32", 2501),
+                                                     (0.0, 4, "u8", 64), (0.75, 4, "f32", 6)])
+def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, overlap, kmax, fmt, frames):
+    """The same for spectro16y (N = 4096, odd taper counts, hop = 4/8/16 sixteenths): frames taken in
+    pairs, a lone first or last frame and the stream's first frames through the corrected copy."""
+    n, nw = 4096, 2.5 if kmax <= 4 else 4.0
+    h = oracle.hop(n, overlap)
+    x = synth(frames * h + 3, seed=kmax + frames) + np.float32(0.3)
+    if fmt == "s16":
+        raw = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16)
+        xf, sf = oracle.pcm_s16_to_float(raw), lib.SAMPLES_S16
+    elif fmt == "u8":
+        raw = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8)
+        xf, sf = oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
+    else:
+        raw, xf, sf = x, x, lib.SAMPLES_F32
+    sp = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=1, sample_format=sf))
+    dx = torch_cuda.from_numpy(raw).cuda()
+    got = sp.run(dx).cpu().numpy()
+    nchk = min(frames, 300)
+    want = oracle.spectrogram_mtm(xf[:nchk * h].copy(), n, overlap, nw, kmax, sub_mean=1, history_mode=0)
+    peak = np.abs(want).max(axis=1, keepdims=True)
+    assert (np.abs(got[:nchk] - want) / peak).max() < TOL
+    try:
+        os.environ["GLFER_MEAN_PREPASS"] = "1"
+        pre = sp.run(dx).cpu().numpy()
+    finally:
+        os.environ.pop("GLFER_MEAN_PREPASS", None)
+    rowpeak = np.abs(pre).max(axis=1, keepdims=True)
+    assert (np.abs(got - pre) / rowpeak).max() < 2e-6
+    if frames > 40:
+        cnt = (frames - 21) // 2 * 2
+        part = sp.run(dx, first_frame=14, nframes=cnt).cpu().numpy()             # even start and end: the same frame pairs
+        assert np.array_equal(part, got[14:14 + cnt])
+        odd = sp.run(dx, first_frame=13, nframes=frames - 20).cpu().numpy()      # odd start and end: lone frames by the copy
+        assert (np.abs(odd - got[13:frames - 7]) / np.abs(got[13:frames - 7]).max(axis=1, keepdims=True)).max() < 2e-6
+
+
 @pytest.mark.parametrize("n,overlap,kmax,nw,sub_mean", [(2048, 0.25, 4, 2.5, 0), (4096, 0.0, 4, 2.5, 0), (4096, 0.75, 7, 4.0, 1),
                                                        (8192, 0.5, 4, 2.5, 0), (16384, 0.0, 8, 4.5, 0), (16384, 0.75, 1, 1.5, 1)])
 def test_multitaper_forms_agree(lib, oracle, torch_cuda, n, overlap, kmax, nw, sub_mean):
