@@ -678,8 +678,8 @@ static hipError_t launch_shared_odd(const SpectroParams &sp, int n, hipStream_t 
 //                                 tables in LDS, when they fit), spectro16x.hip otherwise
 // The first ceil(R/H) frames of a stream reach back before sample 0 (zero history, fft.c:103-108);
 // they stay with spectro16.hip, which has the range-checked gather for that.
-static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
-  if (n > 16384) return launch_wave_private(sp, n, st);        // its general form takes every case itself
+enum BodyRoute { ROUTE_PACKED, ROUTE_REAL_INPUT, ROUTE_SHARED_ODD, ROUTE_WAVE_PRIVATE };
+static BodyRoute body_route(const SpectroParams &sp, int n) {
   // spectro16h.hip fetches y[2j], y[2j+1] with one load: integer samples must then sit on naturally
   // aligned pairs (even hop, so every frame starts on an even sample, and an aligned stream)
   const unsigned esz = sp.fmt == GLFER_FMT_F32 ? 4u : (sp.fmt == GLFER_FMT_S16 ? 2u : 1u);
@@ -696,11 +696,30 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   if (force == 'h') wave_private = false;
   if (force == 'x') wave_private = real_input = false;
   if (wave_private) real_input = true, shared_odd = false;
-  // only spectro16h.hip's periodogram form and spectro16y.hip remove the hop means themselves
-  if (sp.mean_inkernel && (sp.spec || sp.nonlin || wave_private ||
-                           !((real_input && sp.npairs == 1 && sp.htapers <= 1) || (!real_input && shared_odd && n == 4096))))
-    return hipErrorInvalidValue;
-  if (sp.spec || sp.nonlin || !(real_input || shared_odd)) return launch_packed(sp, n, st);
+  if (sp.spec || sp.nonlin || !(real_input || shared_odd)) return ROUTE_PACKED;
+  if (wave_private) return ROUTE_WAVE_PRIVATE;
+  return real_input ? ROUTE_REAL_INPUT : ROUTE_SHARED_ODD;
+}
+// the forms that remove the hop means themselves (SpectroParams::mean_inkernel): the packed kernel,
+// spectro16h.hip's periodogram form, spectro16y.hip
+static bool route_takes_mean(BodyRoute r, const SpectroParams &sp, int n) {
+  if (n < 256 || n > 16384 || sp.spec || sp.nonlin || sp.history_mode) return false;
+  if ((16 * sp.H) % n) return false;
+  const int k16 = 16 * sp.H / n;
+  switch (r) {
+    case ROUTE_PACKED: return k16 == 4 || k16 == 8 || k16 == 16;
+    case ROUTE_REAL_INPUT: return sp.npairs == 1 && sp.htapers <= 1 && (k16 == 2 || k16 == 4 || k16 == 8 || k16 == 16);
+    case ROUTE_SHARED_ODD: return n == 4096 && (k16 == 4 || k16 == 8 || k16 == 16);
+    default: return false;
+  }
+}
+
+static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
+  if (n > 16384) return launch_wave_private(sp, n, st);        // its general form takes every case itself
+  const BodyRoute route = body_route(sp, n);
+  const bool real_input = route == ROUTE_REAL_INPUT || route == ROUTE_WAVE_PRIVATE, wave_private = route == ROUTE_WAVE_PRIVATE;
+  if (sp.mean_inkernel && !route_takes_mean(route, sp, n)) return hipErrorInvalidValue;
+  if (route == ROUTE_PACKED) return launch_packed(sp, n, st);
   const long long first_inside = ((long long)sp.R + sp.H - 1) / sp.H;          // first frame f with f*H >= R
   if (sp.mean_inkernel && sp.frame0 < first_inside) return hipErrorInvalidValue;   // (the caller sends the head frames another way)
   // spectro16x.hip works on groups of G consecutive frames (frame f shares its last transform with
@@ -720,6 +739,7 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
     q.frame0 = from;
     q.nframes = (int)(to - from);
     q.psd = sp.psd + (size_t)(from - lo) * (size_t)(n / 2 + 1);
+    q.mean_inkernel = 0;                           // (head and tail frames: never with mean_inkernel, see above)
     return q;
   };
   if (b0 > lo) {
@@ -732,7 +752,8 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
     hipError_t e = launch_packed(tail, n, st);
     if (e != hipSuccess) return e;
   }
-  const SpectroParams body = sub(b0, b1);
+  SpectroParams body = sub(b0, b1);
+  body.mean_inkernel = sp.mean_inkernel;
   if (wave_private) return launch_wave_private(body, n, st);
   return real_input ? launch_real_input(body, n, st) : launch_shared_odd(body, n, st);
 }
@@ -816,22 +837,10 @@ static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t fi
 // keeps the pre-pass (A/B runs, and the tests that compare the two).
 static bool mean_inkernel_ok(const glfer_hip_plan *p, const SpectroParams &sp, const float *d_spec, long tail_fresh) {
   if (p->nonlin || d_spec || tail_fresh >= 0 || sp.history_mode) return false;
+  if (p->cfg.mode != GLFER_MODE_FFT && p->cfg.mode != GLFER_MODE_LMP && p->cfg.mode != GLFER_MODE_MTM) return false;
   const char *e = getenv("GLFER_MEAN_PREPASS");
   if (e && *e == '1') return false;
-  const int force = form_override();
-  if (p->cfg.mode == GLFER_MODE_MTM) {
-    // spectro16y.hip: N = 4096, an odd taper count >= 3, a hop of 4, 8 or 16 of a lane's 16 registers (75 / 50 / 0 %)
-    if (p->n != 4096 || !sp.xtaps || sp.npairs < 2 || force == 'w' || force == 'h') return false;
-    return p->hop == 4096 || p->hop == 2048 || p->hop == 1024;
-  }
-  if (p->cfg.mode != GLFER_MODE_FFT && p->cfg.mode != GLFER_MODE_LMP) return false;
-  if (p->n < 512 || p->n > 16384 || !sp.htaps || sp.htapers > 1 || sp.npairs != 1) return false;
-  if ((16 * p->hop) % p->n) return false;
-  const int k16 = 16 * p->hop / p->n;
-  if (k16 != 2 && k16 != 4 && k16 != 8 && k16 != 16) return false;
-  const unsigned esz = sp.fmt == GLFER_FMT_F32 ? 4u : (sp.fmt == GLFER_FMT_S16 ? 2u : 1u);
-  if (sp.fmt != GLFER_FMT_F32 && ((sp.H & 1) || (reinterpret_cast<uintptr_t>(sp.stream) & (2u * esz - 1u)))) return false;
-  return force != 'w' && force != 'x';
+  return route_takes_mean(body_route(sp, p->n), sp, p->n);
 }
 
 // Periodograms of frames [first, first + nframes) with the mean removal (fft.c:86-96) done inside the
@@ -841,7 +850,7 @@ static bool mean_inkernel_ok(const glfer_hip_plan *p, const SpectroParams &sp, c
 static int launch_mean_inkernel(const glfer_hip_plan *p, const SpectroParams &sp, size_t first, size_t nframes, float *d_psd,
                                 hipStream_t st) {
   const size_t first_inside = (size_t)((p->keep + p->hop - 1) / p->hop);
-  const size_t G = p->cfg.mode == GLFER_MODE_MTM ? 2 : 1;        // spectro16y.hip takes whole pairs of frames (launch_by_n)
+  const size_t G = body_route(sp, p->n) == ROUTE_SHARED_ODD ? 2 : 1;   // spectro16y.hip takes whole pairs of frames (launch_by_n)
   const size_t end = first + nframes;
   size_t b0 = std::max(first, first_inside);
   b0 = (b0 + G - 1) / G * G;

@@ -40,8 +40,16 @@ namespace glfer {
 // remaining two passes instead of stalling the next round.
 // (The timing ablations and the alternative exchange layout of the first round of work are kept
 // with tools/experiments/kbench.hip; their results are in profiles/r01_kbench_ablation.txt.)
-template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD, int STG = GLFER16_STAGGER>
+// KM > 0: per-hop mean removal (fft.c:86-96, the reference's default) inside the kernel for frames
+// that lie wholly inside the stream, the hop being KM of a lane's 16 sample registers (16, 8, 4:
+// overlap 0, 50, 75 %): when a frame's samples arrive, the sums of its 16/KM hops are taken from
+// the registers (lane partial in register order, a butterfly over the frame's lanes of a
+// wavefront, the frame's wavefronts through LDS and one barrier) and x - mu replaces x for all the
+// frame's rounds.  The same lanes, registers and order whichever frame a hop is seen in.
+template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD, int STG = GLFER16_STAGGER, int KM = 0>
 __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(SpectroParams p) {
+  static_assert(KM == 0 || (!GEN && (KM == 16 || KM == 8 || KM == 4)), "in-kernel mean removal: the plain path");
+  constexpr int NH = KM > 0 ? 16 / KM : 1;
   using C = Plan16<LOGN>;
   using L = Launch16<LOGN>;
   constexpr int N = C::N, T = C::T, NPASS = C::NPASS, FPB = L::FPB, PADN = L::PADN;
@@ -49,6 +57,8 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
   constexpr int NTWR = C::NTW - TW1;            // later passes: per lane, in registers
   constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
   __shared__ v2f32 lds[L::LDS_WORDS];
+  constexpr int WPF = T > 64 ? T / 64 : 1;        // wavefronts per frame
+  __shared__ float mred[KM > 0 && WPF > 1 ? FPB * WPF * NH : 1];
 
   const unsigned tid = threadIdx.x;
   const unsigned t = tid % T;
@@ -149,6 +159,36 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
   for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 
   while (true) {
+    if constexpr (KM > 0) {
+      if (pair == 0) {                               // a new frame's samples: x <- x - (mean of the hop x arrived in)
+        float sm[NH];
+#pragma unroll
+        for (int q = 0; q < NH; q++) {
+          sm[q] = 0.0f;
+#pragma unroll
+          for (int m = 0; m < KM; m++) sm[q] += px[q * KM + m];
+#pragma unroll
+          for (int o = 1; o < (T < 64 ? T : 64); o <<= 1) sm[q] += __shfl_xor(sm[q], o);
+        }
+        if constexpr (WPF > 1) {
+          if ((t & 63u) == 0) {
+#pragma unroll
+            for (int q = 0; q < NH; q++) mred[(fl * WPF + (t >> 6)) * NH + q] = sm[q];
+          }
+          frame_sync<T>();
+#pragma unroll
+          for (int q = 0; q < NH; q++) {
+            float tot = mred[(fl * WPF) * NH + q];
+#pragma unroll
+            for (int w = 1; w < WPF; w++) tot += mred[(fl * WPF + w) * NH + q];
+            sm[q] = tot;
+          }
+          // (the next frame's partials are written a whole frame of barriers later)
+        }
+#pragma unroll
+        for (int m = 0; m < 16; m++) px[m] = px[m] - sm[m / KM] / (float)p.H;   // fft.c:91, 93-95
+      }
+    }
     // ---- form the packed complex frame: re = x*taper(2*pair), im = x*taper(2*pair+1)
     float zr[16], zi[16];
 #pragma unroll
@@ -367,6 +407,16 @@ static hipError_t launch16_fmt(const SpectroParams &p, hipStream_t st) {
   const long long resident = 256LL * ((GLFER16_WAVES_PER_SIMD * 256) / LC::BLOCK > 0 ? (GLFER16_WAVES_PER_SIMD * 256) / LC::BLOCK : 1);
   unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
+  if (p.mean_inkernel) {
+    // frames inside the stream only, history from the stream, a hop of 4, 8 or 16 sixteenths of the block
+    if (p.nonlin || p.spec || p.history_mode || p.frame0 * (long long)p.H < (long long)p.R) return hipErrorInvalidValue;
+    const int km = (16 * p.H) % (1 << L) == 0 ? (16 * p.H) >> L : 0;
+    if (km == 16) hipLaunchKernelGGL((spectro16_kernel<L, FMT, false, GLFER16_WAVES_PER_SIMD, GLFER16_STAGGER, 16>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    else if (km == 8) hipLaunchKernelGGL((spectro16_kernel<L, FMT, false, GLFER16_WAVES_PER_SIMD, GLFER16_STAGGER, 8>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    else if (km == 4) hipLaunchKernelGGL((spectro16_kernel<L, FMT, false, GLFER16_WAVES_PER_SIMD, GLFER16_STAGGER, 4>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (p.nonlin || p.spec)
     hipLaunchKernelGGL((spectro16_kernel<L, FMT, true>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   else

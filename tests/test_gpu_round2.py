@@ -508,12 +508,16 @@ def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, 
         assert np.array_equal(part, got[13:frames - 7])
 
 
-@pytest.mark.parametrize("overlap,kmax,fmt,frames", [(0.0, 4, "f32", 4001), (0.5, 2, "s16", 3000), (0.75, 6, "f32", 2501),
-                                                     (0.0, 4, "u8", 64), (0.75, 4, "f32", 6)])
-def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, overlap, kmax, fmt, frames):
-    """The same for spectro16y (N = 4096, odd taper counts, hop = 4/8/16 sixteenths): frames taken in
-    pairs, a lone first or last frame and the stream's first frames through the corrected copy."""
-    n, nw = 4096, 2.5 if kmax <= 4 else 4.0
+@pytest.mark.parametrize("n,overlap,kmax,fmt,frames", [(4096, 0.0, 4, "f32", 4001), (4096, 0.5, 2, "s16", 3000), (4096, 0.75, 6, "f32", 2501),
+                                                       (4096, 0.0, 4, "u8", 64), (4096, 0.75, 4, "f32", 6),
+                                                       (1024, 0.0, 7, "f32", 9001), (2048, 0.5, 4, "s16", 4000), (256, 0.75, 3, "u8", 9000),
+                                                       (4096, 0.5, 5, "f32", 1500), (512, 0.0, 1, "f32", 7000)])
+def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, n, overlap, kmax, fmt, frames):
+    """The same for spectro16y (N = 4096, odd taper counts: frames taken in pairs, a lone first or last
+    frame and the stream's first frames through the corrected copy) and for the packed kernel (even
+    taper counts -- N = 1024 with 8 tapers at overlap 0 is the reference's default multitaper
+    setting -- and the block sizes whose odd counts it takes); hop = 4/8/16 sixteenths of the block."""
+    nw = 2.5 if kmax <= 4 else 4.0
     h = oracle.hop(n, overlap)
     x = synth(frames * h + 3, seed=kmax + frames) + np.float32(0.3)
     if fmt == "s16":
@@ -538,11 +542,11 @@ def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, over
         os.environ.pop("GLFER_MEAN_PREPASS", None)
     rowpeak = np.abs(pre).max(axis=1, keepdims=True)
     assert (np.abs(got - pre) / rowpeak).max() < 2e-6
-    if frames > 40:
-        cnt = (frames - 21) // 2 * 2
-        part = sp.run(dx, first_frame=14, nframes=cnt).cpu().numpy()             # even start and end: the same frame pairs
-        assert np.array_equal(part, got[14:14 + cnt])
-        odd = sp.run(dx, first_frame=13, nframes=frames - 20).cpu().numpy()      # odd start and end: lone frames by the copy
+    if frames > 100:
+        cnt = (frames - 39) // 32 * 32                                           # cuts on the frame-group grid (GLFER_FRAME_ALIGN): the same groups
+        part = sp.run(dx, first_frame=32, nframes=cnt).cpu().numpy()
+        assert np.array_equal(part, got[32:32 + cnt])
+        odd = sp.run(dx, first_frame=13, nframes=frames - 20).cpu().numpy()      # off the grid: lone frames by other routes
         assert (np.abs(odd - got[13:frames - 7]) / np.abs(got[13:frames - 7]).max(axis=1, keepdims=True)).max() < 2e-6
 
 

@@ -16,3 +16,5 @@ for sm in (0, 1):
     bench(G.FftParams(n=4096, window_type=0, overlap=0.75, sub_mean=sm), 1 << 20, "C2 periodogram sub_mean=%d" % sm)
     bench(G.MtmParams(n=4096, overlap=0.0, w=2.5, kmax=4, sub_mean=sm), 1 << 18, "C3 multitaper sub_mean=%d" % sm)
     bench(G.FftParams(n=1024, window_type=0, overlap=0.5, sub_mean=sm), 1 << 21, "C1 periodogram sub_mean=%d" % sm)
+    bench(G.MtmParams(n=1024, overlap=0.0, w=4.0, kmax=7, sub_mean=sm), 1 << 20, "reference defaults: MTM N=1024 8 tapers sub_mean=%d" % sm)
+    bench(G.FftParams(n=1024, window_type=7, overlap=0.0, sub_mean=sm), 1 << 21, "reference defaults: FFT N=1024 Kaiser sub_mean=%d" % sm)
