@@ -29,7 +29,13 @@
 #define GLFER16_STAGGER 8     /* start delay, in s_sleep units, per (blockIdx/256)%4 */
 #endif
 #ifndef GLFER16_WAVES_PER_SIMD
+/* 3 runs with a few dozen spilled registers; at N = 1024 and 2048 two spill-free wavefronts per SIMD are faster
+   (+3..9 %, tools/packed_sizes.py), at 256 / 512 / 4096 three are (or equal) */
+#if defined(GLFER_LOGN) && (GLFER_LOGN == 10 || GLFER_LOGN == 11)
+#define GLFER16_WAVES_PER_SIMD 2
+#else
 #define GLFER16_WAVES_PER_SIMD 3
+#endif
 #endif
 
 namespace glfer {
