@@ -137,6 +137,9 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
     }
   };
   auto prefetch_taps = [&](int pair) {
+#ifdef GLFER16_ABL_TAPS                            /* timing ablation: the first pair's table for every round (results wrong) */
+    if (pair != 0) return;
+#endif
     // table layout [pair][m/2][lane][4] = (taper 2p, taper 2p+1) at samples t+T*m and t+T*(m+1):
     // one 16-byte load per lane brings two complex points' worth of tapers (8 loads per round)
     const unsigned tap_p = (unsigned)pair * (N * 8u);              // byte offset of this pair's table (uniform)
