@@ -709,7 +709,7 @@ static bool route_takes_mean(BodyRoute r, const SpectroParams &sp, int n) {
   switch (r) {
     case ROUTE_PACKED: return k16 == 4 || k16 == 8 || k16 == 16;
     case ROUTE_REAL_INPUT: return sp.npairs == 1 && sp.htapers <= 1 && (k16 == 2 || k16 == 4 || k16 == 8 || k16 == 16);
-    case ROUTE_SHARED_ODD: return n == 4096 && (k16 == 4 || k16 == 8 || k16 == 16);
+    case ROUTE_SHARED_ODD: return (n == 4096 || n <= 1024) && (k16 == 4 || k16 == 8 || k16 == 16);   // y; x / xl while a frame sits in one wavefront
     default: return false;
   }
 }
@@ -850,7 +850,9 @@ static bool mean_inkernel_ok(const glfer_hip_plan *p, const SpectroParams &sp, c
 static int launch_mean_inkernel(const glfer_hip_plan *p, const SpectroParams &sp, size_t first, size_t nframes, float *d_psd,
                                 hipStream_t st) {
   const size_t first_inside = (size_t)((p->keep + p->hop - 1) / p->hop);
-  const size_t G = body_route(sp, p->n) == ROUTE_SHARED_ODD ? 2 : 1;   // spectro16y.hip takes whole pairs of frames (launch_by_n)
+  // the shared-odd-taper kernels take whole, globally aligned groups of frames (launch_by_n): pairs at N = 4096
+  const size_t lanes = (size_t)p->n / 16;
+  const size_t G = body_route(sp, p->n) == ROUTE_SHARED_ODD ? 2 * (lanes >= 256 ? 1 : 256 / lanes) : 1;
   const size_t end = first + nframes;
   size_t b0 = std::max(first, first_inside);
   b0 = (b0 + G - 1) / G * G;

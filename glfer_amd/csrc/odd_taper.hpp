@@ -40,6 +40,29 @@ __device__ __forceinline__ void load_frame16(const SpectroParams &p, unsigned t,
   }
 }
 
+// The same with per-hop mean removal (fft.c:86-96) for a hop of KM of the lane's 16 registers
+// (history from the stream; T <= 64: a frame's lanes sit in one wavefront): the hop sums are taken
+// from the registers -- lane partial in register order, a butterfly over the frame's T lanes -- and
+// x - mu replaces x.  The same lanes, registers and order whichever frame a hop is seen in.
+template <int FMT, int T, int KM>
+__device__ __forceinline__ void load_frame16_mean(const SpectroParams &p, unsigned t, unsigned fl, long long fblk, float (&dst)[16]) {
+  static_assert(T <= 64 && (KM == 16 || KM == 8 || KM == 4), "a frame within one wavefront; hop = 4, 8 or 16 registers");
+  load_frame16<FMT, T, 0>(p, t, fl, fblk, dst);
+  constexpr int NH = 16 / KM;
+  float mu[NH];
+#pragma unroll
+  for (int q = 0; q < NH; q++) {
+    float sm = 0.0f;
+#pragma unroll
+    for (int m = 0; m < KM; m++) sm += dst[q * KM + m];
+#pragma unroll
+    for (int o = 1; o < T; o <<= 1) sm += __shfl_xor(sm, o);
+    mu[q] = sm / (float)p.H;                           // fft.c:91
+  }
+#pragma unroll
+  for (int m = 0; m < 16; m++) dst[m] = dst[m] - mu[m / KM];
+}
+
 // A frame enters the shared transform scaled by 2^-hx, hx = half the binary exponent of its power
 // summed over the tapers already done, so that both halves of the transform have the same
 // magnitude and each frame sees the rounding of a transform of its own size.  A frame whose power

@@ -40,7 +40,8 @@ struct LaunchX {
   static constexpr int LDS_WORDS = FPB * PADN + 16 * 17 + 2 * FPB * PART / 2 + (FPB * WPF + 1) / 2;
 };
 
-template <int LOGN, int FMT, int WPS = GLFER16X_WAVES_PER_SIMD>
+// KM > 0: per-hop mean removal inside the kernel (load_frame16_mean, odd_taper.hpp)
+template <int LOGN, int FMT, int WPS = GLFER16X_WAVES_PER_SIMD, int KM = 0>
 __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(SpectroParams p) {
   using C = Plan16<LOGN>;
   using L = LaunchX<LOGN>;
@@ -91,7 +92,10 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
 
   float px[16];          // samples of the frame group in work (A, then B)
   v2f32 pt[16];          // next full round: taper pair; shared round: pt[0..7] = the odd taper, pt[8..15] = group A's samples
-  auto load_x = [&](float (&dst)[16], long long fblk) { load_frame16<FMT, T>(p, t, fl, fblk, dst); };
+  auto load_x = [&](float (&dst)[16], long long fblk) {
+    if constexpr (KM > 0) load_frame16_mean<FMT, T, KM>(p, t, fl, fblk, dst);
+    else load_frame16<FMT, T>(p, t, fl, fblk, dst);
+  };
   auto prefetch_taps = [&](int pair) {
     const unsigned tap_p = (unsigned)pair * (N * 8u);
     static_for<0, 8>([&](auto mc) {
@@ -247,6 +251,19 @@ static hipError_t launch16x_fmt(const SpectroParams &p, hipStream_t st) {
   const long long resident = 256LL * per_cu;
   unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
+  if (p.mean_inkernel) {
+    if constexpr (Plan16<L>::T <= 64) {
+      if (p.history_mode) return hipErrorInvalidValue;
+      const int km = (16 * p.H) % (1 << L) == 0 ? (16 * p.H) >> L : 0;
+      if (km == 16) hipLaunchKernelGGL((spectro16x_kernel<L, FMT, GLFER16X_WAVES_PER_SIMD, 16>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      else if (km == 8) hipLaunchKernelGGL((spectro16x_kernel<L, FMT, GLFER16X_WAVES_PER_SIMD, 8>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      else if (km == 4) hipLaunchKernelGGL((spectro16x_kernel<L, FMT, GLFER16X_WAVES_PER_SIMD, 4>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      else return hipErrorInvalidValue;
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   hipLaunchKernelGGL((spectro16x_kernel<L, FMT>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   return hipGetLastError();
 }

@@ -34,7 +34,8 @@ struct LaunchXL {
   static constexpr size_t lds_bytes(int nfull) { return ((size_t)FIXED_WORDS + (size_t)nfull * 8 * T + 4 * T) * 8; }
 };
 
-template <int LOGN, int FMT>
+// KM > 0: per-hop mean removal inside the kernel (load_frame16_mean, odd_taper.hpp)
+template <int LOGN, int FMT, int KM = 0>
 __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
   using C = Plan16<LOGN>;
   using L = LaunchXL<LOGN>;
@@ -79,7 +80,10 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
   const v2f32 *tw1row = tw1 + (t & 15) * 17;
   const long long stride = (long long)gridDim.x * (2 * FPB);
 
-  auto load_x = [&](float (&dst)[16], long long fblk) { load_frame16<FMT, T>(p, t, fl, fblk, dst); };
+  auto load_x = [&](float (&dst)[16], long long fblk) {
+    if constexpr (KM > 0) load_frame16_mean<FMT, T, KM>(p, t, fl, fblk, dst);
+    else load_frame16<FMT, T>(p, t, fl, fblk, dst);
+  };
 
   long long fblk = (long long)xcd_block_index() * (2 * FPB);
   if (fblk >= p.nframes) return;
@@ -242,6 +246,18 @@ static hipError_t launch16xl_fmt(const SpectroParams &p, hipStream_t st) {
   unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
   if (grid >= 64) grid &= ~7u;                       // whole XCD slices: see xcd_block_index()
   auto kern = spectro16xl_kernel<L, FMT>;
+  if (p.mean_inkernel) {
+    if constexpr (Plan16<L>::T <= 64) {
+      if (p.history_mode) return hipErrorInvalidValue;
+      const int km = (16 * p.H) % (1 << L) == 0 ? (16 * p.H) >> L : 0;
+      if (km == 16) kern = spectro16xl_kernel<L, FMT, 16>;
+      else if (km == 8) kern = spectro16xl_kernel<L, FMT, 8>;
+      else if (km == 4) kern = spectro16xl_kernel<L, FMT, 4>;
+      else return hipErrorInvalidValue;
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, st, p);

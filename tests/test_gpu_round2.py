@@ -511,12 +511,15 @@ def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, 
 @pytest.mark.parametrize("n,overlap,kmax,fmt,frames", [(4096, 0.0, 4, "f32", 4001), (4096, 0.5, 2, "s16", 3000), (4096, 0.75, 6, "f32", 2501),
                                                        (4096, 0.0, 4, "u8", 64), (4096, 0.75, 4, "f32", 6),
                                                        (1024, 0.0, 7, "f32", 9001), (2048, 0.5, 4, "s16", 4000), (256, 0.75, 3, "u8", 9000),
-                                                       (4096, 0.5, 5, "f32", 1500), (512, 0.0, 1, "f32", 7000)])
+                                                       (4096, 0.5, 5, "f32", 1500), (512, 0.0, 1, "f32", 7000),
+                                                       (1024, 0.0, 4, "f32", 9001), (512, 0.5, 2, "s16", 9000), (256, 0.75, 4, "u8", 9001),
+                                                       (1024, 0.75, 6, "f32", 5000)])
 def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, n, overlap, kmax, fmt, frames):
     """The same for spectro16y (N = 4096, odd taper counts: frames taken in pairs, a lone first or last
     frame and the stream's first frames through the corrected copy) and for the packed kernel (even
     taper counts -- N = 1024 with 8 tapers at overlap 0 is the reference's default multitaper
-    setting -- and the block sizes whose odd counts it takes); hop = 4/8/16 sixteenths of the block."""
+    setting -- and the block sizes whose odd counts it takes) and for spectro16x / xl (odd counts
+    up to N = 1024); hop = 4/8/16 sixteenths of the block."""
     nw = 2.5 if kmax <= 4 else 4.0
     h = oracle.hop(n, overlap)
     x = synth(frames * h + 3, seed=kmax + frames) + np.float32(0.3)
