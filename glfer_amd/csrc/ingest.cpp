@@ -78,6 +78,8 @@ struct Job {
   // fills dst with whole hops [hop_index, hop_index + nhops) of the stream, raw sample format;
   // returns the hops delivered (fewer only at the end of a file)
   std::function<size_t(unsigned char *dst, size_t hop_index, size_t nhops)> read;
+  const unsigned char *pinned_src = nullptr;   // the whole stream in pinned host memory (hop 0 at this address): uploaded
+                                               // from where it lies, no staging copy
   Sink sink;                             // rows of frame f go to index f - frame_lo
 };
 
@@ -120,7 +122,7 @@ int run_job(const Job &job, size_t *frames_done) {
   hipError_t e = hipSuccess;
   for (int b = 0; b < 2 && e == hipSuccess; b++) {
     e = hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&h_in[b], in_bytes, hipHostMallocDefault);
+    if (e == hipSuccess && !job.pinned_src) e = hipHostMalloc((void **)&h_in[b], in_bytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&d_in[b], in_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&d_psd[b], rows_cap * bins * sizeof(float));
     if (e == hipSuccess && !direct_out) e = hipHostMalloc((void **)&h_out[b], rows_cap * row_bytes, hipHostMallocDefault);
@@ -166,25 +168,37 @@ int run_job(const Job &job, size_t *frames_done) {
     const size_t lo_hop = cf > halo_hops ? cf - halo_hops : 0;       // first hop the chunk's buffer holds
     rc = drain(b);                                 // buffer set b is free once chunk c-2 is out
     if (rc) break;
+    if (job.pinned_src) {
+      // the caller's stream is pinned: history, hops and all go up from where they lie
+      const size_t up = cf - lo_hop + nf;
+      e = hipMemcpyAsync(d_in[b], job.pinned_src + lo_hop * hop * esz, up * hop * esz, hipMemcpyHostToDevice, st[b]);
+      if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
+    }
     // history: from the previous chunk's pinned buffer where it has it, else from the reader
     size_t have = 0;                               // hops of [lo_hop, cf) copied so far
     const int pb = b ^ 1;
-    if (prev_hops && lo_hop >= prev_lo_hop && lo_hop < prev_lo_hop + prev_hops) {
+    if (job.pinned_src) {
+      have = cf - lo_hop;
+    } else if (prev_hops && lo_hop >= prev_lo_hop && lo_hop < prev_lo_hop + prev_hops) {
       const size_t from = lo_hop - prev_lo_hop;
       have = std::min(cf - lo_hop, prev_hops - from);
       memcpy(h_in[b], h_in[pb] + from * hop * esz, have * hop * esz);
     }
-    if (lo_hop + have < cf) {
+    if (!job.pinned_src && lo_hop + have < cf) {
       const size_t want = cf - lo_hop - have;
       if (job.read(h_in[b] + have * hop * esz, lo_hop + have, want) != want) { rc = GLFER_E_ARG; break; }
     }
-    const size_t got = job.read(h_in[b] + (cf - lo_hop) * hop * esz, cf, nf);
-    if (got < nf) { nf = got; ended = true; }
+    if (!job.pinned_src) {
+      const size_t got = job.read(h_in[b] + (cf - lo_hop) * hop * esz, cf, nf);
+      if (got < nf) { nf = got; ended = true; }
+    }
     if (nf == 0) break;
     const bool has_tail = job.tail_fresh >= 0 && cf + nf == frame_hi;
     const size_t up_hops = cf - lo_hop + nf;
-    e = hipMemcpyAsync(d_in[b], h_in[b], up_hops * hop * esz, hipMemcpyHostToDevice, st[b]);
-    if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
+    if (!job.pinned_src) {
+      e = hipMemcpyAsync(d_in[b], h_in[b], up_hops * hop * esz, hipMemcpyHostToDevice, st[b]);
+      if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
+    }
     const unsigned char *vbase = d_in[b] - lo_hop * hop * esz;       // virtual address of stream sample 0
     rc = glfer_run_device(p, vbase, (cf + nf) * hop, cf, nf, d_psd[b], nullptr, st[b], has_tail ? job.tail_fresh : -1);
     if (rc) break;
@@ -312,6 +326,7 @@ int glfer_hip_spectrogram_host(glfer_hip_plan *p, const void *h_stream, size_t n
   job.p = p;
   job.frames = frames;
   job.read = array_reader(h_stream, hop_bytes);
+  if (is_pinned_host(h_stream)) job.pinned_src = (const unsigned char *)h_stream;
   job.sink.h_psd = h_psd;
   return run_job(job, nframes_out);
 }
@@ -330,6 +345,7 @@ int glfer_hip_waterfall_host(glfer_hip_plan *p, glfer_hip_display *disp, const v
   job.p = p;
   job.frames = frames;
   job.read = array_reader(h_stream, (size_t)p->hop * sample_bytes(p->cfg.sample_format));
+  if (is_pinned_host(h_stream)) job.pinned_src = (const unsigned char *)h_stream;
   job.sink.disp = disp;
   job.sink.h_rgb = h_rgb;
   job.sink.h_lev = h_lev;
@@ -359,6 +375,11 @@ int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *d
   if (!h_psd) return GLFER_E_ARG;
   const unsigned world = (unsigned)nworkers;
   const size_t hop_bytes = (size_t)hop * sample_bytes(cfg->sample_format);
+  bool pinned_in = false;
+  {
+    DeviceGuard g0(devices[0]);                                  // (pointer attributes need a current device)
+    pinned_in = g0.error() == hipSuccess && is_pinned_host(h_stream);
+  }
   std::vector<int> rcs(world, GLFER_OK);
   std::vector<std::string> msgs(world);
   std::vector<size_t> done(world, 0);
@@ -376,6 +397,7 @@ int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *d
       job.frame_lo = first;
       job.frames = count;
       job.read = array_reader(h_stream, hop_bytes);
+      if (pinned_in) job.pinned_src = (const unsigned char *)h_stream;
       job.sink.h_psd = h_psd + first * bins;
       rc = run_job(job, &done[r]);
       if (rc == GLFER_OK && done[r] != count) rc = GLFER_E_HIP;

@@ -315,6 +315,13 @@ def test_host_ring_many_chunks_and_pinned_rows(lib, oracle, torch_cuda):
         nf = C.c_size_t(0)
         lib.api._check(lib.api.lib().glfer_hip_spectrogram_host(sp._h, x.ctypes.data, x.size, pin.ptr, C.byref(nf)), "host")
         assert nf.value == frames and np.array_equal(pin.array.view(np.uint32), want.view(np.uint32))
+        # the stream itself in pinned memory: uploaded from where it lies (no staging copy)
+        pin_in = lib.PinnedArray((x.size,), np.float32)
+        pin_in.array[:] = x
+        pin.array[:] = 0
+        lib.api._check(lib.api.lib().glfer_hip_spectrogram_host(sp._h, pin_in.ptr, x.size, pin.ptr, C.byref(nf)), "host, pinned in")
+        assert nf.value == frames and np.array_equal(pin.array.view(np.uint32), want.view(np.uint32))
+        pin_in.free()
         pin.free()
 
 

@@ -47,6 +47,16 @@ for name, params in (("C2 periodogram n=4096 overlap 0.75", dict(kind="fft", n=4
     dt = time.perf_counter() - t0
     print("%s, s16 host buffer -> PINNED host PSD rows: %.2f M frames/s, %.1f GB/s over PCIe both ways"
           % (name, nf.value / dt / 1e6, (ns * 2 + pin.nbytes) / dt / 1e9), flush=True)
+    # ... and the samples in pinned memory too: uploaded from where they lie
+    pin_in = G.PinnedArray((raw.size,), np.int16)
+    pin_in.array[:] = raw
+    lib.glfer_hip_spectrogram_host(sp._h, pin_in.ptr, raw.size, pin.ptr, C.byref(nf))
+    t0 = time.perf_counter()
+    lib.glfer_hip_spectrogram_host(sp._h, pin_in.ptr, raw.size, pin.ptr, C.byref(nf))
+    dt = time.perf_counter() - t0
+    print("%s, PINNED s16 host buffer -> PINNED host PSD rows: %.2f M frames/s, %.1f GB/s over PCIe both ways"
+          % (name, nf.value / dt / 1e6, (ns * 2 + pin.nbytes) / dt / 1e9), flush=True)
+    pin_in.free()
     pin.free()
     # waterfall: RGB + levbuf back instead of float PSD (5 bytes per bin instead of 4 -- or 3 without levbuf)
     for want_lev in (True, False):
