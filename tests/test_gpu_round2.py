@@ -503,11 +503,15 @@ def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, 
     want_head = oracle.spectrogram_fft(xf[:nchk * h].copy(), n, overlap, 7, 0.0, 0, 1, 0)
     peak = np.abs(want_head).max(axis=1, keepdims=True)
     assert (np.abs(got[:nchk] - want_head) / peak).max() < TOL
+    before = os.environ.get("GLFER_MEAN_PREPASS")
     try:
         os.environ["GLFER_MEAN_PREPASS"] = "1"
         pre = sp.run(dx).cpu().numpy()
     finally:
-        os.environ.pop("GLFER_MEAN_PREPASS", None)
+        if before is None:
+            os.environ.pop("GLFER_MEAN_PREPASS", None)
+        else:
+            os.environ["GLFER_MEAN_PREPASS"] = before
     rowpeak = np.abs(pre).max(axis=1, keepdims=True)
     assert (np.abs(got - pre) / rowpeak).max() < 2e-6
     if frames > 40:
@@ -545,11 +549,15 @@ def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, n, o
     want = oracle.spectrogram_mtm(xf[:nchk * h].copy(), n, overlap, nw, kmax, sub_mean=1, history_mode=0)
     peak = np.abs(want).max(axis=1, keepdims=True)
     assert (np.abs(got[:nchk] - want) / peak).max() < TOL
+    before = os.environ.get("GLFER_MEAN_PREPASS")
     try:
         os.environ["GLFER_MEAN_PREPASS"] = "1"
         pre = sp.run(dx).cpu().numpy()
     finally:
-        os.environ.pop("GLFER_MEAN_PREPASS", None)
+        if before is None:
+            os.environ.pop("GLFER_MEAN_PREPASS", None)
+        else:
+            os.environ["GLFER_MEAN_PREPASS"] = before
     rowpeak = np.abs(pre).max(axis=1, keepdims=True)
     assert (np.abs(got - pre) / rowpeak).max() < 2e-6
     if frames > 100:
