@@ -43,7 +43,7 @@ METRICS = {"mtm": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4",
            "mtm16k": "spectrogram frames/sec + achieved HBM GB/s, N=16384 MTM K=8",
            "hparma": "spectrogram frames/sec, HP-ARMA t=128 p_e=32 N=4096"}
 # the kernel that takes the body of the launch (glfer_hip.cpp launch_by_n) and its committed PMC summary
-KERNELS = {"mtm": ("spectro16y_kernel", "hbm_traffic.json"), "fft": ("spectro16h_kernel<12>", "hbm_traffic_fft.json"),
+KERNELS = {"mtm": ("spectro16y_kernel", "hbm_traffic.json"), "fft": ("spectro16h_kernel<12, ..., SHIFT 4> (register reuse across overlapped frames)", "hbm_traffic_fft.json"),
            "mtm16k": ("spectro16w_kernel<14> (multitaper form)", "hbm_traffic_mtm16k.json"),
            "hparma": ("hparma_kernel", None)}
 
