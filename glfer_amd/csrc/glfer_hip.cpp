@@ -548,7 +548,7 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   DeviceGuard guard(p->cfg.device);
   if (p->d_taps) (void)hipFree(p->d_taps);
   if (p->d_window) (void)hipFree(p->d_window);
-  if (p->d_ftaps) (void)hipFree(p->d_ftaps);
+  if (p->d_ftaps_mu_first) (void)hipFree(p->d_ftaps_mu_first);
   if (p->d_U0) (void)hipFree(p->d_U0);
   if (p->d_tw) (void)hipFree(p->d_tw);
   if (p->d_htaps) (void)hipFree(p->d_htaps);
@@ -1018,10 +1018,11 @@ int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t n
     p->U0.resize(T);
     p->hn.resize(n);
     glfer::make_ftest_tables(n, T - 1, p->tapers.data(), p->U0.data(), p->hn.data(), &p->sum_U0_sqr);
-    std::vector<float> taps((size_t)(T + 1) * 2 * n, 0.0f);
-    for (int j = 0; j <= T; j++)
+    // [hn][taper 0..T-1][hn]: the one-launch form starts with hn (mu first), the spectrum-by-spectrum form ends with it
+    std::vector<float> taps((size_t)(T + 2) * 2 * n, 0.0f);
+    for (int j = -1; j <= T; j++)
       for (int i = 0; i < n; i++)
-        taps[(size_t)j * 2 * n + tap_slot(n, 0, i, 0)] = j < T ? (float)p->tapers[(size_t)j * n + i] : p->hn[i];
+        taps[(size_t)(j + 1) * 2 * n + tap_slot(n, 0, i, 0)] = (j >= 0 && j < T) ? (float)p->tapers[(size_t)j * n + i] : p->hn[i];
     float *d = nullptr;
     double *du = nullptr;
     HIP_TRY(hipMalloc((void **)&d, taps.size() * sizeof(float)));
@@ -1033,7 +1034,8 @@ int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t n
       (void)hipFree(du);
       return hip_fail(e, "ftest tables");
     }
-    p->d_ftaps = d;
+    p->d_ftaps_mu_first = d;
+    p->d_ftaps = d + (size_t)2 * n;
     p->d_U0 = du;
   }
   SpectroParams sp;
@@ -1049,6 +1051,25 @@ int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t n
   if (p->cfg.sub_mean) {
     sp.frame0 = (long long)first;
     rc = submean_scratch(p, sp, first, nframes, st, &scratch);
+  }
+  if (rc == GLFER_OK && n >= 256) {
+    // one launch: every round of spectro16_kernel's FT form transforms the frame under one taper and
+    // keeps what the statistic needs in registers (no spectrum goes through HBM)
+    SpectroParams q = sp;
+    q.frame0 = (long long)first;
+    q.nframes = (int)nframes;
+    q.psd = nullptr;
+    q.spec = nullptr;
+    q.ftest = d_ftest;
+    q.ft_U0 = p->d_U0;
+    q.ft_sum_U0_sqr = p->sum_U0_sqr;
+    q.ft_mu_live = mu_live ? 1 : 0;
+    q.npairs = mu_live ? T + 1 : T;                    // rounds: hn first (mu), then the tapers
+    q.taps = mu_live ? p->d_ftaps_mu_first : p->d_ftaps;
+    hipError_t e = launch_packed(q, n, st);
+    if (e != hipSuccess) rc = hip_fail(e, "ftest launch");
+    if (scratch) (void)hipFreeAsync(scratch, st);
+    return rc;
   }
   size_t group = ((size_t)256 << 20) / ((size_t)(T + 1) * n * sizeof(float));
   group = std::max<size_t>(1, std::min<size_t>(group, 32768));

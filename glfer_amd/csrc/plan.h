@@ -77,7 +77,8 @@ struct glfer_hip_plan {
   uint16_t *d_lagmap = nullptr;     // HP-ARMA: [t][p_e+1] lag held by each matrix cell
   float2 *d_unit = nullptr;         // HP-ARMA: [n/2+1] exp(-2 pi i k/n)
   // harmonic F-test (mtm.c:124-136): built on first use
-  float *d_ftaps = nullptr;         // [ntapers+1][2n]: taper j (and hn, last) alone in slot 0 of the packed layout
+  float *d_ftaps_mu_first = nullptr;   // the allocation: [hn][taper 0..ntapers-1][hn], each [2n] alone in slot 0 of the packed layout
+  float *d_ftaps = nullptr;         // = d_ftaps_mu_first + 2n: [ntapers+1][2n], taper j, then hn
   double *d_U0 = nullptr;           // [ntapers]
   std::vector<double> U0;           // [ntapers]
   std::vector<float> hn;            // [n]

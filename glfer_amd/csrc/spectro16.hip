@@ -52,9 +52,16 @@ namespace glfer {
 // the registers (lane partial in register order, a butterfly over the frame's lanes of a
 // wavefront, the frame's wavefronts through LDS and one barrier) and x - mu replaces x for all the
 // frame's rounds.  The same lanes, registers and order whichever frame a hop is seen in.
-template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD, int STG = GLFER16_STAGGER, int KM = 0>
+// FT: the harmonic F statistic of mtm_do (mtm.c:165-174, 203-233) instead of the PSD.  Every round
+// transforms the frame under ONE taper (im part zero, so Z[k] = X[k] for k <= N/2): first hn -- its
+// spectrum mu stays in 32 registers -- then tapers 0..ntap-1, each adding |X_j - mu U0_j|^2 to a
+// per-bin float sum with the reference's own double/float statement types; the quotient is formed
+// and stored after the last round.  No spectrum goes through HBM (round 2's first form wrote
+// ntap+1 spectra per frame and read them back: 7.4 M frames/s at N = 4096).
+template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD, int STG = GLFER16_STAGGER, int KM = 0, bool FT = false>
 __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(SpectroParams p) {
   static_assert(KM == 0 || (!GEN && (KM == 16 || KM == 8 || KM == 4)), "in-kernel mean removal: the plain path");
+  static_assert(!FT || !GEN, "F statistic: the plain path");
   constexpr int NH = KM > 0 ? 16 / KM : 1;
   using C = Plan16<LOGN>;
   using L = Launch16<LOGN>;
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
   float acc[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+  float ftmur[FT ? 16 : 1], ftmui[FT ? 16 : 1], ftsum[FT ? 16 : 1];   // FT: mu (re, im) and the per-bin sum, by register
 
   while (true) {
     if constexpr (KM > 0) {
@@ -241,6 +249,52 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
     // After the last pass register rho = b + B*brev(q',R) holds bin t + T*(b + B*q').
     const long long f = fblk + fl;
     const bool live = f < p.nframes;
+    if constexpr (FT) {
+      constexpr int R = C::radix(NPASS - 1), B = 16 / R;
+      const int jt = p.ft_mu_live ? pair - 1 : pair;             // taper of this round (-1: the hn round)
+      if (jt < 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ftmur[r] = zr[r]; ftmui[r] = zi[r]; ftsum[r] = 0.0f; }
+      } else {
+        if (!p.ft_mu_live && pair == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) { ftmur[r] = 0.0f; ftmui[r] = 0.0f; ftsum[r] = 0.0f; }
+        }
+        const double U0j = p.ft_U0[jt];
+        static_for<0, 16>([&](auto rc) {
+          constexpr int rho = decltype(rc)::value;
+          constexpr int b = rho % B, qp = brev(rho / B, R);
+          const int k = (int)t + T * (b + B * qp);
+          {
+#pragma clang fp contract(off)
+            // mtm.c:203-210: tmpr = ob[i] - mu[i]*U0[j] (double), ft (float) += tmpr*tmpr + tmpi*tmpi; bin 0 has no imaginary part
+            const double tmpr = (double)zr[rho] - (double)ftmur[rho] * U0j;
+            const double tmpi = (double)zi[rho] - (double)ftmui[rho] * U0j;
+            const double both = tmpr * tmpr + tmpi * tmpi, one = tmpr * tmpr;
+            ftsum[rho] = (float)((double)ftsum[rho] + (k == 0 ? one : both));
+          }
+        });
+      }
+      if (npair == 0 && live) {                                  // the frame's last round: the quotient (mtm.c:222-233)
+        float *o = p.ftest + (size_t)f * (N / 2 + 1);
+        const int kk = p.npairs - (p.ft_mu_live ? 2 : 1);        // params->kmax = ntap - 1
+        static_for<0, 16>([&](auto rc) {
+          constexpr int rho = decltype(rc)::value;
+          constexpr int b = rho % B, qp = brev(rho / B, R);
+          const int k = (int)t + T * (b + B * qp);
+          if (k <= N / 2) {
+#pragma clang fp contract(off)
+            const float mur = ftmur[rho];
+            const float mui = k == N / 2 ? mur : ftmui[rho];     // mu[n_fft - i] at i = N/2 is mu[N/2] again
+            const float ft = k < (N + 1) / 2 ? ftsum[rho] : 0.0f;
+            double num;
+            if (k == 0) num = kk * (mur * mur) * p.ft_sum_U0_sqr;
+            else num = kk * (mur * mur + mui * mui) * p.ft_sum_U0_sqr;
+            o[k] = (float)(num / ft);
+          }
+        });
+      }
+    }
     if constexpr (GEN) {
       // halfcomplex spectrum of the (single, real) tapered frame in fft_radix2.c's layout:
       // data[k] = Re X_k (k<=N/2), data[N-k] = Im X_k (0<k<N/2).  Compat/debug output.
@@ -261,7 +315,7 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
     for (int r = 0; r < 16; r++)
       acc[r] = __builtin_fmaf(zr[r], zr[r], __builtin_fmaf(zi[r], zi[r], acc[r]));
 
-    if (npair == 0) {
+    if (!FT && npair == 0) {
       // ---- last pair of this frame: mirror fold through LDS, psd[k] = acc[k] + acc[(N-k) mod N]
       float *fold = reinterpret_cast<float *>(xb);
       frame_sync<T>();
@@ -416,6 +470,12 @@ static hipError_t launch16_fmt(const SpectroParams &p, hipStream_t st) {
   const long long resident = 256LL * ((GLFER16_WAVES_PER_SIMD * 256) / LC::BLOCK > 0 ? (GLFER16_WAVES_PER_SIMD * 256) / LC::BLOCK : 1);
   unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
+  if (p.ftest) {
+    // the F statistic: one taper per round (two spill-free wavefronts per SIMD: mu and the sums are 48 more registers)
+    if (p.nonlin || p.spec || p.mean_inkernel || !p.ft_U0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((spectro16_kernel<L, FMT, false, 2, GLFER16_STAGGER, 0, true>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    return hipGetLastError();
+  }
   if (p.mean_inkernel) {
     // frames inside the stream only, history from the stream, a hop of 4, 8 or 16 sixteenths of the block
     if (p.nonlin || p.spec || p.history_mode || p.frame0 * (long long)p.H < (long long)p.R) return hipErrorInvalidValue;

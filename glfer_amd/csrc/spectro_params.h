@@ -38,6 +38,12 @@ struct SpectroParams {
   const float *ltaps;      /* device: [npairs-1][8][N/16][2] pair halves, then [8][N/16] the last taper */
   float *psd;              /* device: [nframes][N/2+1]                                       */
   float *spec;             /* device, optional: [nframes][N] halfcomplex spectrum            */
+  /* harmonic F statistic (mtm.c:165-174, 203-233) inside spectro16_kernel; ftest NULL = off.  taps then holds
+     [rounds][2N] tables with ONE taper each (im part zero): hn first when ft_mu_live, then tapers 0..ntap-1 */
+  float *ftest;            /* device: [nframes][N/2+1]                                        */
+  const double *ft_U0;     /* device: [ntap]                                                  */
+  float ft_sum_U0_sqr;
+  int ft_mu_live;          /* 0: mu is all zeros (the reference build without FFTW, mtm.c:173) */
   int mean_inkernel;       /* per-hop mean removal (fft.c:86-96) inside spectro16h.hip: the stream is the RAW one;
                               only where the hop is 2, 4, 8 or 16 sixteenths of N               */
 };
