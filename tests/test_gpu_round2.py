@@ -323,6 +323,10 @@ def test_host_ring_many_chunks_and_pinned_rows(lib, oracle, torch_cuda):
         assert nf.value == frames and np.array_equal(pin.array.view(np.uint32), want.view(np.uint32))
         pin_in.free()
         pin.free()
+        # the Python mirror's pinned rows: same values, memory released with the array
+        got_p = sp.run_host(x, pinned=True)
+        assert np.array_equal(got_p.view(np.uint32), want.view(np.uint32))
+        del got_p
 
 
 def test_multi_gpu_entry_frame_ranges_on_one_device(lib, oracle, torch_cuda):
