@@ -1,7 +1,7 @@
 #!/bin/bash
 # AddressSanitizer + UBSan over the CPU-side code (GPU ASAN is not available on this pool):
 #  1. the oracle, through the whole oracle test module;
-#  2. the product's host table builders (windows, DPSS eigen-solve, twiddles, palettes).
+#  2. the product's host table builders (windows, DPSS eigen-solve, twiddles, palettes, the display's dB-step table).
 set -e
 cd "$(dirname "$0")/.."
 tmp=$(mktemp -d)
@@ -20,6 +20,8 @@ int main() {
   for (int l = 8; l <= 14; l++) { int slots = glfer::make_twiddles16(l, nullptr); std::vector<float> tw((size_t)2 * slots * ((1 << l) / 16)); glfer::make_twiddles16(l, tw.data()); }
   unsigned char tab[768];
   for (int p = -1; p < 10; p++) glfer::make_palette(p, tab);
+  const double *thr = glfer::log_thresholds();       // the whole-dB steps of the display mapping: monotonic, and exact at both ends
+  for (int k = -glfer::kLogThrK + 1; k <= glfer::kLogThrK; k++) if (!(thr[glfer::kLogThrK + k] > thr[glfer::kLogThrK + k - 1])) return 2;
   puts("host tables: clean");
   return 0;
 }
