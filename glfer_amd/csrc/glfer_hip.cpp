@@ -519,6 +519,19 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     if (e == hipSuccess) e = hipMemcpy(p->d_wtaps, wtaps.data(), wtaps.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_wtw, wtw.data(), wtw.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_wcomb, wcomb.data(), wcomb.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && huge) {
+      // spectro_big.hip: W_M^(w k1), k1 = t + 64 m, is exp(-2 pi i w t / M) (one sincos per lane) times this table's entry
+      const int M = n / 2, W = M / 1024;
+      std::vector<float> bt((size_t)W * 16 * 2);
+      for (int w = 0; w < W; w++)
+        for (int m = 0; m < 16; m++) {
+          const double ang = -2.0 * 3.14159265358979323846 * (double)(((long long)64 * w * m) % M) / M;
+          bt[2 * ((size_t)w * 16 + m)] = (float)std::cos(ang);
+          bt[2 * ((size_t)w * 16 + m) + 1] = (float)std::sin(ang);
+        }
+      e = hipMalloc((void **)&p->d_bigtw, bt.size() * sizeof(float));
+      if (e == hipSuccess) e = hipMemcpy(p->d_bigtw, bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
   }
   if (e == hipSuccess && !xtaps.empty()) {
     e = hipMalloc((void **)&p->d_xtaps, xtaps.size() * sizeof(float));
@@ -558,6 +571,7 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (p->d_wtaps) (void)hipFree(p->d_wtaps);
   if (p->d_wtw) (void)hipFree(p->d_wtw);
   if (p->d_wcomb) (void)hipFree(p->d_wcomb);
+  if (p->d_bigtw) (void)hipFree(p->d_bigtw);
   if (p->d_ltaps) (void)hipFree(p->d_ltaps);
   if (p->d_lagmap) (void)hipFree(p->d_lagmap);
   if (p->d_unit) (void)hipFree(p->d_unit);
@@ -632,13 +646,17 @@ static hipError_t launch_real_input(const SpectroParams &sp, int n, hipStream_t 
 #define GLFER_W_PERIODOGRAM(n) (false)
 #define GLFER_W_MULTITAPER(n, tapers) ((n) >= 16384)
 
+static int form_override();
+
 static hipError_t launch_wave_private(const SpectroParams &sp, int n, hipStream_t st) {
   switch (n) {
     case 2048: return glfer_launch_spectro16w_n11(&sp, st);
     case 4096: return glfer_launch_spectro16w_n12(&sp, st);
     case 8192: return glfer_launch_spectro16w_n13(&sp, st);
     case 16384: return glfer_launch_spectro16w_n14(&sp, st);
-    case 32768: return glfer_launch_spectro16w_n15(&sp, st);
+    // N = 32768: the two-kernel form is the faster one (profiles/r02_big_blocks.txt); spectro16w.hip's single-kernel
+    // form keeps the halfcomplex spectrum output and GLFER_FORM=w
+    case 32768: return (sp.spec || form_override() == 'w') ? glfer_launch_spectro16w_n15(&sp, st) : glfer_launch_spectro_big(&sp, n, st);
     case 65536: return glfer_launch_spectro_big(&sp, n, st);
   }
   return hipErrorInvalidValue;
@@ -785,6 +803,7 @@ static void fill_params(const glfer_hip_plan *p, SpectroParams &sp) {
   sp.wtapers = p->wtapers;
   sp.wtw = p->d_wtw;
   sp.wcomb = p->d_wcomb;
+  sp.bigtw = p->d_bigtw;
 }
 
 // K0 (fft.c:86-96) for the hops that frames [first, first+nframes) touch: the mean of each hop's

@@ -72,6 +72,7 @@ struct glfer_hip_plan {
   int wtapers = 0;
   float2 *d_wtw = nullptr;          //   [27][64] twiddles of the 1024-point transform
   float2 *d_wcomb = nullptr;        //   combine / split twiddles per lane
+  float2 *d_bigtw = nullptr;        // spectro_big.hip (N >= 32768): [W][16] the register part of the sub-transforms' twiddles
   float *d_xtaps = nullptr;         // odd taper counts (spectro16x.hip): the last taper alone, [4][n/16][4]
   float *d_ltaps = nullptr;         // odd taper counts, LDS-resident half tables (spectro16xl.hip)
   uint16_t *d_lagmap = nullptr;     // HP-ARMA: [t][p_e+1] lag held by each matrix cell

@@ -1,5 +1,6 @@
 // spectro_big.hip -- block sizes whose sub-transforms no longer fit one workgroup's LDS (N = 65536:
-// W = N/2048 = 32 wavefront-private 1024-point transforms per frame and taper, 256 KB of results).
+// W = N/2048 = 32 wavefront-private 1024-point transforms per frame and taper, 256 KB of results;
+// N = 32768 too, where the one-kernel form of spectro16w.hip spills at the 128 VGPRs its 16 wavefronts leave it).
 // The same decimation-in-time split as spectro16w.hip, cut into two kernels around a scratch buffer
 // in HBM:
 //   subfft_kernel  : one wavefront per (frame, taper, w): gather z[W j + w] = y[2n] + i y[2n+1],
@@ -61,16 +62,64 @@ __global__ __launch_bounds__(256) void subfft_kernel(SpectroParams p, int W, int
     typedef float v4f32 __attribute__((ext_vector_type(4)));
     const v4f32 *ht = reinterpret_cast<const v4f32 *>(p.wtaps) + ((size_t)j * W + w) * (8 * 64) + t;
     float zr[16], zi[16];
+    const bool inside = s0 >= 0 && p.history_mode == 0;          // workgroup-uniform: no per-sample range test needed
+    // The sub-transforms' inputs lie 2W samples apart: gathered lane by lane, a wavefront's load touches 64 cache
+    // lines for 8 bytes each (N = 65536: 14 TB/s of L2 traffic for 0.9 TB/s of samples -- what bounded this
+    // kernel).  The workgroup's four sub-transforms w0..w0+3 (same frame, same taper) need 32 contiguous bytes
+    // per position W(t + 64 m): the workgroup fetches those runs with 16-byte loads and deals them into the four
+    // wavefronts' exchange strips (free until the first pass writes them), one barrier, and every wavefront reads
+    // its 16 pairs from its own strip.
+    __syncthreads();                                             // the strips are free: last iteration's exchanges are over
+    if (inside) {
+      const int w0 = w - (int)wv;                                // this workgroup's first sub-transform (wave-uniform, a multiple of 4)
+      const int relb = (int)(s0 - sbase) + 2 * w0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int pos = (int)tid + 256 * i;
+        const unsigned boff = (unsigned)(relb + 2 * W * pos) * esz;      // 8 consecutive samples = the pairs of w0..w0+3
+        float sv[8];
+        if constexpr (FMT == GLFER_FMT_F32) {
+          const auto a = __builtin_amdgcn_raw_buffer_load_b128(rs, boff, 0u, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rs, boff + 16u, 0u, 0);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            sv[e] = __uint_as_float(a[e]);
+            sv[4 + e] = __uint_as_float(b[e]);
+          }
+        } else if constexpr (FMT == GLFER_FMT_S16) {
+          const auto a = __builtin_amdgcn_raw_buffer_load_b128(rs, boff, 0u, 0);
+          const unsigned q[4] = {a[0], a[1], a[2], a[3]};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            sv[2 * e] = (float)(short)(q[e] & 0xffffu) / 32768.0f;
+            sv[2 * e + 1] = (float)(short)(q[e] >> 16) / 32768.0f;
+          }
+        } else {
+          const auto a = __builtin_amdgcn_raw_buffer_load_b64(rs, boff, 0u, 0);
+          const unsigned q[2] = {a[0], a[1]};
+#pragma unroll
+          for (int e = 0; e < 8; e++) sv[e] = ((float)((q[e >> 2] >> (8 * (e & 3))) & 0xffu) - 128.0f) / 128.0f;
+        }
+#pragma unroll
+        for (int ww = 0; ww < 4; ww++) lds[ww * STRIP + pos] = v2f32{sv[2 * ww], sv[2 * ww + 1]};
+      }
+    }
+    __syncthreads();
     static_for<0, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       const int off = 2 * W * 64 * m;
       float xv[2];
+      if (inside) {
+        const v2f32 pr = xb[t + 64 * m];
+        xv[0] = pr.x;
+        xv[1] = pr.y;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 2; e++) {
-        const int rel = rel0 + off + e, jfr = 2 * (W * (int)t + w) + off + e;
-        const bool ok = p.history_mode ? (jfr >= p.R) : (rel >= 0);
-        const float v = buf_sample<FMT>(rs, ok ? (unsigned)rel * esz : 0x80000000u, 0u);
-        xv[e] = ok ? v : 0.0f;
+        for (int e = 0; e < 2; e++) {
+          const int rel = rel0 + off + e, jfr = 2 * (W * (int)t + w) + off + e;
+          const bool ok = p.history_mode ? (jfr >= p.R) : (rel >= 0);
+          const float v = buf_sample<FMT>(rs, ok ? (unsigned)rel * esz : 0x80000000u, 0u);
+          xv[e] = ok ? v : 0.0f;
+        }
       }
       const v4f32 q = ht[64 * (m / 2)];
       const float w0 = (m & 1) ? q.z : q.x, w1 = (m & 1) ? q.w : q.y;
@@ -96,12 +145,18 @@ __global__ __launch_bounds__(256) void subfft_kernel(SpectroParams p, int W, int
     // ---- A_w[k1] * W_M^(w k1) to the scratch; register rho_of(m) holds bin t + 64 m
     if (live) {
       v2f32 *o = scratch + (((size_t)fr * ntap + j) * W + w) * 1024;
+      // W_M^(w k1), k1 = t + 64 m: the lane's exp(-2 pi i w t / M) (w t < M: no reduction) times the
+      // table's exp(-2 pi i 64 w m / M), which is the same for the whole wavefront (16 sincospif per
+      // lane and sub-transform cost as much as the transform itself)
+      float sa, ca;
+      sincospif(-2.0f * (float)(w * (int)t) / (float)M, &sa, &ca);
+      const v2f32 *bt = reinterpret_cast<const v2f32 *>(p.bigtw) + (size_t)__builtin_amdgcn_readfirstlane(w) * 16;
       static_for<0, 16>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         constexpr int r = (m % 4) + 4 * brev(m / 4, 4);
         const int k1 = (int)t + 64 * m;
-        float sn, cs;
-        sincospif(-2.0f * (float)((long long)w * k1 % M) / (float)M, &sn, &cs);
+        const v2f32 b = bt[m];
+        const float cs = __builtin_fmaf(ca, b.x, -sa * b.y), sn = __builtin_fmaf(sa, b.x, ca * b.y);
         o[k1] = v2f32{__builtin_fmaf(zr[r], cs, -zi[r] * sn), __builtin_fmaf(zr[r], sn, zi[r] * cs)};
       });
     }
@@ -166,9 +221,9 @@ using namespace glfer;
 
 // frames [p->frame0 .. +nframes) in groups that keep the scratch under ~512 MiB; p->psd is row 0 of the launch
 extern "C" hipError_t glfer_launch_spectro_big(const SpectroParams *p, int n, hipStream_t st) {
-  if (n != 65536 || !p->wtaps || !p->wtw || p->spec) return hipErrorInvalidValue;
+  if ((n != 65536 && n != 32768) || !p->wtaps || !p->wtw || !p->bigtw || p->spec) return hipErrorInvalidValue;
   if (p->nframes <= 0) return hipSuccess;
-  constexpr int W = 32;
+  const int W = n / 2048;
   const int ntap = p->wtapers > 0 ? p->wtapers : 1;
   const size_t per_frame = (size_t)ntap * W * 1024 * sizeof(v2f32);
   long long group = (long long)(((size_t)512 << 20) / per_frame);
@@ -189,7 +244,8 @@ extern "C" hipError_t glfer_launch_spectro_big(const SpectroParams *p, int n, hi
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(combine_kernel<W>, dim3(9, (unsigned)nf), dim3(64), 0, st, *p, ntap, f0, nf, scratch);
+      if (W == 32) hipLaunchKernelGGL(combine_kernel<32>, dim3(9, (unsigned)nf), dim3(64), 0, st, *p, ntap, f0, nf, scratch);
+      else hipLaunchKernelGGL(combine_kernel<16>, dim3(9, (unsigned)nf), dim3(64), 0, st, *p, ntap, f0, nf, scratch);
       e = hipGetLastError();
     }
   }

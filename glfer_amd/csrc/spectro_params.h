@@ -32,6 +32,7 @@ struct SpectroParams {
   int wtapers;             /* tables in wtaps: 1 = periodogram window; > 1 = the tapers of mtm_do       */
   const float2 *wtw;       /* device: [27][64] inter-pass twiddles of the 1024-point transform          */
   const float2 *wcomb;     /* device: [IPL*W][64 W] (cos,sin): [i][0] = 2 pi k1/N, [i][w] = 2 pi w k1/M, k1 = u + 64 W i */
+  const float2 *bigtw;     /* device: [W][16] (cos,sin)(-2 pi 64 w m / M), spectro_big.hip (N >= 32768); NULL when not built */
   /* odd taper counts, spectro16x.hip: the last taper alone; NULL when not built for this plan */
   const float *xtaps;      /* device: [4][N/16][4] last taper, sqrt(1/(4N(1+sig))) folded               */
   /* odd taper counts with LDS-resident half tables, spectro16xl.hip; NULL when not built */

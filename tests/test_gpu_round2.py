@@ -594,9 +594,10 @@ def test_multitaper_forms_agree(lib, oracle, torch_cuda, n, overlap, kmax, nw, s
 # ---- block sizes outside 256 .. 16384 (the reference takes any power of two, g_options.c:386-387) ---------
 @pytest.mark.parametrize("n", [8, 16, 32, 64, 128, 32768, 65536])
 def test_block_sizes_outside_the_16_point_range(lib, oracle, torch_cuda, n):
-    """N = 8..128 (spectro_small.hip) and N = 32768 (spectro16w.hip, W = 16, also its general form:
-    zero-history frames, RA9MB / limiter, spectrum output, integer samples on odd hops): periodogram
-    with every option, multitaper with odd and even taper counts, LMP, against the oracle."""
+    """N = 8..128 (spectro_small.hip), N = 32768 and 65536 (spectro_big.hip: zero-history frames,
+    RA9MB / limiter, integer samples on odd hops; the halfcomplex spectrum at 32768 from
+    spectro16w.hip's general form): periodogram with every option, multitaper with odd and even
+    taper counts, LMP, against the oracle."""
     big = n > 16384
     frames = 7 if big else 40
     for window, overlap, kw in (("hanning", 0.5, {}), ("kaiser", 0.0, dict(sub_mean=1)), ("blackman", 0.75, dict(a=0.001)),
@@ -646,6 +647,12 @@ def test_block_sizes_outside_the_16_point_range(lib, oracle, torch_cuda, n):
     sp = lib.Spectrogram(lib.FftParams(n=n, window_type=7, overlap=0.33, sample_format=lib.SAMPLES_S16))
     want = oracle.spectrogram_fft(oracle.pcm_s16_to_float(raw), n, 0.33, 7)
     got = sp.run(torch_cuda.from_numpy(raw).cuda()).cpu().numpy()
+    assert max(max(rel_err(got[f], want[f])) for f in range(want.shape[0])) < ((2e-4 if n == 32768 else 1e-3) if big else TOL)
+    # 8-bit samples, frames inside the stream (the staged gather of the two-kernel form at N >= 32768)
+    raw8 = np.clip(np.round(synth((frames + 2) * (n // 2), seed=6) * 100 + 128), 0, 255).astype(np.uint8)
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=2, overlap=0.5, sample_format=lib.SAMPLES_U8))
+    want = oracle.spectrogram_fft(oracle.pcm_u8_to_float(raw8), n, 0.5, 2)
+    got = sp.run(torch_cuda.from_numpy(raw8).cuda()).cpu().numpy()
     assert max(max(rel_err(got[f], want[f])) for f in range(want.shape[0])) < ((2e-4 if n == 32768 else 1e-3) if big else TOL)
     # multitaper, odd and even counts; LMP
     for kmax, nw, overlap in ((4, 2.5, 0.5), (3, 2.5, 0.0), (0, 1.0, 0.0)):
