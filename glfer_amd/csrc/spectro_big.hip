@@ -219,6 +219,10 @@ __global__ __launch_bounds__(64) void combine_kernel(SpectroParams p, int ntap, 
 
 using namespace glfer;
 
+namespace glfer {
+hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st);   // plan.h / glfer_hip.cpp: stream-ordered, from a pool that keeps its memory
+}
+
 // frames [p->frame0 .. +nframes) in groups that keep the scratch under ~512 MiB; p->psd is row 0 of the launch
 extern "C" hipError_t glfer_launch_spectro_big(const SpectroParams *p, int n, hipStream_t st) {
   if ((n != 65536 && n != 32768) || !p->wtaps || !p->wtw || !p->bigtw || p->spec) return hipErrorInvalidValue;
@@ -230,7 +234,7 @@ extern "C" hipError_t glfer_launch_spectro_big(const SpectroParams *p, int n, hi
   if (group < 1) group = 1;
   if (group > p->nframes) group = p->nframes;
   v2f32 *scratch = nullptr;
-  hipError_t e = hipMallocAsync((void **)&scratch, (size_t)group * per_frame, st);
+  hipError_t e = glfer::scratch_malloc((void **)&scratch, (size_t)group * per_frame, st);
   if (e != hipSuccess) return e;
   for (long long f0 = 0; f0 < p->nframes && e == hipSuccess; f0 += group) {
     const int nf = (int)((p->nframes - f0 < group) ? p->nframes - f0 : group);
