@@ -137,8 +137,11 @@ int glfer_hip_make_dpss(int n, int kmax, double nw, double *tapers, double *sig)
  *   d_psd    : device, [nframes][N/2+1] floats, row i = frame first_frame+i
  * Equivalent to calling fft_do+fft_psd (source.c:143-144) or mtm_do (source.c:148)
  * once per hop.  Asynchronous on hip_stream.  With sub_mean the per-hop means are
- * removed from a device copy of the hops involved (the reference mutates the caller's
- * buffer, fft.c:93-95; the device stream is left untouched). */
+ * removed inside the estimator kernels where the hop is 2, 4, 8 or 16 sixteenths of the block
+ * (overlap 87.5 / 75 / 50 / 0 %; a stream's first ceil((N-H)/H) frames and the remaining
+ * forms go through a device copy of the hops involved); the reference mutates the caller's
+ * buffer (fft.c:93-95), the device stream is left untouched either way.
+ * GLFER_MEAN_PREPASS=1 in the environment forces the copy everywhere (A/B runs). */
 int glfer_hip_spectrogram_device(glfer_hip_plan *plan, const void *d_stream, size_t nsamples,
                                  size_t first_frame, size_t nframes, float *d_psd,
                                  void *hip_stream);
