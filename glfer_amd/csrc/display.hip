@@ -36,12 +36,23 @@ struct LevelsParams {
 // is also a contraction (0.99 per frame), so two walks over the same frames from different states
 // approach each other and, once within an ulp, merge exactly (each frame merges a 1-ulp gap with
 // probability ~1 %).  The frames are therefore cut into chunks of LEV_CHUNK walked in parallel, each
-// chunk warming up over the LEV_WARM frames before it from an arbitrary state (from the true state
-// when that reaches back to frame 0): the chance that a warm-up of 4096 frames has not merged with
-// the true walk is ~1e-11, and it is not left to chance: levels_fixup_kernel compares every chunk's
-// warm-up end state with its predecessor's final state, bit for bit, and re-walks the chunk from
-// the true state where they differ.  131 072 columns: 10 M columns/s as one walk, ~16x that in chunks.
-constexpr int LEV_CHUNK = 1024, LEV_WARM = 4096;   // a block walks WARM + CHUNK frames; more, shorter chunks = more blocks, less per block
+// chunk warming up over the frames before it from an approximate state (from the true state when
+// that reaches back to frame 0).  That the warm-up has merged with the true walk is not left to
+// chance: levels_fixup_kernel compares every chunk's warm-up end state with its predecessor's final
+// state, bit for bit, and re-walks the chunk from the true state where they differ.
+// 131 072 columns: 10 M columns/s as one walk, ~40x that in chunks.
+constexpr int LEV_CHUNK = 1024;   // a block walks warm-up + CHUNK frames; more, shorter chunks = more blocks, less per block
+// A better starting state shortens the warm-up: without the rounding to float the recurrence has the closed form
+// lvl[f] = sum_d 0.01 * 0.99^d * x[f - d] (0.99^2048 = 1e-9: 2048 terms are all of it), a sum every lane can take a
+// share of.  That value is a few float ulp from the true state (whose roundings it ignores), so the walk from it is
+// within an ulp of the true walk at once and merges with it like any 1-ulp gap, ~1 % per frame: LEV_WARM_SEEDED frames
+// of warm-up (round 1: 4096 from an arbitrary state), the same verification (and re-walk) by levels_fixup_kernel.
+// Measured (131 072 columns, display with autoscale): 512 frames 169, 1024 frames 190, 2048 frames 178 M rows/s --
+// shorter, and the re-walks of the chunks that have not merged cost more than the warm-up saves.
+#ifndef GLFER_LEV_WARM_SEEDED
+#define GLFER_LEV_WARM_SEEDED 1024
+#endif
+constexpr int LEV_WARM_SEEDED = GLFER_LEV_WARM_SEEDED, LEV_SEED = 2048;
 
 // Lanes 0 / 1 of a 64-lane block carry the max / min chains over frames [from, to); the other lanes
 // stage loads and stores through LDS.  Frames >= out_from get their levels written.  The chain is the
@@ -125,15 +136,31 @@ __global__ __launch_bounds__(64) void levels_kernel(const float *__restrict__ st
   const int lane = threadIdx.x;
   const long long c = blockIdx.x, begin = c * LEV_CHUNK;
   const long long end = begin + LEV_CHUNK < nframes ? begin + LEV_CHUNK : nframes;
-  const long long ws = begin - LEV_WARM;
+  const long long ws = begin - LEV_WARM_SEEDED;
   float lvl = (lane == 0) ? p.max_lvl0 : p.min_lvl0;       // the state carried into the call
   bool first;
-  if (ws <= 0) {                                           // the walk starts at frame 0: the true state
+  if (ws - LEV_SEED <= 0) {                                // the walk starts at frame 0: the true state
     first = p.first_buffer != 0;
     levels_walk(stats, 0, begin, begin, p, p.overlap, lvl, first, levels, sx, sy);
-  } else {                                                 // warm-up from an arbitrary state (lvl = x[ws])
-    first = true;
-    levels_walk(stats, ws, begin, begin, p, 0.0f, lvl, first, levels, sx, sy);
+  } else {
+    // warm-up from the closed form of the recurrence at frame ws - 1: lane l sums the terms d = l + 64 i
+    double w = 0.01 * pow(0.99, (double)lane), s0 = 0.0, s1 = 0.0;
+    const double r64 = pow(0.99, 64.0);
+#pragma unroll 4
+    for (int i = 0; i < LEV_SEED / 64; i++) {
+      const long long f = ws - 1 - (lane + 64 * i);
+      s0 += w * (double)stats[f * 4 + 0];
+      s1 += w * (double)stats[f * 4 + 1];
+      w *= r64;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      s0 += __shfl_xor(s0, o);
+      s1 += __shfl_xor(s1, o);
+    }
+    lvl = lane == 0 ? (float)s0 : (float)s1;
+    first = false;
+    levels_walk(stats, ws, begin, begin, p, p.overlap, lvl, first, levels, sx, sy);
   }
   if (lane < 2) chunk_state[c * 4 + lane] = lvl;
   levels_walk(stats, begin, end, begin, p, p.overlap, lvl, first, levels, sx, sy);
