@@ -40,6 +40,21 @@ __device__ __forceinline__ void load_frame16(const SpectroParams &p, unsigned t,
   }
 }
 
+// Sum over the wavefront by DPP (row_shr 1,2,4,8 leave a row's sum in its lane 15, row_bcast 15 / 31
+// carry it to lane 63), broadcast from lane 63: a tenth of the latency of six ds_bpermute rounds.
+__device__ __forceinline__ float wave_total_f32(float v) {
+  auto dpp = [](float x, auto ctrl, auto rowmask) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rowmask)::value, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // The same with per-hop mean removal (fft.c:86-96) for a hop of KM of the lane's 16 registers
 // (history from the stream; T <= 64: a frame's lanes sit in one wavefront): the hop sums are taken
 // from the registers -- lane partial in register order, a butterfly over the frame's T lanes -- and

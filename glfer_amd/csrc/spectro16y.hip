@@ -17,6 +17,10 @@
 #include <stdint.h>
 #include "odd_taper.hpp"
 
+#ifndef GLFER16Y_DPP_SUM
+#define GLFER16Y_DPP_SUM 1
+#endif
+
 namespace glfer {
 
 struct LaunchY {
@@ -134,8 +138,8 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
       mu[q] = ((mred[q] + mred[(NH + 1) + q]) + (mred[2 * (NH + 1) + q] + mred[3 * (NH + 1) + q])) / (float)p.H;   // fft.c:91
 #pragma unroll
     for (int m = 0; m < 16; m++) {
-      xA[m] = xA[m] - mu[m / KM];
-      xB[m] = xB[m] - mu[m / KM + 1];
+      xA[m] = xA[m] - mu[m / (KM ? KM : 1)];
+      xB[m] = xB[m] - mu[m / (KM ? KM : 1) + 1];
     }
   };
   if constexpr (KM > 0) {
@@ -199,11 +203,16 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
         eA += accA[r];
         eB += accB[r];
       }
+#if GLFER16Y_DPP_SUM
+      eA = wave_total_f32(eA);
+      eB = wave_total_f32(eB);
+#else
 #pragma unroll
       for (int w = 1; w < 64; w <<= 1) {
         eA += __shfl_xor(eA, w);
         eB += __shfl_xor(eB, w);
       }
+#endif
       float *foldA = reinterpret_cast<float *>(xbA), *foldB = reinterpret_cast<float *>(xbB);
       static_for<8, 16>([&](auto mc) {               // the buffers are free: barrier after the last reads
         constexpr int m = decltype(mc)::value;
