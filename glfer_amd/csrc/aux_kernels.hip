@@ -3,7 +3,13 @@
 //   K5  update_avg_{plain,sumextreme,sumavg} (avg.c:108-298) -> avg_cum_kernel + avg_norm_kernel
 // HBM-bound streaming/reduction kernels over PSD rows; no LDS tiling beyond the row itself.
 #include <hip/hip_runtime.h>
+#include "display_map.hpp"
 #include <stdint.h>
+#include <type_traits>
+
+namespace glfer {
+hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);   // plan.h / glfer_hip.cpp: once per device, kernel and size class
+}
 
 namespace glfer {
 
@@ -518,6 +524,9 @@ __global__ __launch_bounds__(256) void avg_norm_kernel(const float *__restrict__
 #ifndef GLFER_AVG_NT
 #define GLFER_AVG_NT 1    /* +1..3 % */
 #endif
+#ifndef GLFER_AVG_AHEAD
+#define GLFER_AVG_AHEAD 1    /* frames requested ahead of the one being reduced: 1 or 2 (measured: no difference, see the kernel) */
+#endif
 #ifndef GLFER_AVG_ABL
 #define GLFER_AVG_ABL 0    /* timing ablations (results wrong): 1 no row stores, 2 no wavefront reduction, 4 no barrier, 8 no quotients */
 #endif
@@ -598,71 +607,166 @@ struct Divisor {
 // memory a second time -- measured without it: 16 161 B read per 8 196-B row (rocprofv3 FETCH_SIZE),
 // the second read comes from HBM, not L2 (1024 blocks x depth rows do not stay there beside the
 // 16 KB/row write stream).  The launcher uses it while depth x BPT KB fit the 64 KB dynamic limit.
-template <int BPT, bool RING>
-__global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict__ psd, long long nframes, int chunk, int bins,
+// MAP: the averaged row is not stored but mapped at once (main_window_draw's loop over avgdata.avg,
+// g_main.c:1186-1236) -- what leaves the kernel is the column's RGB bytes and levbuf shorts, 3 + 2 B
+// per bin, instead of 8 B per bin written here and read again by map_kernel.  The levels of every
+// column are known beforehand (they come from compute_floor of the PSD rows, not from the average:
+// g_main.c:1109-1139).  A thread's bins are 256 apart and a pixel is 3 bytes, so the (colour index,
+// dB short) words of a column go through LDS (two buffers: frame f's words are written after frame f's
+// reduction barrier and stored as 12-byte / 8-byte pieces after frame f+1's -- no barrier of their
+// own).  Frames [fbeg, nframes) are walked; the sums reach back before fbeg (a tile of a longer batch).
+#ifndef GLFER_AVGMAP_ABL
+#define GLFER_AVGMAP_ABL 0    /* timing ablations (results wrong): 1 columns not stored, 2 bins not mapped, 4 no colour table, 8 levels not loaded */
+#endif
+struct AvgMapArgs {
+  const float *levels;             // [nframes - fbeg][4], display_max / display_min first
+  const unsigned char *colortab;   // 768 bytes
+  const double *log_thr;
+  unsigned char *rgb;              // [nframes - fbeg][bins][3]
+  short *lev;                      // [nframes - fbeg][bins] or null
+  int scale_log;
+  double thr255, one_m_thr;
+  long long fbeg;
+};
+
+template <int BPT, bool RING, bool MAP, int NT = 256>
+__global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__ psd, long long nframes, int chunk, int bins,
                                                         int n_out, int depth, int minbin, int maxbin, int mode, int max0,
-                                                        double *__restrict__ avg, double *__restrict__ ret) {
-  __shared__ double p_sum[2][4], p_max[2][4], p_min[2][4], p_var[2][4];
-  __shared__ int p_idx[2][4], p_cnt[2][4];
-  extern __shared__ float hist[];                // RING: [depth][BPT][256]
+                                                        double *__restrict__ avg, double *__restrict__ ret, AvgMapArgs ma) {
+  constexpr int NW = NT / 64;                     // wavefronts of the block
+  __shared__ double p_sum[2][NW], p_max[2][NW], p_min[2][NW], p_var[2][NW];
+  __shared__ int p_idx[2][NW], p_cnt[2][NW];
+  __shared__ unsigned tab[MAP ? 256 : 1];
+  __shared__ unsigned char vtab[2][MAP ? 256 : 1];   // logarithmic scales: dB short l0 + i -> colour index, per frame parity (display_map.hpp)
+  __shared__ int vtab_ok[2];
+  extern __shared__ float dyn_lds[];             // MAP: [2][n_out] words of (colour index << 16 | dB short); RING: [depth][BPT][NT]
+  unsigned *const pix = reinterpret_cast<unsigned *>(dyn_lds);
+  float *const hist = dyn_lds + (MAP ? 2 * (size_t)n_out : 0);
   const int tid = threadIdx.x, wave = tid >> 6;
-  const long long f0 = (long long)blockIdx.x * chunk;
+  const long long f0 = (MAP ? ma.fbeg : 0) + (long long)blockIdx.x * chunk;
   const long long f1 = f0 + chunk < nframes ? f0 + chunk : nframes;
+  if constexpr (MAP)
+    if (tid < 256) tab[tid] = (unsigned)ma.colortab[3 * tid] | ((unsigned)ma.colortab[3 * tid + 1] << 8) | ((unsigned)ma.colortab[3 * tid + 2] << 16);
+  const double inv_one_m_thr = MAP ? 1.0 / ma.one_m_thr : 0.0;
+  // column fr's words -> its RGB bytes and shorts: pixel i is bin n_out-1-i; four pixels per thread and piece
+  auto emit = [&](long long fr) {
+#if GLFER_AVGMAP_ABL & 1
+    if (fr != -12345) return;
+#endif
+    const unsigned *pw = pix + (size_t)(fr & 1) * n_out;
+    const size_t col = (size_t)(fr - ma.fbeg);
+    unsigned char *orow = ma.rgb + col * (size_t)n_out * 3;
+    short *lrow = ma.lev ? ma.lev + col * (size_t)n_out : nullptr;
+    const int n4 = n_out & ~3;
+    for (int i = 4 * tid; i < n4; i += 4 * NT) {
+      unsigned c[4];
+      short l[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const unsigned w = pw[n_out - 1 - i - u];
+        c[u] = tab[w >> 16];
+        l[u] = (short)(w & 0xffffu);
+      }
+      const unsigned o[3] = {c[0] | (c[1] << 24), (c[1] >> 8) | (c[2] << 16), (c[2] >> 16) | (c[3] << 8)};
+      __builtin_memcpy(orow + 3 * (size_t)i, o, 12);
+      if (lrow) __builtin_memcpy(lrow + i, l, 8);
+    }
+    for (int i = n4 + tid; i < n_out; i += NT) {
+      const unsigned w = pw[n_out - 1 - i], c = tab[w >> 16];
+      orow[3 * i] = (unsigned char)c;
+      orow[3 * i + 1] = (unsigned char)(c >> 8);
+      orow[3 * i + 2] = (unsigned char)(c >> 16);
+      if (lrow) lrow[i] = (short)(w & 0xffffu);
+    }
+  };
   const int b0 = minbin + tid;
   double cum[BPT];
 #pragma unroll
   for (int j = 0; j < BPT; j++) cum[j] = 0.0;
   for (long long g = f0 > depth ? f0 - depth : 0; g < f0; g++) {
     const float *r = psd + (size_t)g * bins;
-    float *h = hist + ((size_t)(g % depth) * BPT) * 256 + tid;
+    float *h = hist + ((size_t)(g % depth) * BPT) * NT + tid;
 #pragma unroll
     for (int j = 0; j < BPT; j++)
-      if (b0 + 256 * j < maxbin) {
-        const float x = r[b0 + 256 * j];
+      if (b0 + NT * j < maxbin) {
+        const float x = r[b0 + NT * j];
         cum[j] += (double)x;
-        if constexpr (RING) h[256 * j] = x;
+        if constexpr (RING) h[NT * j] = x;
       }
   }
-  float v[BPT], old[BPT];
-  auto fetch = [&](long long f) {
+  // The next frame's samples are requested before the current one is reduced (AHEAD = 1).  Two frames
+  // ahead (AHEAD = 2: two buffers taken in turn, a buffer fetched into again as soon as its frame has
+  // gone into the sums) was built to see whether a block that walks its frames in order is short of
+  // requests in flight: no -- update_avg 172-181 M rows/s and the average-and-map waterfall 74-75 either way.
+  constexpr int AHEAD = GLFER_AVG_AHEAD;
+  float v[AHEAD][BPT], old[AHEAD][BPT];
+  auto fetch = [&](long long f, auto buf) {
+    constexpr int CUR = decltype(buf)::value;
     const float *r = psd + (size_t)f * bins;
     const float *ro = psd + (size_t)(f >= depth ? f - depth : 0) * bins;
 #pragma unroll
     for (int j = 0; j < BPT; j++) {
-      const bool in = b0 + 256 * j < maxbin;
-      v[j] = in ? r[b0 + 256 * j] : 0.0f;
-      if constexpr (!RING) old[j] = (in && f >= depth) ? ro[b0 + 256 * j] : 0.0f;
+      const bool in = b0 + NT * j < maxbin;
+      v[CUR][j] = in ? r[b0 + NT * j] : 0.0f;
+      if constexpr (!RING) old[CUR][j] = (in && f >= depth) ? ro[b0 + NT * j] : 0.0f;
     }
   };
-  fetch(f0);
+  fetch(f0, std::integral_constant<int, 0>{});
+  if constexpr (AHEAD == 2) {
+    if (f0 + 1 < f1) fetch(f0 + 1, std::integral_constant<int, 1>{});
+  }
   const double span = (double)(maxbin - minbin - 1);
-  for (long long f = f0; f < f1; f++) {
+  auto frame = [&](const long long f, auto cur) {
+    constexpr int CUR = decltype(cur)::value;
     const int par = (int)(f & 1);
     const int eff = (f + 1 < depth) ? (int)(f + 1) : depth;   // effdepth after this frame
+    RowScale rs{};
+    DbTable dt{};
+    if constexpr (MAP) {
+      // the column's levels and (logarithmic scales) its table of colour indices, ready before the
+      // frame's barrier; the buffer was last read two frames ago, before the barrier in between
+      const float *lv = ma.levels + (size_t)(f - ma.fbeg) * 4;
+#if GLFER_AVGMAP_ABL & 8
+      rs = row_scale(-20.0f + (float)f1 * 1e-9f, -80.0f);
+#else
+      rs = row_scale(lv[0], lv[1]);
+#endif
+      dt = db_table(rs, ma.thr255);
+#if GLFER_AVGMAP_ABL & 4
+      if (tid == 255) vtab_ok[par] = 1;
+      if (tid > 256) {
+#else
+      if (tid < 256) {
+#endif
+        bool above = false;
+        if (ma.scale_log) vtab[par][tid] = (unsigned char)colour_index((float)(short)(dt.l0 + tid), rs, ma.thr255, ma.one_m_thr, inv_one_m_thr, above);
+        if (tid == 255) vtab_ok[par] = ma.scale_log && dt.low_ok && above;
+      }
+    }
     const double init = (double)psd[(size_t)f * bins + minbin];
     double s = 0.0, mx = -1.0e300, mn = 1.0e300;
     int mi = 0x7fffffff;
     if constexpr (RING) {                                      // row f - depth leaves the sum, row f takes its slot
-      float *h = hist + ((size_t)(f % depth) * BPT) * 256 + tid;
+      float *h = hist + ((size_t)(f % depth) * BPT) * NT + tid;
 #pragma unroll
       for (int j = 0; j < BPT; j++)
-        if (b0 + 256 * j < maxbin) {
-          old[j] = h[256 * j];
-          h[256 * j] = v[j];
+        if (b0 + NT * j < maxbin) {
+          old[CUR][j] = h[NT * j];
+          h[NT * j] = v[CUR][j];
         }
     }
 #pragma unroll
     for (int j = 0; j < BPT; j++) {
-      if (b0 + 256 * j < maxbin) {
-        if (f < depth) cum[j] += (double)v[j];
-        else cum[j] += (double)v[j] - (double)old[j];
+      if (b0 + NT * j < maxbin) {
+        if (f < depth) cum[j] += (double)v[CUR][j];
+        else cum[j] += (double)v[CUR][j] - (double)old[CUR][j];
         const double c = cum[j];
         s += c;
-        if (c > mx) { mx = c; mi = b0 + 256 * j; }
+        if (c > mx) { mx = c; mi = b0 + NT * j; }
         if (c < mn) mn = c;
       }
     }
-    if (f + 1 < f1) fetch(f + 1);                              // in flight under the reduction
+    if (f + AHEAD < f1) fetch(f + AHEAD, cur);                 // into the buffer just read: in flight under this frame and the next
 #if !(GLFER_AVG_ABL & 2)
     wave_sum_max_min(s, mx, mi, mn);
 #endif
@@ -673,7 +777,7 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
     double r_sum = p_sum[par][0], r_max = p_max[par][0], r_min = p_min[par][0];
     int r_idx = p_idx[par][0];
 #pragma unroll
-    for (int w = 1; w < 4; w++) {
+    for (int w = 1; w < NW; w++) {
       r_sum += p_sum[par][w];
       if (p_max[par][w] > r_max || (p_max[par][w] == r_max && p_idx[par][w] < r_idx)) { r_max = p_max[par][w]; r_idx = p_idx[par][w]; }
       if (p_min[par][w] < r_min) r_min = p_min[par][w];
@@ -687,7 +791,17 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
     if (mode == 2) spec = (r_sum - top) / (span * (double)(eff + 1));   // avg.c:147
     else spec = (r_sum - top) / span;                                    // avg.c:199,260
 
-    double *row = avg + (size_t)f * n_out;
+    double *row = MAP ? nullptr : avg + (size_t)f * n_out;
+    unsigned *prow = pix + (size_t)par * n_out;
+    if constexpr (MAP) {
+      if (f > f0) emit(f - 1);                                 // every thread is past this frame's barrier: column f-1's words are complete
+    }
+    // one averaged bin: to the row, or kept for the mapping below (one copy of it for all the modes)
+    double outv[MAP ? BPT : 1];
+    auto put = [&](int j, int b, double val) {
+      if constexpr (MAP) outv[j] = val;
+      else GLFER_AVG_STORE(row[b], val);
+    };
     double var = 0.0;
     int cnt = 0;
     // the frame's divisors (the same in every lane); one loop per mode, so that a bin's code is its
@@ -696,21 +810,21 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
       const Divisor by_depth((double)(eff + 1));
 #pragma unroll
       for (int j = 0; j < BPT; j++) {
-        const int b = b0 + 256 * j;
-        if (b < maxbin) GLFER_AVG_STORE(row[b], by_depth(cum[j]));                        // avg.c:155
+        const int b = b0 + NT * j;
+        if (b < maxbin) put(j, b, by_depth(cum[j]));                        // avg.c:155
       }
     } else if (mode == 3) {
       const Divisor by_spec(spec), by_range(top - low);
 #pragma unroll
       for (int j = 0; j < BPT; j++) {
-        const int b = b0 + 256 * j;
-        if (b < maxbin) GLFER_AVG_STORE(row[b], max0 ? by_range(cum[j] - low) : by_spec(cum[j]));   // avg.c:209-212
+        const int b = b0 + NT * j;
+        if (b < maxbin) put(j, b, max0 ? by_range(cum[j] - low) : by_spec(cum[j]));   // avg.c:209-212
       }
     } else {
       const Divisor by_spec(spec), by_range(top - spec);
 #pragma unroll
       for (int j = 0; j < BPT; j++) {
-        const int b = b0 + 256 * j;
+        const int b = b0 + NT * j;
         if (b < maxbin) {
           const double c = cum[j];
           double out = 1e-15;
@@ -719,14 +833,47 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
             out = max0 ? by_range(c - spec) : q;
             if (b != peak) { var += q * q; cnt++; }
           }
-          GLFER_AVG_STORE(row[b], out);
+          put(j, b, out);
         }
       }
     }
     // the columns outside the band (avg.c:150-153): usually a few dozen
-    for (int b = tid; b < minbin; b += 256) row[b] = 1e-15;
-    for (int b = maxbin + tid; b < n_out; b += 256) row[b] = 1e-15;
-    if (mode == 1) {
+    if constexpr (MAP) {
+      auto map_column = [&](auto table) {
+        constexpr bool TABLE = decltype(table)::value;
+        auto word = [&](double val) {
+          short l;
+          unsigned vv;
+#if GLFER_AVGMAP_ABL & 2
+          return (unsigned)(long long)val;
+#endif
+          if constexpr (TABLE) {
+            float sf;
+            l = db_short<double>(val, 1, ma.log_thr, sf);
+            vv = vtab[par][db_table_slot(dt, l)];
+          } else {
+            map_bin<double>(val, ma.scale_log, rs, ma.thr255, ma.one_m_thr, inv_one_m_thr, ma.log_thr, l, vv);
+          }
+          return (vv << 16) | (unsigned)(unsigned short)l;
+        };
+#pragma unroll
+        for (int j = 0; j < BPT; j++) {
+          const int b = b0 + NT * j;
+          if (b < maxbin) prow[b] = word(outv[j]);
+        }
+        if (minbin > 0 || maxbin < n_out) {
+          const unsigned w = word(1e-15);
+          for (int b = tid; b < minbin; b += NT) prow[b] = w;
+          for (int b = maxbin + tid; b < n_out; b += NT) prow[b] = w;
+        }
+      };
+      if (vtab_ok[par]) map_column(std::true_type{});
+      else map_column(std::false_type{});
+    } else {
+      for (int b = tid; b < minbin; b += NT) row[b] = 1e-15;
+      for (int b = maxbin + tid; b < n_out; b += NT) row[b] = 1e-15;
+    }
+    if (mode == 1 && ret) {
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         var += __shfl_xor(var, o);
@@ -736,13 +883,29 @@ __global__ __launch_bounds__(256) void avg_fused_kernel(const float *__restrict_
       __syncthreads();
       var = (p_var[par][0] + p_var[par][1]) + (p_var[par][2] + p_var[par][3]);
       cnt = (p_cnt[par][0] + p_cnt[par][1]) + (p_cnt[par][2] + p_cnt[par][3]);
+      if constexpr (NW == 8) {
+        var += (p_var[par][4] + p_var[par][5]) + (p_var[par][6] + p_var[par][7]);
+        cnt += (p_cnt[par][4] + p_cnt[par][5]) + (p_cnt[par][6] + p_cnt[par][7]);
+      }
     }
-    if (tid == 0) {
+    if (tid == 0 && ret) {
       double *o = ret + (size_t)f * 4;
       o[0] = (mode == 2) ? spec : top / spec;                             // avg.c:158,218,297
       o[1] = (double)peak;
       o[2] = (mode == 1) ? var / (double)cnt : 0.0;                       // avg.c:294
       o[3] = (double)eff;
+    }
+  };
+  for (long long f = f0; f < f1; f += AHEAD) {
+    frame(f, std::integral_constant<int, 0>{});
+    if constexpr (AHEAD == 2) {
+      if (f + 1 < f1) frame(f + 1, std::integral_constant<int, 1>{});
+    }
+  }
+  if constexpr (MAP) {
+    if (f1 > f0) {
+      __syncthreads();
+      emit(f1 - 1);
     }
   }
 }
@@ -772,12 +935,8 @@ extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int b
 #undef GLFER_FLOOR_WAVE
   else {                                         // longer rows than any block size gives: one workgroup per row, the row in LDS
     const size_t shmem = (size_t)bins * sizeof(float) + 256 * sizeof(uint32_t);
-    static size_t allowed = 0;               // raised once per process and size class, not per launch
-    if (shmem > allowed) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(floor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      if (e != hipSuccess) return e;
-      allowed = shmem;
-    }
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(floor_kernel), shmem);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(floor_kernel, dim3((unsigned)nframes), dim3(256), shmem, st, psd, bins, m, stats);
   }
   return hipGetLastError();
@@ -805,8 +964,8 @@ extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframe
     const bool ring = ring_bytes <= 60 * 1024;                 // beside the kernel's static words, under the 64 KB limit
 #define GLFER_AVG_FUSED(B)                                                                                              \
   do {                                                                                                                  \
-    if (ring) hipLaunchKernelGGL((avg_fused_kernel<B, true>), dim3(blocks), dim3(256), ring_bytes, st, psd, nf, chunk, bins, n_out, depth, minbin, maxbin, mode, max0, avg, ret); \
-    else hipLaunchKernelGGL((avg_fused_kernel<B, false>), dim3(blocks), dim3(256), 0, st, psd, nf, chunk, bins, n_out, depth, minbin, maxbin, mode, max0, avg, ret); \
+    if (ring) hipLaunchKernelGGL((avg_fused_kernel<B, true, false>), dim3(blocks), dim3(256), ring_bytes, st, psd, nf, chunk, bins, n_out, depth, minbin, maxbin, mode, max0, avg, ret, AvgMapArgs{}); \
+    else hipLaunchKernelGGL((avg_fused_kernel<B, false, false>), dim3(blocks), dim3(256), 0, st, psd, nf, chunk, bins, n_out, depth, minbin, maxbin, mode, max0, avg, ret, AvgMapArgs{}); \
   } while (0)
     if (bpt <= 1) GLFER_AVG_FUSED(1);
     else if (bpt <= 2) GLFER_AVG_FUSED(2);
@@ -825,6 +984,80 @@ extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframe
                        mode, max0, avg, ret);
   }
 #undef GLFER_AVG_FUSED
+  return hipGetLastError();
+}
+
+// update_avg_* and the column mapping in one kernel (avg_fused_kernel<.., MAP>): frames [fbeg, nframes)
+// of the batch `psd` (the sums reach back before fbeg).  levels / rgb / lev are indexed from fbeg.
+// Returns hipErrorNotSupported where the fused form does not apply (very wide bands, windows much
+// deeper than a chunk, rows whose words do not fit LDS): the caller then runs the two stages.
+// 256 threads per block whatever the band: the kernel is bound by the instructions it issues (the
+// mapping is ~70 per bin, and ~400 per wavefront and frame do not depend on the bins at all --
+// reductions, divisors, the out-of-band word), so blocks of 512 threads on a 2049-bin row, meant to
+// halve the chain a frame is, came out SLOWER: 52 M rows/s against 66 for the whole waterfall
+// (GLFER_AVGMAP_WIDE=1 builds that form).
+#ifndef GLFER_AVGMAP_WIDE
+#define GLFER_AVGMAP_WIDE 0
+#endif
+struct AvgMapShape { int chunk, bpt, nt; bool ring; size_t shmem; bool ok; };
+static AvgMapShape avgmap_shape(long long walk, int bins, int depth, int minbin, int maxbin) {
+  AvgMapShape a{AVG_CHUNK, 0, 256, false, 0, false};
+  while (a.chunk > 8 && walk / a.chunk < 1024) a.chunk /= 2;
+  if (GLFER_AVGMAP_WIDE && maxbin - minbin >= 1024) a.nt = 512;
+  a.bpt = (maxbin - minbin + a.nt - 1) / a.nt;
+  const size_t pix_bytes = 2 * (size_t)bins * sizeof(unsigned);
+  const size_t ring_bytes = (size_t)depth * bpt_of(a.bpt) * a.nt * sizeof(float);
+  a.ring = pix_bytes + ring_bytes <= 76 * 1024;               // two blocks per CU
+  a.shmem = pix_bytes + (a.ring ? ring_bytes : 0);
+  a.ok = a.bpt >= 1 && a.bpt <= 33 && depth <= 2 * a.chunk && a.shmem <= 150 * 1024;
+  return a;
+}
+extern "C" int glfer_avgmap_applies(size_t walk, int bins, int depth, int minbin, int maxbin) {
+  return avgmap_shape((long long)walk, bins, depth, minbin, maxbin).ok ? 1 : 0;
+}
+
+extern "C" hipError_t glfer_launch_avgmap(int mode, const float *psd, size_t fbeg, size_t nframes, int bins, int depth,
+                                          int minbin, int maxbin, int max0, double *ret, int scale_log, double thr255,
+                                          double one_m_thr, const float *levels, const unsigned char *colortab,
+                                          const double *log_thr, unsigned char *rgb, short *lev, hipStream_t st) {
+  if (nframes <= fbeg) return hipSuccess;
+  const int band = maxbin - minbin;
+  if (band < 1 || minbin < 0 || maxbin > bins || depth < 1) return hipErrorInvalidValue;
+  const long long nf = (long long)nframes, walk = nf - (long long)fbeg;
+  const AvgMapShape shape = avgmap_shape(walk, bins, depth, minbin, maxbin);
+  if (!shape.ok) return hipErrorNotSupported;
+  const int chunk = shape.chunk, bpt = shape.bpt;
+  const bool ring = shape.ring;
+  const size_t shmem = shape.shmem;
+  const unsigned blocks = (unsigned)((walk + chunk - 1) / chunk);
+  const AvgMapArgs ma{levels, colortab, log_thr, rgb, lev, scale_log, thr255, one_m_thr, (long long)fbeg};
+#define GLFER_AVGMAP_NT(B, NT)                                                                                          \
+  do {                                                                                                                  \
+    const void *fn = ring ? reinterpret_cast<const void *>(avg_fused_kernel<B, true, true, NT>)                         \
+                          : reinterpret_cast<const void *>(avg_fused_kernel<B, false, true, NT>);                       \
+    hipError_t e = allow_dynamic_lds(fn, shmem);                                                                        \
+    if (e != hipSuccess) return e;                                                                                      \
+    if (ring) hipLaunchKernelGGL((avg_fused_kernel<B, true, true, NT>), dim3(blocks), dim3(NT), shmem, st, psd, nf, chunk, bins, bins, depth, minbin, maxbin, mode, max0, (double *)nullptr, ret, ma); \
+    else hipLaunchKernelGGL((avg_fused_kernel<B, false, true, NT>), dim3(blocks), dim3(NT), shmem, st, psd, nf, chunk, bins, bins, depth, minbin, maxbin, mode, max0, (double *)nullptr, ret, ma); \
+  } while (0)
+#if GLFER_AVGMAP_WIDE
+#define GLFER_AVGMAP(B)                                                                                                 \
+  do {                                                                                                                  \
+    if (shape.nt == 512) GLFER_AVGMAP_NT(B, 512);                                                                       \
+    else GLFER_AVGMAP_NT(B, 256);                                                                                       \
+  } while (0)
+#else
+#define GLFER_AVGMAP(B) GLFER_AVGMAP_NT(B, 256)
+#endif
+  if (bpt <= 1) GLFER_AVGMAP(1);
+  else if (bpt <= 2) GLFER_AVGMAP(2);
+  else if (bpt <= 3) GLFER_AVGMAP(3);
+  else if (bpt <= 5) GLFER_AVGMAP(5);
+  else if (bpt <= 9) GLFER_AVGMAP(9);
+  else if (bpt <= 17) GLFER_AVGMAP(17);
+  else GLFER_AVGMAP(33);
+#undef GLFER_AVGMAP_NT
+#undef GLFER_AVGMAP
   return hipGetLastError();
 }
 

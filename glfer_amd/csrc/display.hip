@@ -10,19 +10,11 @@
 // Built with -ffp-contract=off: the reference's float/double expression order is the contract.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
-#ifndef GLFER_MAP_GUARD
-#define GLFER_MAP_GUARD 2.5e-4f    /* the float logarithm is within 8e-5 of 10 log10 x (1 ulp of v_log_f32 at |log2 x| <= 128, the product, the constant) */
-#endif
+#include "display_map.hpp"
 
 namespace glfer {
-
-// double -> int32 the way the reference's implicit double->short / double->unsigned char
-// conversions behave on x86-64 (cvttsd2si: out of range or NaN gives INT_MIN; low bits kept)
-__device__ __forceinline__ int x86_d2i(double d) {
-  if (!(d > -2147483649.0 && d < 2147483648.0)) return (int)0x80000000u;
-  return (int)d;
-}
 
 struct LevelsParams {
   int scale_log, autoscale, first_buffer;
@@ -204,70 +196,6 @@ __global__ __launch_bounds__(256) void levels_fixed_kernel(long long nframes, fl
   }
 }
 
-// One bin of one column: the dB short and the 0..255 colour index (g_main.c:1186-1226).
-//   levbuf = (short)(10 log10 x)  [double log10, truncated]       colour = (uchar)((f - thr255) / one_m_thr)
-// Both truncate a double: the value only matters next to an integer.  So the logarithm is taken in
-// float (v_log_f32: error < 1e-4 over |y| <= 400) and a result further than GLFER_MAP_GUARD from an
-// integer is truncated as it is; a result inside the guard band (0.05 % of the bins; a wavefront
-// takes the branch when ANY of its lanes does, 3 % of the time -- with the 2e-3 band and a double
-// log10 behind it, round 1's form, that was 23 % and a third of the kernel) is decided by ONE comparison with the
-// point where the reference's own 10.0*log10(x) crosses that integer (log_thr: host_tables.cpp
-// log_thresholds(), built with the host libm the reference itself would run on), not by a double
-// log10 on the device.  The quotient is a product with the reciprocal, recomputed the reference's
-// way only within 1e-9 of an integer (a few double ulp of at most 255).  Same integers as the
-// all-double form, at a fraction of the instructions.
-constexpr int kLogThrK = 400;                              // host_tables.h
-struct RowScale {                                          // per column: display_min and 1/(display_max - display_min)
-  float display_min, span, inv_span;
-  bool fast;                                               // the reciprocal form of x / span is exact (see fdiv)
-};
-// a / span, correctly rounded, for many a and one span: y = RN(1/span), q0 = RN(a y),
-// r = a - span q0 (exact in an fma), RN(q0 + r y) = RN(a / span) (Markstein) while nothing over- or
-// underflows: |span| and |a| within 2^-60 .. 2^59; anything else (0 included) takes the division.
-__device__ __forceinline__ float fdiv(float a, const RowScale &rs) {
-  const unsigned e = (__float_as_uint(a) >> 23) & 0xffu;   // biased exponent
-  if (rs.fast && e - 67u < 120u) {
-    const float q0 = a * rs.inv_span;
-    const float r = __builtin_fmaf(-rs.span, q0, a);
-    return __builtin_fmaf(r, rs.inv_span, q0);
-  }
-  return a / rs.span;
-}
-
-template <typename SRC>
-__device__ __forceinline__ void map_bin(SRC s, int scale_log, const RowScale &rs, double thr255,
-                                        double one_m_thr, double inv_one_m_thr, const double *__restrict__ log_thr,
-                                        short &l, unsigned &v) {
-  const float sf = (float)s;                               // the linear scale maps (float)s, and logs that
-  const double sd = scale_log ? (double)s : (double)sf;
-  const float y = __builtin_amdgcn_logf(sf) * 3.010299956639812f;         // 10 log10 = log2 * 10 log10(2)
-  const float yr = __builtin_rintf(y);
-  int li;
-  if (sf > 1e-37f && sf < 3e38f) {                         // normal floats (a double source rounded to float moves y by 3e-7)
-    if (__builtin_fabsf(y - yr) > GLFER_MAP_GUARD) {
-      li = (int)y;
-    } else {                                               // 10 log10(sd) is within the guard band of k: k, or the integer before it
-      const int k = (int)yr;
-      const double t = log_thr[kLogThrK + k];
-      li = k > 0 ? (sd >= t ? k : k - 1) : (k < 0 ? (sd <= t ? k : k + 1) : 0);
-    }
-  } else {
-    li = x86_d2i(10.0 * log10(sd));
-  }
-  l = (short)li;
-  const float sig_level = scale_log ? (float)l : sf;
-  const float f = 255.0f * fdiv(sig_level - rs.display_min, rs);
-  if ((double)f < thr255) {
-    v = 0;
-  } else if (f > 255.0f) {
-    v = 255;
-  } else {
-    const double num = (double)f - thr255, q = num * inv_one_m_thr;
-    const int qi = (__builtin_fabs(q - __builtin_rint(q)) > 1e-9) ? (int)q : x86_d2i(num / one_m_thr);
-    v = (unsigned)qi & 0xffu;                              // (unsigned char) of the conversion
-  }
-}
-
 // One block per column.  A thread maps FOUR consecutive pixels: the 12 RGB bytes and the 4 shorts go
 // out as one 12-byte and one 8-byte store (byte-aligned: rows of 3n bytes start anywhere; gfx950 runs
 // with unaligned global access enabled and the compiler emits dwordx3/dwordx2 for it), instead of
@@ -279,53 +207,67 @@ __global__ __launch_bounds__(256) void map_kernel(const SRC *__restrict__ src, i
                                                   const unsigned char *__restrict__ colortab,
                                                   const double *__restrict__ log_thr,
                                                   unsigned char *__restrict__ rgb, short *__restrict__ lev) {
-  __shared__ unsigned tab[256];
-  {
-    const int c = threadIdx.x;
-    tab[c] = (unsigned)colortab[3 * c] | ((unsigned)colortab[3 * c + 1] << 8) | ((unsigned)colortab[3 * c + 2] << 16);
-  }
-  __syncthreads();
+  __shared__ unsigned tab[256];      // palette: colour index -> RGB dword
+  __shared__ unsigned ctab[256];     // logarithmic scales: dB short l0 + i -> RGB dword (display_map.hpp, DbTable)
+  __shared__ int table_ok;
+  const int c0 = threadIdx.x;
+  auto rgb_of = [&](unsigned v) {
+    return (unsigned)colortab[3 * v] | ((unsigned)colortab[3 * v + 1] << 8) | ((unsigned)colortab[3 * v + 2] << 16);
+  };
+  tab[c0] = rgb_of(c0);
   const size_t fr = blockIdx.x;
   const SRC *row = src + fr * (size_t)n;
   const float display_max = levels[fr * 4 + 0];
   const float display_min = levels[fr * 4 + 1];
-  RowScale rs;
-  rs.display_min = display_min;
-  rs.span = display_max - display_min;
-  rs.inv_span = 1.0f / rs.span;
-  {
-    const unsigned e = (__float_as_uint(rs.span) >> 23) & 0xffu;
-    rs.fast = e - 67u < 120u;
-  }
+  const RowScale rs = row_scale(display_max, display_min);
   const double inv = 1.0 / one_m_thr;
+  const DbTable dt = db_table(rs, thr255);
+  if (scale_log) {
+    bool above;
+    ctab[c0] = rgb_of(colour_index((float)(short)(dt.l0 + c0), rs, thr255, one_m_thr, inv, above));
+    if (c0 == 255) table_ok = dt.low_ok && above;
+  } else if (c0 == 255) {
+    table_ok = 0;
+  }
+  __syncthreads();
   unsigned char *orow = rgb + fr * (size_t)n * 3;
   short *lrow = lev ? lev + fr * (size_t)n : nullptr;
   const int n4 = n & ~3;
-  for (int i = 4 * (int)threadIdx.x; i < n4; i += 4 * 256) {         // pixels i..i+3 <- bins n-1-i .. n-4-i
-    SRC q[4];
-    __builtin_memcpy(q, row + (n - 4 - i), sizeof q);
-    short l[4];
-    unsigned c[4];
+  auto columns = [&](auto by_table) {
+    constexpr bool TABLE = decltype(by_table)::value;
+    auto pixel = [&](SRC q, short &l) -> unsigned {
+      if constexpr (TABLE) {
+        float sf;
+        l = db_short<SRC>(q, 1, log_thr, sf);
+        return ctab[db_table_slot(dt, l)];
+      } else {
+        unsigned v;
+        map_bin<SRC>(q, scale_log, rs, thr255, one_m_thr, inv, log_thr, l, v);
+        return tab[v];
+      }
+    };
+    for (int i = 4 * (int)threadIdx.x; i < n4; i += 4 * 256) {         // pixels i..i+3 <- bins n-1-i .. n-4-i
+      SRC q[4];
+      __builtin_memcpy(q, row + (n - 4 - i), sizeof q);
+      short l[4];
+      unsigned c[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      unsigned v;
-      map_bin<SRC>(q[3 - u], scale_log, rs, thr255, one_m_thr, inv, log_thr, l[u], v);
-      c[u] = tab[v];
+      for (int u = 0; u < 4; u++) c[u] = pixel(q[3 - u], l[u]);
+      const unsigned w[3] = {c[0] | (c[1] << 24), (c[1] >> 8) | (c[2] << 16), (c[2] >> 16) | (c[3] << 8)};
+      __builtin_memcpy(orow + 3 * (size_t)i, w, 12);
+      if (lrow) __builtin_memcpy(lrow + i, l, 8);
     }
-    const unsigned w[3] = {c[0] | (c[1] << 24), (c[1] >> 8) | (c[2] << 16), (c[2] >> 16) | (c[3] << 8)};
-    __builtin_memcpy(orow + 3 * (size_t)i, w, 12);
-    if (lrow) __builtin_memcpy(lrow + i, l, 8);
-  }
-  for (int i = n4 + (int)threadIdx.x; i < n; i += 256) {              // the last n mod 4 pixels
-    short l;
-    unsigned v;
-    map_bin<SRC>(row[n - i - 1], scale_log, rs, thr255, one_m_thr, inv, log_thr, l, v);
-    const unsigned c = tab[v];
-    orow[3 * i] = (unsigned char)c;
-    orow[3 * i + 1] = (unsigned char)(c >> 8);
-    orow[3 * i + 2] = (unsigned char)(c >> 16);
-    if (lrow) lrow[i] = l;
-  }
+    for (int i = n4 + (int)threadIdx.x; i < n; i += 256) {              // the last n mod 4 pixels
+      short l;
+      const unsigned c = pixel(row[n - i - 1], l);
+      orow[3 * i] = (unsigned char)c;
+      orow[3 * i + 1] = (unsigned char)(c >> 8);
+      orow[3 * i + 2] = (unsigned char)(c >> 16);
+      if (lrow) lrow[i] = l;
+    }
+  };
+  if (table_ok) columns(std::true_type{});
+  else columns(std::false_type{});
 }
 
 }  // namespace glfer

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 
@@ -26,6 +27,11 @@ extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int b
 extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframes, int bins, int n_out,
                                        int depth, int minbin, int maxbin, int max0, double *avg,
                                        double *ret, hipStream_t st);
+extern "C" int glfer_avgmap_applies(size_t walk, int bins, int depth, int minbin, int maxbin);
+extern "C" hipError_t glfer_launch_avgmap(int mode, const float *psd, size_t fbeg, size_t nframes, int bins, int depth,
+                                          int minbin, int maxbin, int max0, double *ret, int scale_log, double thr255,
+                                          double one_m_thr, const float *levels, const unsigned char *colortab,
+                                          const double *log_thr, unsigned char *rgb, short *lev, hipStream_t st);
 extern "C" hipError_t glfer_launch_avg_cum(const float *psd, size_t nframes, int bins, int n_out, int depth,
                                            int minbin, int maxbin, double *cum, hipStream_t st);
 extern "C" hipError_t glfer_launch_lmp(const float *rows, long long row0, long long first, size_t nframes, int bins,
@@ -76,6 +82,23 @@ hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st) {
   return hipMallocAsync(p, bytes, st);
 }
 
+// Dynamic LDS above the default limit has to be allowed per kernel -- and per DEVICE: a process that
+// drives several GPUs (glfer_hip_spectrogram_host_multi) launches the same kernel on each.  One call
+// per (device, kernel) and size class, not one per launch.
+hipError_t allow_dynamic_lds(const void *kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, size_t> allowed;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t &have = allowed[{dev, kernel}];
+  if (bytes <= have) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
+
 }  // namespace glfer
 using glfer::DeviceGuard;
 using glfer::hip_fail;
@@ -109,11 +132,23 @@ int glfer_hip_palette(int palette, unsigned char colortab[768]) {
   return GLFER_OK;
 }
 
-int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const double *d_avg, const float *d_stats,
-                             size_t nframes, int bins, unsigned char *d_rgb, short *d_lev, float *d_levels,
-                             void *hip_stream) {
+}  // extern "C"
+
+// update_avg_* inside the mapping (avg_fused_kernel<.., MAP>): the PSD batch the columns belong to,
+// their first row in it, and update_avg's arguments
+struct MapAverages {
+  int mode, depth, minbin, maxbin, max0;
+  const float *d_batch;
+  size_t first;
+};
+
+// The mapping part of main_window_draw for `nframes` columns: level tracking, then the pixel map of the
+// PSD rows, of averaged rows, or (fused) of the averages taken on the way.
+static int display_columns(glfer_hip_display *d, const float *d_psd, const double *d_avg, const MapAverages *fused,
+                           const float *d_stats, size_t nframes, int bins, unsigned char *d_rgb, short *d_lev,
+                           float *d_levels, void *hip_stream) {
   if (!d || !d_stats || !d_rgb || bins < 1) return GLFER_E_ARG;
-  if ((d_psd == nullptr) == (d_avg == nullptr)) return GLFER_E_ARG;
+  if ((d_psd != nullptr) + (d_avg != nullptr) + (fused != nullptr) != 1) return GLFER_E_ARG;
   if (d->scale_type < GLFER_SCALE_LIN || d->scale_type > GLFER_SCALE_LOG_MAX0) return GLFER_E_ARG;
   if (nframes == 0) return GLFER_OK;
   hipStream_t st = (hipStream_t)hip_stream;
@@ -157,8 +192,13 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
   }
   if (rc == GLFER_OK) {
     const float thr_level = d->thr_level / 100.0;                              // g_main.c:1099
-    e = glfer_launch_map(d_psd, d_avg, nframes, bins, scale_log, 255.0 * thr_level, 1.0 - thr_level, levels,
-                         d_tab, d_thr, d_rgb, d_lev, st);
+    if (fused)
+      e = glfer_launch_avgmap(fused->mode, fused->d_batch, fused->first, fused->first + nframes, bins, fused->depth,
+                              fused->minbin, fused->maxbin, fused->max0, nullptr, scale_log, 255.0 * thr_level,
+                              1.0 - thr_level, levels, d_tab, d_thr, d_rgb, d_lev, st);
+    else
+      e = glfer_launch_map(d_psd, d_avg, nframes, bins, scale_log, 255.0 * thr_level, 1.0 - thr_level, levels,
+                           d_tab, d_thr, d_rgb, d_lev, st);
     if (e != hipSuccess) fail(e);
   }
   float last[4] = {0, 0, 0, 0};
@@ -175,6 +215,15 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
     if (d->autoscale) d->first_buffer = 0;                                     // g_main.c:1120
   }
   return rc;
+}
+
+extern "C" {
+
+int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const double *d_avg, const float *d_stats,
+                             size_t nframes, int bins, unsigned char *d_rgb, short *d_lev, float *d_levels,
+                             void *hip_stream) {
+  if ((d_psd == nullptr) == (d_avg == nullptr)) return GLFER_E_ARG;
+  return display_columns(d, d_psd, d_avg, nullptr, d_stats, nframes, bins, d_rgb, d_lev, d_levels, hip_stream);
 }
 
 // compute_floor + update_avg_* + the display mapping of main_window_draw (g_main.c:1109-1236) for a
@@ -200,21 +249,26 @@ int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, in
   HIP_TRY(guard.error());
   // Tiles only bound the scratch: the level walk costs its ~0.13 ms of latency per display call
   // however few columns it gets, so fewer, larger tiles are faster (two 65536-row tiles: 116 M rows/s
-  // against 147 M stage by stage).  Averaged rows are 8 B per bin: 4 GiB of them per tile; without
-  // averaging only the 16 B of statistics per row are scratch.
-  size_t tile = averaging ? std::max<size_t>(16384, ((size_t)4 << 30) / ((size_t)bins * sizeof(double))) : (size_t)1 << 22;
+  // against 147 M stage by stage).  The averages are taken inside the mapping kernel where that form
+  // applies (no averaged rows in memory at all: GLFER_WATERFALL_FUSED=0 forces the staged form, for
+  // A/B runs and tests); staged, averaged rows are 8 B per bin: 4 GiB of them per tile.  Otherwise
+  // only the 16 B of statistics per row are scratch.
+  bool fused = averaging;
+  if (const char *e = getenv("GLFER_WATERFALL_FUSED")) fused = fused && atoi(e) != 0;
+  size_t tile = (averaging && !fused) ? std::max<size_t>(16384, ((size_t)4 << 30) / ((size_t)bins * sizeof(double))) : (size_t)1 << 22;
   if (const char *e = getenv("GLFER_WATERFALL_TILE")) {    // rows per tile, for tests of the tile seams and for tuning
     const long v = atol(e);
     if (v >= 64) tile = (size_t)v;
   }
   tile = std::min(tile, nframes);
   tile = (nframes + (nframes + tile - 1) / tile - 1) / ((nframes + tile - 1) / tile);   // equal tiles: no short last one
+  if (fused) fused = glfer_avgmap_applies(tile, bins, depth, minbin, maxbin) != 0;
   const size_t back = averaging ? (size_t)depth : 0;       // rows re-read in front of a tile to restart the sliding sums
   float *stats = d_stats;
   double *avg = nullptr, *ret = nullptr;
   if (!stats) HIP_TRY(glfer::scratch_malloc((void **)&stats, tile * 4 * sizeof(float), st));
   int rc = GLFER_OK;
-  if (averaging) {
+  if (averaging && !fused) {
     hipError_t e = glfer::scratch_malloc((void **)&avg, (tile + back) * (size_t)bins * sizeof(double), st);
     if (e == hipSuccess) e = glfer::scratch_malloc((void **)&ret, (tile + back) * 4 * sizeof(double), st);
     if (e != hipSuccess) rc = hip_fail(e, "hipMallocAsync(waterfall tile)");
@@ -222,9 +276,18 @@ int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, in
   for (size_t f0 = 0; rc == GLFER_OK && f0 < nframes; f0 += tile) {
     const size_t nf = std::min(tile, nframes - f0);
     float *tstats = d_stats ? d_stats + f0 * 4 : stats;
+    unsigned char *trgb = d_rgb + f0 * (size_t)bins * 3;
+    short *tlev = d_lev ? d_lev + f0 * (size_t)bins : nullptr;
     rc = glfer_hip_floor_device(d_psd + f0 * (size_t)bins, nf, bins, tstats, st);
+    if (rc != GLFER_OK) break;
+    if (fused) {
+      // the sliding sums of the tile's first rows reach back into the rows before it by themselves
+      const MapAverages ma{avg_mode, depth, minbin, maxbin, max0 ? 1 : 0, d_psd, f0};
+      rc = display_columns(d, nullptr, nullptr, &ma, tstats, nf, bins, trgb, tlev, nullptr, st);
+      continue;
+    }
     const double *src_avg = nullptr;
-    if (rc == GLFER_OK && averaging) {
+    if (averaging) {
       // the sums of the tile's first rows reach `depth` rows back: run from there (from an empty
       // state at row 0 of the batch, as update_avg does after alloc_avg) and use the tile's rows
       const size_t lead = std::min(back, f0);
@@ -233,8 +296,8 @@ int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, in
       src_avg = avg + lead * (size_t)bins;
     }
     if (rc == GLFER_OK)
-      rc = glfer_hip_display_device(d, averaging ? nullptr : d_psd + f0 * (size_t)bins, src_avg, tstats, nf, bins,
-                                    d_rgb + f0 * (size_t)bins * 3, d_lev ? d_lev + f0 * (size_t)bins : nullptr, nullptr, st);
+      rc = display_columns(d, averaging ? nullptr : d_psd + f0 * (size_t)bins, src_avg, nullptr, tstats, nf, bins, trgb, tlev,
+                           nullptr, st);
   }
   if (avg) (void)hipFreeAsync(avg, st);
   if (ret) (void)hipFreeAsync(ret, st);

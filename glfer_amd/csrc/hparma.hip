@@ -16,6 +16,10 @@
 #include "spectro_params.h"
 
 namespace glfer {
+hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);   // plan.h / glfer_hip.cpp: once per device, kernel and size class
+}
+
+namespace glfer {
 
 // sum of v over the 64 lanes, result in every lane
 __device__ __forceinline__ double wave_sum(double v) {
@@ -299,15 +303,15 @@ extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t,
   hipError_t e = hipSuccess;
   switch (sp->fmt) {
     case GLFER_FMT_F32:
-      e = hipFuncSetAttribute((const void *)hparma_kernel<GLFER_FMT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      e = glfer::allow_dynamic_lds((const void *)hparma_kernel<GLFER_FMT_F32>, shmem);
       if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<GLFER_FMT_F32>), dim3(grid), dim3(64), shmem, st, hp);
       break;
     case GLFER_FMT_S16:
-      e = hipFuncSetAttribute((const void *)hparma_kernel<GLFER_FMT_S16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      e = glfer::allow_dynamic_lds((const void *)hparma_kernel<GLFER_FMT_S16>, shmem);
       if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<GLFER_FMT_S16>), dim3(grid), dim3(64), shmem, st, hp);
       break;
     case GLFER_FMT_U8:
-      e = hipFuncSetAttribute((const void *)hparma_kernel<GLFER_FMT_U8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      e = glfer::allow_dynamic_lds((const void *)hparma_kernel<GLFER_FMT_U8>, shmem);
       if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<GLFER_FMT_U8>), dim3(grid), dim3(64), shmem, st, hp);
       break;
     default: return hipErrorInvalidValue;

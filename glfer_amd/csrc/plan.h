@@ -46,6 +46,10 @@ int device_of(const void *d_ptr);
 // for the mapping every time.
 hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st);
 
+// Allow `bytes` of dynamic LDS for `kernel` on the current device (hipFuncSetAttribute, once per
+// device, kernel and size class).
+hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);
+
 }  // namespace glfer
 
 #define HIP_TRY(call)                                          \

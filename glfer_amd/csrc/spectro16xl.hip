@@ -19,6 +19,10 @@
 #include "odd_taper.hpp"
 
 namespace glfer {
+hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);   // plan.h / glfer_hip.cpp: once per device, kernel and size class
+}
+
+namespace glfer {
 
 template <int LOGN>
 struct LaunchXL {
@@ -258,7 +262,7 @@ static hipError_t launch16xl_fmt(const SpectroParams &p, hipStream_t st) {
       return hipErrorInvalidValue;
     }
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipError_t e = glfer::allow_dynamic_lds(reinterpret_cast<const void *>(kern), shmem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, st, p);
   return hipGetLastError();

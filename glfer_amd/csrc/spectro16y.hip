@@ -23,6 +23,8 @@
 
 namespace glfer {
 
+hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);   // plan.h / glfer_hip.cpp: once per device, kernel and size class
+
 struct LaunchY {
   static constexpr int N = 4096, T = 256, PADN = N + N / 16;
   static constexpr int LDS_WORDS = 2 * PADN + 16 * 17 + 4;       // two exchange buffers, pass-1 twiddles, power partials
@@ -309,24 +311,17 @@ static hipError_t launch16y_fmt(const SpectroParams &p, hipStream_t st) {
   unsigned grid = (unsigned)(work < 16 * resident ? work : 16 * resident);   // tools/xbench: 16x beats 4x by ~2 %
   if (grid >= 64) grid &= ~7u;                       // whole XCD slices: see xcd_block_index()
   constexpr size_t shmem = (size_t)LaunchY::LDS_WORDS * 8;
-  static bool raised = false;                        // once per process and format, not per launch
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(spectro16y_kernel<FMT, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(spectro16y_kernel<FMT, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  {
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(p.history_mode ? spectro16y_kernel<FMT, 0, 1> : spectro16y_kernel<FMT, 0, 0>), shmem);
     if (e != hipSuccess) return e;
-    raised = true;
   }
   if (p.mean_inkernel) {
     if (p.history_mode) return hipErrorInvalidValue;
     const int km = p.H % 256 == 0 ? p.H / 256 : 0;
 #define GLFER_Y_MEAN(K)                                                                                              \
   do {                                                                                                               \
-    static bool up = false;                                                                                          \
-    if (!up) {                                                                                                       \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(spectro16y_kernel<FMT, 0, 0, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-      if (e != hipSuccess) return e;                                                                                 \
-      up = true;                                                                                                     \
-    }                                                                                                                \
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(spectro16y_kernel<FMT, 0, 0, K>), shmem);       \
+    if (e != hipSuccess) return e;                                                                                   \
     hipLaunchKernelGGL((spectro16y_kernel<FMT, 0, 0, K>), dim3(grid), dim3(256), shmem, st, p);                     \
     return hipGetLastError();                                                                                        \
   } while (0)

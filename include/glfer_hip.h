@@ -304,13 +304,17 @@ int glfer_hip_display_device(glfer_hip_display *disp, const float *d_psd, const 
                              short *d_lev, float *d_levels, void *hip_stream);
 
 /* compute_floor + update_avg_* + the mapping for a batch of PSD rows in one call (statistics,
- * [moving average], level tracking, pixel map; averaged rows are scratch, at most 4 GiB at a time:
- * the batch is walked in tiles of that many rows, GLFER_WATERFALL_TILE=<rows> overrides).  A single
- * pass over a row is not possible: the level tracking is a chain over the columns fed by every
- * column's statistics, so a row is read once for those and once to be mapped.  avg_mode 0 =
- * NO_AVG (the PSD rows are mapped), else GLFER_AVG_* with depth/minbin/maxbin/max0 as
- * glfer_hip_avg_device (the state starts empty at row 0).  d_stats: [nframes][4] or NULL.
- * disp carries the level-tracking state in and out; the call synchronises the stream per tile. */
+ * level tracking, [moving average +] pixel map).  A single pass over a row is not possible: the level
+ * tracking is a chain over the columns fed by every column's statistics, so a row is read once for
+ * those and once to be mapped.  With averaging the averages are taken INSIDE the mapping kernel (the
+ * levels come from compute_floor of the PSD rows, g_main.c:1109-1139, not from the average): no
+ * averaged rows in memory at all.  Where that kernel does not apply (bands wider than 33 x 256 bins,
+ * windows much deeper than its frame chunks; or GLFER_WATERFALL_FUSED=0) the averaged rows are scratch,
+ * at most 4 GiB at a time, and the batch is walked in tiles of that many rows
+ * (GLFER_WATERFALL_TILE=<rows> overrides).  avg_mode 0 = NO_AVG (the PSD rows are mapped), else
+ * GLFER_AVG_* with depth/minbin/maxbin/max0 as glfer_hip_avg_device (the state starts empty at row
+ * 0).  d_stats: [nframes][4] or NULL.  disp carries the level-tracking state in and out; the call
+ * synchronises the stream per tile. */
 int glfer_hip_waterfall_device(glfer_hip_display *disp, int avg_mode, int depth, int minbin, int maxbin,
                                int max0, const float *d_psd, size_t nframes, int bins,
                                unsigned char *d_rgb, short *d_lev, float *d_stats, void *hip_stream);

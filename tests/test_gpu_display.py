@@ -196,3 +196,33 @@ def test_waterfall_end_to_end(lib, oracle, torch_cuda):
     assert np.count_nonzero((lev != w_lev) & strong) <= 1e-2 * np.count_nonzero(strong)
     # colour index moves by at most one whole dB's worth: 255/(display span in dB) + rounding
     assert np.count_nonzero((rgb.cpu().numpy() != w_rgb).any(axis=2) & (lev == w_lev)) <= 1e-3 * lev.size
+
+
+@pytest.mark.parametrize("max_db,min_db,thr", [(0.0, -100.0, 0.0), (-5.5, -60.25, 7.0), (0.0, -253.0, 0.0), (0.0, -254.0, 0.0),
+                                               (0.0, -255.0, 2.0), (10.0, -300.0, 0.0), (-20.0, -21.0, 0.0), (-20.0, -20.5, 50.0),
+                                               (-30.0, -10.0, 0.0), (-30.0, -30.0, 0.0), (120.0, -120.0, 99.0)])
+def test_log_scale_colour_table_edges(lib, oracle, torch_cuda, max_db, min_db, thr):
+    """On the logarithmic scales a column's colours come from a table over 256 whole-dB levels from
+    floor(display_min) - 1 on, valid when its last entry is past display_max; wider spans, reversed
+    or equal levels map bin by bin.  Fixed levels (exact on both sides), spans of 1/2 dB, 253, 254,
+    255 and 300 dB, fractional levels, thresholds, max < min (the reference then uses max/10) and
+    max == min; bins over the whole float range and ON the whole-dB steps; float rows and
+    averaged (double) rows; pixels and levbuf must be identical."""
+    rng = np.random.default_rng(int(abs(max_db) * 7 + abs(min_db)))
+    rows, n = 16, 1027
+    psd = (10.0 ** rng.uniform(-37, 38, (rows, n))).astype(np.float32)
+    ks = np.arange(-370, 381)
+    psd.reshape(-1)[rng.permutation(rows * n)[: ks.size]] = (10.0 ** (ks / 10.0)).astype(np.float32)
+    psd[3, :5] = [0.0, 1e-45, np.inf, np.nan, 3e38]
+    stats = np.array([oracle.floor_stats(r) for r in psd], np.float32)
+    avg = psd.astype(np.float64) * 1.0000001
+    avg[5, :4] = [1e-300, 1e300, 1e-15, 1e-15]
+    for scale_type in (lib.SCALE_LOG, lib.SCALE_LOG_MAX0):
+        for src in (psd, avg):
+            d = lib.Display(palette=1, scale_type=scale_type, autoscale=0, max_level_db=max_db, min_level_db=min_db, thr_level=thr)
+            rgb, lev, levels = lib.display(d, torch_cuda.from_numpy(src).cuda(), torch_cuda.from_numpy(stats).cuda())
+            w_rgb, w_lev, w_levels, _ = oracle.display(src, stats, palette_id=1, scale_log=True, autoscale=False, max_level_db=max_db,
+                                                       min_level_db=min_db, thr_level=thr)
+            assert np.array_equal(levels.cpu().numpy()[:, :2], w_levels)
+            assert np.array_equal(lev.cpu().numpy(), w_lev), src.dtype
+            assert np.array_equal(rgb.cpu().numpy(), w_rgb), src.dtype

@@ -749,3 +749,73 @@ def test_per_column_stages_at_n32768(lib, oracle, torch_cuda):
     rgb, lev, _ = lib.display(d, psd, lib.compute_floor(psd))
     rgb_w, lev_w, _, _ = oracle.display(rows, stats, palette_id=3, scale_log=True, autoscale=True, overlap=0.0)
     assert np.array_equal(rgb.cpu().numpy(), rgb_w) and np.array_equal(lev.cpu().numpy(), lev_w)
+
+
+@pytest.mark.parametrize("bins,minbin,maxbin,depth", [(513, 25, 500, 4), (129, 0, 129, 1), (2049, 0, 2049, 4), (2049, 30, 1999, 11),
+                                                      (8193, 100, 8100, 6), (1025, 0, 1024, 40)])
+def test_waterfall_averages_inside_the_map_kernel(lib, torch_cuda, bins, minbin, maxbin, depth):
+    """update_avg_* taken inside the mapping kernel (no averaged rows in memory) against the staged
+    form of the same entry (GLFER_WATERFALL_FUSED=0: update_avg rows, then the map): identical
+    pixels, levbuf and carried state in every averaging mode and both normalisations, with bands
+    that do and do not reach the row's ends, windows shorter and longer than a chunk restart, LDS
+    ring and memory re-read forms (depth 40 at 1025 bins exceeds the ring), and across tile seams."""
+    torch = torch_cuda
+    rows = 3000 if bins > 4096 else 9000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(bins + depth)
+    psd = (torch.rand((rows, bins), device="cuda", generator=g) ** 4 * 1e-3 + 1e-9).contiguous()
+    psd[rows // 3, minbin + (maxbin - minbin) // 3] = 0.7
+    saved = {k: os.environ.get(k) for k in ("GLFER_WATERFALL_FUSED", "GLFER_WATERFALL_TILE")}
+    try:
+        for kw in (dict(scale_type=lib.SCALE_LOG, autoscale=1, overlap=0.5, palette=0),
+                   dict(scale_type=lib.SCALE_LIN, autoscale=1, overlap=0.0, palette=3),
+                   dict(scale_type=lib.SCALE_LOG_MAX0, autoscale=0, max_level_db=0.0, min_level_db=-60.0, thr_level=10.0, palette=5)):
+            for avg_mode in (lib.AVG_PLAIN, lib.AVG_SUMEXTREME, lib.AVG_SUMAVG):
+                for max0 in (0, 1):
+                    out = {}
+                    for fused, tile in (("0", None), ("1", None), ("1", str(rows // 3 + 7))):
+                        os.environ["GLFER_WATERFALL_FUSED"] = fused
+                        if tile:
+                            os.environ["GLFER_WATERFALL_TILE"] = tile
+                        else:
+                            os.environ.pop("GLFER_WATERFALL_TILE", None)
+                        d = lib.Display(**kw)
+                        rgb, lev, _ = lib.waterfall(d, psd, avg_mode=avg_mode, depth=depth, minbin=minbin, maxbin=maxbin, max0=max0,
+                                                    want_stats=True)
+                        out[(fused, tile)] = (rgb, lev, (d.first_buffer, d.display_max_lvl, d.display_min_lvl))
+                    want = out[("0", None)]
+                    got = out[("1", None)]
+                    assert got[2] == want[2]
+                    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (kw["scale_type"], avg_mode, max0)
+                    tiled = out[("1", str(rows // 3 + 7))]
+                    assert tiled[2] == want[2]
+                    if avg_mode == lib.AVG_PLAIN:
+                        assert torch.equal(tiled[0], want[0]) and torch.equal(tiled[1], want[1])
+                    else:   # the chunk restarts fall elsewhere: band statistics differ by ulps in a few columns
+                        assert (tiled[0] != want[0]).float().mean().item() < 1e-4 and (tiled[1] != want[1]).float().mean().item() < 1e-4
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_waterfall_plain_average_against_the_oracle(lib, oracle, torch_cuda):
+    """The fused average-and-map kernel against the oracle's row-by-row chain (compute_floor ->
+    update_avg_plain -> the waterfall loop): plain averaging is bit-identical to avg.c, so pixels and
+    levbuf must be identical too."""
+    rng = np.random.default_rng(77)
+    frames, bins, depth, minbin, maxbin = 400, 513, 4, 10, 500
+    p = (rng.random((frames, bins)) ** 4 * 1e-2 + 1e-8).astype(np.float32)
+    stats = np.array([oracle.floor_stats(r) for r in p], np.float32)
+    a = oracle.Averager(bins, depth)
+    avg = np.stack([a.update("plain", p[f], minbin, maxbin, n=bins)[1] for f in range(frames)])
+    for scale_type, autoscale in ((lib.SCALE_LOG, 1), (lib.SCALE_LIN, 0)):
+        w_rgb, w_lev, _, _ = oracle.display(avg, stats, palette_id=2, scale_log=scale_type >= 2, autoscale=bool(autoscale),
+                                            overlap=0.5, max_level_db=-20.0, min_level_db=-70.0)
+        d = lib.Display(palette=2, scale_type=scale_type, autoscale=autoscale, overlap=0.5, max_level_db=-20.0, min_level_db=-70.0)
+        rgb, lev, _ = lib.waterfall(d, torch_cuda.from_numpy(p).cuda(), avg_mode=lib.AVG_PLAIN, depth=depth, minbin=minbin, maxbin=maxbin,
+                                    want_stats=True)
+        assert np.array_equal(lev.cpu().numpy(), w_lev), scale_type
+        assert np.array_equal(rgb.cpu().numpy(), w_rgb), scale_type
