@@ -33,7 +33,14 @@ struct LevelsParams {
 // chance: levels_fixup_kernel compares every chunk's warm-up end state with its predecessor's final
 // state, bit for bit, and re-walks the chunk from the true state where they differ.
 // 131 072 columns: 10 M columns/s as one walk, ~40x that in chunks.
-constexpr int LEV_CHUNK = 1024;   // a block walks warm-up + CHUNK frames; more, shorter chunks = more blocks, less per block
+// A block walks warm-up + CHUNK frames, ~60 ns a frame, and a chunk that fails the check costs CHUNK
+// frames in the one fix-up block: the walk is ~(warm-up + CHUNK + nframes x P(fail)) frames long whatever
+// CHUNK is, so short chunks -- as long as the fix-up does not visit them one by one (it compares 64
+// at a time).  256 against 1024: display with autoscale +3 % (two same-box runs).
+#ifndef GLFER_LEV_CHUNK
+#define GLFER_LEV_CHUNK 256
+#endif
+constexpr int LEV_CHUNK = GLFER_LEV_CHUNK;
 // A better starting state shortens the warm-up: without the rounding to float the recurrence has the closed form
 // lvl[f] = sum_d 0.01 * 0.99^d * x[f - d] (0.99^2048 = 1e-9: 2048 terms are all of it), a sum every lane can take a
 // share of.  That value is a few float ulp from the true state (whose roundings it ignores), so the walk from it is
@@ -131,24 +138,44 @@ __global__ __launch_bounds__(64) void levels_kernel(const float *__restrict__ st
   const long long ws = begin - LEV_WARM_SEEDED;
   float lvl = (lane == 0) ? p.max_lvl0 : p.min_lvl0;       // the state carried into the call
   bool first;
-  if (ws - LEV_SEED <= 0) {                                // the walk starts at frame 0: the true state
+  if (ws <= 0) {                                           // the warm-up would start at frame 0: walk from the true state
     first = p.first_buffer != 0;
     levels_walk(stats, 0, begin, begin, p, p.overlap, lvl, first, levels, sx, sy);
   } else {
-    // warm-up from the closed form of the recurrence at frame ws - 1: lane l sums the terms d = l + 64 i
+    // warm-up from the closed form of the recurrence at frame ws - 1: lane l sums the terms d = l + 64 i.
+    // Where the 2048 terms reach frame 0 the sum ends there with the start of the true walk: the
+    // state carried into the call (0.99^ws of it is left), or -- first buffer -- frame 0 taken whole
+    // (g_main.c:1112-1120: lvl = x0 [/ overlap], of which 0.99^(ws-1) is left).  (Walking those
+    // chunks from frame 0 instead made the first of them, up to 3072 frames, the longest block by 3x.)
     double w = 0.01 * pow(0.99, (double)lane), s0 = 0.0, s1 = 0.0;
     const double r64 = pow(0.99, 64.0);
+    const bool whole0 = p.first_buffer != 0;
 #pragma unroll 4
     for (int i = 0; i < LEV_SEED / 64; i++) {
       const long long f = ws - 1 - (lane + 64 * i);
-      s0 += w * (double)stats[f * 4 + 0];
-      s1 += w * (double)stats[f * 4 + 1];
+      if (f > 0 || (f == 0 && !whole0)) {
+        s0 += w * (double)stats[f * 4 + 0];
+        s1 += w * (double)stats[f * 4 + 1];
+      } else if (f == 0) {
+        float a = stats[0], b = stats[1];
+        if (p.overlap > 0.0) {
+          a /= p.overlap;
+          b /= p.overlap;
+        }
+        s0 += 100.0 * w * (double)a;
+        s1 += 100.0 * w * (double)b;
+      }
       w *= r64;
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       s0 += __shfl_xor(s0, o);
       s1 += __shfl_xor(s1, o);
+    }
+    if (!whole0 && ws <= LEV_SEED) {
+      const double left = pow(0.99, (double)ws);
+      s0 += left * (double)p.max_lvl0;
+      s1 += left * (double)p.min_lvl0;
     }
     lvl = lane == 0 ? (float)s0 : (float)s1;
     first = false;
@@ -159,30 +186,46 @@ __global__ __launch_bounds__(64) void levels_kernel(const float *__restrict__ st
   if (lane < 2) chunk_state[c * 4 + 2 + lane] = lvl;
 }
 
-// One block: where a chunk's warm-up did not end in its predecessor's final state (bit for bit),
-// walk the chunk again from that state.
+// One block (one wavefront): where a chunk's warm-up did not end in its predecessor's final state
+// (bit for bit), walk the chunk again from that state.  The comparisons of 64 chunks are taken at
+// once, a lane each (one after the other they cost a memory round trip per chunk: 26 us for the 128
+// chunks of 131 072 columns, a fifth of the whole level tracking); the chunks that differ -- a few
+// per thousand -- are then walked in order.  A re-walk that changes its chunk's final state makes
+// the successor's comparison stale: the successor is walked again too (always correct, and rarer still).
 __global__ __launch_bounds__(64) void levels_fixup_kernel(const float *__restrict__ stats, long long nframes,
                                                           LevelsParams p, float *__restrict__ levels,
                                                           float *__restrict__ chunk_state, int nchunks) {
   __shared__ float sx[2][64];
   __shared__ float sy[2][64];
-  __shared__ int differs;
   const int lane = threadIdx.x;
-  for (int c = 1; c < nchunks; c++) {
-    if (lane == 0) differs = 0;
-    __syncthreads();
-    if (lane < 2 && __float_as_uint(chunk_state[c * 4 + lane]) != __float_as_uint(chunk_state[(c - 1) * 4 + 2 + lane]))
-      differs = 1;
-    __syncthreads();
-    if (differs) {                                         // block-uniform
-      const long long begin = (long long)c * LEV_CHUNK;
+  bool carry = false;                                      // the chunk before this batch changed its final state
+  for (int c0 = 1; c0 < nchunks; c0 += 64) {
+    const int c = c0 + lane;
+    bool differs = false;
+    if (c < nchunks)
+      differs = __float_as_uint(chunk_state[c * 4 + 0]) != __float_as_uint(chunk_state[(c - 1) * 4 + 2]) ||
+                __float_as_uint(chunk_state[c * 4 + 1]) != __float_as_uint(chunk_state[(c - 1) * 4 + 3]);
+    unsigned long long todo = __ballot(differs);
+    if (carry) todo |= 1ull;
+    carry = false;
+    while (todo) {                                         // wavefront-uniform
+      const int b = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int cc = c0 + b;
+      if (cc >= nchunks) break;
+      const long long begin = (long long)cc * LEV_CHUNK;
       const long long end = begin + LEV_CHUNK < nframes ? begin + LEV_CHUNK : nframes;
-      float lvl = lane < 2 ? chunk_state[(c - 1) * 4 + 2 + lane] : 0.0f;
+      float lvl = lane < 2 ? chunk_state[(cc - 1) * 4 + 2 + lane] : 0.0f;
+      const float was = lane < 2 ? chunk_state[cc * 4 + 2 + lane] : 0.0f;
       bool first = false;
       levels_walk(stats, begin, end, begin, p, p.overlap, lvl, first, levels, sx, sy);
-      if (lane < 2) chunk_state[c * 4 + 2 + lane] = lvl;
+      if (lane < 2) chunk_state[cc * 4 + 2 + lane] = lvl;
+      const bool moved = __ballot(lane < 2 && __float_as_uint(lvl) != __float_as_uint(was)) != 0;
+      if (moved) {
+        if (b < 63) todo |= 1ull << (b + 1);
+        else carry = true;
+      }
     }
-    __syncthreads();
   }
 }
 
