@@ -558,13 +558,19 @@ __device__ __forceinline__ double lane63_f64(double v) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 // over the wavefront: the sum of s, the maximum of mx with the LOWEST index mi among equals, the minimum of mn
+// (INDEX = false: the index is not wanted -- a column that is only mapped has no peak bin to return)
+template <bool INDEX = true>
 __device__ __forceinline__ void wave_sum_max_min(double &s, double &mx, int &mi, double &mn) {
   auto step = [&](auto ctrl, auto rowmask) {
     constexpr int CT = decltype(ctrl)::value, RM = decltype(rowmask)::value;
     const double os = dpp_f64<CT, RM, true>(s), om = dpp_f64<CT, RM, false>(mx), on = dpp_f64<CT, RM, false>(mn);
-    const int oi = __builtin_amdgcn_update_dpp(mi, mi, CT, RM, 0xf, false);
     s += os;
-    if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+    if constexpr (INDEX) {
+      const int oi = __builtin_amdgcn_update_dpp(mi, mi, CT, RM, 0xf, false);
+      if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+    } else {
+      mx = om > mx ? om : mx;
+    }
     mn = on < mn ? on : mn;
   };
   step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
@@ -576,7 +582,7 @@ __device__ __forceinline__ void wave_sum_max_min(double &s, double &mx, int &mi,
   s = lane63_f64(s);
   mx = lane63_f64(mx);
   mn = lane63_f64(mn);
-  mi = __builtin_amdgcn_readlane(mi, 63);
+  if constexpr (INDEX) mi = __builtin_amdgcn_readlane(mi, 63);
 }
 
 // a / d for many a and one d, correctly rounded: with y = RN(1/d) (one true division),
@@ -615,6 +621,12 @@ struct Divisor {
 // dB short) words of a column go through LDS (two buffers: frame f's words are written after frame f's
 // reduction barrier and stored as 12-byte / 8-byte pieces after frame f+1's -- no barrier of their
 // own).  Frames [fbeg, nframes) are walked; the sums reach back before fbeg (a tile of a longer batch).
+#ifndef GLFER_AVGMAP_STAGE
+#define GLFER_AVGMAP_STAGE 0     /* 1: the averaged bins of a frame wait in LDS for a rolled mapping loop (159 VGPRs instead of 191, three wavefronts per SIMD without the ring) -- measured SLOWER, 70-73 against 79 M rows/s: the kernel is bound by the instructions it issues, not by what hides them */
+#endif
+#ifndef GLFER_AVGMAP_RING_KB
+#define GLFER_AVGMAP_RING_KB 76  /* the ring of the last `depth` rows is kept in LDS while everything fits this many KB */
+#endif
 #ifndef GLFER_AVGMAP_ABL
 #define GLFER_AVGMAP_ABL 0    /* timing ablations (results wrong): 1 columns not stored, 2 bins not mapped, 4 no colour table, 8 levels not loaded */
 #endif
@@ -634,6 +646,7 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
                                                         int n_out, int depth, int minbin, int maxbin, int mode, int max0,
                                                         double *__restrict__ avg, double *__restrict__ ret, AvgMapArgs ma) {
   constexpr int NW = NT / 64;                     // wavefronts of the block
+  constexpr bool RET = !MAP;                      // update_avg's return values (band mean, peak bin, variance): not for columns that are only mapped
   __shared__ double p_sum[2][NW], p_max[2][NW], p_min[2][NW], p_var[2][NW];
   __shared__ int p_idx[2][NW], p_cnt[2][NW];
   __shared__ unsigned tab[MAP ? 256 : 1];
@@ -641,7 +654,12 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
   __shared__ int vtab_ok[2];
   extern __shared__ float dyn_lds[];             // MAP: [2][n_out] words of (colour index << 16 | dB short); RING: [depth][BPT][NT]
   unsigned *const pix = reinterpret_cast<unsigned *>(dyn_lds);
-  float *const hist = dyn_lds + (MAP ? 2 * (size_t)n_out : 0);
+  // MAP: a frame's averaged bins wait in LDS (every thread its own BPT slots: no synchronisation) for a
+  // ROLLED mapping loop -- unrolled over a register array the mapping of BPT bins at once takes the
+  // kernel to 191 VGPRs, two wavefronts per SIMD, for a chain of frames that has nothing else to hide behind
+  const size_t pix_words = MAP ? 2 * (((size_t)n_out + 1) & ~(size_t)1) : 0;       // an even count: the doubles behind it stay aligned
+  double *const stage = reinterpret_cast<double *>(dyn_lds + pix_words);
+  float *const hist = dyn_lds + pix_words + (MAP && GLFER_AVGMAP_STAGE ? 2 * (size_t)BPT * NT : 0);
   const int tid = threadIdx.x, wave = tid >> 6;
   const long long f0 = (MAP ? ma.fbeg : 0) + (long long)blockIdx.x * chunk;
   const long long f1 = f0 + chunk < nframes ? f0 + chunk : nframes;
@@ -653,7 +671,7 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
 #if GLFER_AVGMAP_ABL & 1
     if (fr != -12345) return;
 #endif
-    const unsigned *pw = pix + (size_t)(fr & 1) * n_out;
+    const unsigned *pw = pix + (size_t)(fr & 1) * (pix_words / 2);
     const size_t col = (size_t)(fr - ma.fbeg);
     unsigned char *orow = ma.rgb + col * (size_t)n_out * 3;
     short *lrow = ma.lev ? ma.lev + col * (size_t)n_out : nullptr;
@@ -762,25 +780,38 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
         else cum[j] += (double)v[CUR][j] - (double)old[CUR][j];
         const double c = cum[j];
         s += c;
-        if (c > mx) { mx = c; mi = b0 + NT * j; }
+        if constexpr (RET) {
+          if (c > mx) { mx = c; mi = b0 + NT * j; }
+        } else {
+          mx = c > mx ? c : mx;
+        }
         if (c < mn) mn = c;
       }
     }
     if (f + AHEAD < f1) fetch(f + AHEAD, cur);                 // into the buffer just read: in flight under this frame and the next
+    // the band statistics: the normalising modes divide by them, the return values are made of them;
+    // the plain average of a column that is only mapped (no return values) needs neither
+    const bool band_stats = RET || mode != 2;                                  // the same in every thread
+    if (band_stats) {
 #if !(GLFER_AVG_ABL & 2)
-    wave_sum_max_min(s, mx, mi, mn);
+      wave_sum_max_min<RET>(s, mx, mi, mn);
 #endif
-    if ((tid & 63) == 0) { p_sum[par][wave] = s; p_max[par][wave] = mx; p_min[par][wave] = mn; p_idx[par][wave] = mi; }
+      if ((tid & 63) == 0) { p_sum[par][wave] = s; p_max[par][wave] = mx; p_min[par][wave] = mn; p_idx[par][wave] = mi; }
+    }
 #if !(GLFER_AVG_ABL & 4)
     __syncthreads();
 #endif
-    double r_sum = p_sum[par][0], r_max = p_max[par][0], r_min = p_min[par][0];
-    int r_idx = p_idx[par][0];
+    double r_sum = 0.0, r_max = -1.0e300, r_min = 1.0e300;
+    int r_idx = 0x7fffffff;
+    if (band_stats) {
+      r_sum = p_sum[par][0], r_max = p_max[par][0], r_min = p_min[par][0];
+      r_idx = p_idx[par][0];
 #pragma unroll
-    for (int w = 1; w < NW; w++) {
-      r_sum += p_sum[par][w];
-      if (p_max[par][w] > r_max || (p_max[par][w] == r_max && p_idx[par][w] < r_idx)) { r_max = p_max[par][w]; r_idx = p_idx[par][w]; }
-      if (p_min[par][w] < r_min) r_min = p_min[par][w];
+      for (int w = 1; w < NW; w++) {
+        r_sum += p_sum[par][w];
+        if (p_max[par][w] > r_max || (p_max[par][w] == r_max && p_idx[par][w] < r_idx)) { r_max = p_max[par][w]; r_idx = p_idx[par][w]; }
+        if (p_min[par][w] < r_min) r_min = p_min[par][w];
+      }
     }
     // running max starts at psd[minbin] (avg.c:111,163,224) and only a strictly larger sum moves it
     double top = init;
@@ -792,15 +823,19 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
     else spec = (r_sum - top) / span;                                    // avg.c:199,260
 
     double *row = MAP ? nullptr : avg + (size_t)f * n_out;
-    unsigned *prow = pix + (size_t)par * n_out;
+    unsigned *prow = pix + (size_t)par * (pix_words / 2);
     if constexpr (MAP) {
       if (f > f0) emit(f - 1);                                 // every thread is past this frame's barrier: column f-1's words are complete
     }
     // one averaged bin: to the row, or kept for the mapping below (one copy of it for all the modes)
-    double outv[MAP ? BPT : 1];
+    double outv[(MAP && !GLFER_AVGMAP_STAGE) ? BPT : 1];
     auto put = [&](int j, int b, double val) {
-      if constexpr (MAP) outv[j] = val;
-      else GLFER_AVG_STORE(row[b], val);
+      if constexpr (MAP) {
+        if constexpr (GLFER_AVGMAP_STAGE) stage[j * NT + tid] = val;
+        else outv[j] = val;
+      } else {
+        GLFER_AVG_STORE(row[b], val);
+      }
     };
     double var = 0.0;
     int cnt = 0;
@@ -831,7 +866,9 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
           if (c - spec > 0) {                                             // avg.c:272-284
             const double q = by_spec(c);
             out = max0 ? by_range(c - spec) : q;
-            if (b != peak) { var += q * q; cnt++; }
+            if constexpr (RET) {
+              if (b != peak) { var += q * q; cnt++; }
+            }
           }
           put(j, b, out);
         }
@@ -856,10 +893,18 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
           }
           return (vv << 16) | (unsigned)(unsigned short)l;
         };
+        if constexpr (GLFER_AVGMAP_STAGE) {
+#pragma unroll 1
+          for (int j = 0; j < BPT; j++) {
+            const int b = b0 + NT * j;
+            if (b < maxbin) prow[b] = word(stage[j * NT + tid]);
+          }
+        } else {
 #pragma unroll
-        for (int j = 0; j < BPT; j++) {
-          const int b = b0 + NT * j;
-          if (b < maxbin) prow[b] = word(outv[j]);
+          for (int j = 0; j < BPT; j++) {
+            const int b = b0 + NT * j;
+            if (b < maxbin) prow[b] = word(outv[j]);
+          }
         }
         if (minbin > 0 || maxbin < n_out) {
           const unsigned w = word(1e-15);
@@ -873,7 +918,7 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
       for (int b = tid; b < minbin; b += NT) row[b] = 1e-15;
       for (int b = maxbin + tid; b < n_out; b += NT) row[b] = 1e-15;
     }
-    if (mode == 1 && ret) {
+    if (RET && mode == 1) {
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         var += __shfl_xor(var, o);
@@ -888,7 +933,7 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
         cnt += (p_cnt[par][4] + p_cnt[par][5]) + (p_cnt[par][6] + p_cnt[par][7]);
       }
     }
-    if (tid == 0 && ret) {
+    if (RET && tid == 0) {
       double *o = ret + (size_t)f * 4;
       o[0] = (mode == 2) ? spec : top / spec;                             // avg.c:158,218,297
       o[1] = (double)peak;
@@ -1005,9 +1050,10 @@ static AvgMapShape avgmap_shape(long long walk, int bins, int depth, int minbin,
   while (a.chunk > 8 && walk / a.chunk < 1024) a.chunk /= 2;
   if (GLFER_AVGMAP_WIDE && maxbin - minbin >= 1024) a.nt = 512;
   a.bpt = (maxbin - minbin + a.nt - 1) / a.nt;
-  const size_t pix_bytes = 2 * (size_t)bins * sizeof(unsigned);
+  const size_t pix_bytes = 2 * (((size_t)bins + 1) & ~(size_t)1) * sizeof(unsigned) +
+                           (GLFER_AVGMAP_STAGE ? (size_t)bpt_of(a.bpt) * a.nt * sizeof(double) : 0);   // + the staged bins
   const size_t ring_bytes = (size_t)depth * bpt_of(a.bpt) * a.nt * sizeof(float);
-  a.ring = pix_bytes + ring_bytes <= 76 * 1024;               // two blocks per CU
+  a.ring = pix_bytes + ring_bytes <= (size_t)GLFER_AVGMAP_RING_KB * 1024;
   a.shmem = pix_bytes + (a.ring ? ring_bytes : 0);
   a.ok = a.bpt >= 1 && a.bpt <= 33 && depth <= 2 * a.chunk && a.shmem <= 150 * 1024;
   return a;
@@ -1017,7 +1063,7 @@ extern "C" int glfer_avgmap_applies(size_t walk, int bins, int depth, int minbin
 }
 
 extern "C" hipError_t glfer_launch_avgmap(int mode, const float *psd, size_t fbeg, size_t nframes, int bins, int depth,
-                                          int minbin, int maxbin, int max0, double *ret, int scale_log, double thr255,
+                                          int minbin, int maxbin, int max0, int scale_log, double thr255,
                                           double one_m_thr, const float *levels, const unsigned char *colortab,
                                           const double *log_thr, unsigned char *rgb, short *lev, hipStream_t st) {
   if (nframes <= fbeg) return hipSuccess;
@@ -1037,8 +1083,8 @@ extern "C" hipError_t glfer_launch_avgmap(int mode, const float *psd, size_t fbe
                           : reinterpret_cast<const void *>(avg_fused_kernel<B, false, true, NT>);                       \
     hipError_t e = allow_dynamic_lds(fn, shmem);                                                                        \
     if (e != hipSuccess) return e;                                                                                      \
-    if (ring) hipLaunchKernelGGL((avg_fused_kernel<B, true, true, NT>), dim3(blocks), dim3(NT), shmem, st, psd, nf, chunk, bins, bins, depth, minbin, maxbin, mode, max0, (double *)nullptr, ret, ma); \
-    else hipLaunchKernelGGL((avg_fused_kernel<B, false, true, NT>), dim3(blocks), dim3(NT), shmem, st, psd, nf, chunk, bins, bins, depth, minbin, maxbin, mode, max0, (double *)nullptr, ret, ma); \
+    if (ring) hipLaunchKernelGGL((avg_fused_kernel<B, true, true, NT>), dim3(blocks), dim3(NT), shmem, st, psd, nf, chunk, bins, bins, depth, minbin, maxbin, mode, max0, (double *)nullptr, (double *)nullptr, ma); \
+    else hipLaunchKernelGGL((avg_fused_kernel<B, false, true, NT>), dim3(blocks), dim3(NT), shmem, st, psd, nf, chunk, bins, bins, depth, minbin, maxbin, mode, max0, (double *)nullptr, (double *)nullptr, ma); \
   } while (0)
 #if GLFER_AVGMAP_WIDE
 #define GLFER_AVGMAP(B)                                                                                                 \

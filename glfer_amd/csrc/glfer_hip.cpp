@@ -29,7 +29,7 @@ extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframe
                                        double *ret, hipStream_t st);
 extern "C" int glfer_avgmap_applies(size_t walk, int bins, int depth, int minbin, int maxbin);
 extern "C" hipError_t glfer_launch_avgmap(int mode, const float *psd, size_t fbeg, size_t nframes, int bins, int depth,
-                                          int minbin, int maxbin, int max0, double *ret, int scale_log, double thr255,
+                                          int minbin, int maxbin, int max0, int scale_log, double thr255,
                                           double one_m_thr, const float *levels, const unsigned char *colortab,
                                           const double *log_thr, unsigned char *rgb, short *lev, hipStream_t st);
 extern "C" hipError_t glfer_launch_avg_cum(const float *psd, size_t nframes, int bins, int n_out, int depth,
@@ -194,7 +194,7 @@ static int display_columns(glfer_hip_display *d, const float *d_psd, const doubl
     const float thr_level = d->thr_level / 100.0;                              // g_main.c:1099
     if (fused)
       e = glfer_launch_avgmap(fused->mode, fused->d_batch, fused->first, fused->first + nframes, bins, fused->depth,
-                              fused->minbin, fused->maxbin, fused->max0, nullptr, scale_log, 255.0 * thr_level,
+                              fused->minbin, fused->maxbin, fused->max0, scale_log, 255.0 * thr_level,
                               1.0 - thr_level, levels, d_tab, d_thr, d_rgb, d_lev, st);
     else
       e = glfer_launch_map(d_psd, d_avg, nframes, bins, scale_log, 255.0 * thr_level, 1.0 - thr_level, levels,
