@@ -74,3 +74,58 @@ def test_random_configuration(lib, oracle, case):
         part = sp.run(d, first_frame=first, nframes=count).cpu().numpy()
         for f in range(count):
             assert np.abs(part[f] - want[first + f]).max() <= TOL * want[first + f].max(), (first, count, f)
+
+
+def _column_cases():
+    rng = np.random.default_rng(int(os.environ.get("GLFER_FUZZ_SEED", "20260")) + 7)
+    out = []
+    for i in range(int(os.environ.get("GLFER_FUZZ_COLUMN_CASES", "40"))):
+        bins = int(rng.choice([33, 65, 129, 257, 300, 513, 1000, 1025, 2049, 2049, 4097, 8193]))
+        rows = int(rng.integers(3, 1500 if bins <= 2049 else 400))
+        depth = int(rng.choice([1, 2, 3, 4, 4, 7, 12, 30]))
+        lo = int(rng.integers(0, max(1, bins // 3)))
+        hi = int(rng.integers(lo + 1, bins + 1)) if rng.random() < 0.7 else bins
+        avg_mode = int(rng.integers(0, 4))                 # 0: none, 1 sumavg, 2 plain, 3 sumextreme
+        max0 = int(rng.random() < 0.5)
+        scale_type = int(rng.integers(0, 4))
+        autoscale = int(rng.random() < 0.6)
+        thr = float(rng.choice([0.0, 0.0, 5.0, 40.0]))
+        span = float(rng.choice([1.0, 30.0, 60.0, 120.0, 280.0]))
+        tile = int(rng.choice([0, 0, 64, 200]))
+        out.append((i, bins, rows, depth, lo, hi, avg_mode, max0, scale_type, autoscale, thr, span, tile))
+    return out
+
+
+@pytest.mark.parametrize("case", _column_cases(), ids=lambda c: "%d-b%d-r%d-d%d-%d_%d-a%d%d-s%d%d-t%d" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[12]))
+def test_random_waterfall_configuration(lib, case):
+    """glfer_hip_waterfall_device with parameters nobody hand-picked: the one-call form (averages taken
+    inside the mapping kernel, the column's dB->colour table, tiles) against the stages run one by one
+    over the whole batch (compute_floor, update_avg_*, the display map of the averaged rows)."""
+    import torch
+    i, bins, rows, depth, lo, hi, avg_mode, max0, scale_type, autoscale, thr, span, tile = case
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1000 + i)
+    psd = (10.0 ** (torch.rand((rows, bins), device="cuda", generator=g) * 9.0 - 9.0)).contiguous()
+    psd[rows // 2, lo + (hi - lo) // 2] = 3.0
+    kw = dict(palette=i % 8, scale_type=scale_type, autoscale=autoscale, overlap=0.5 * (i % 2), max_level_db=-3.0,
+              min_level_db=-3.0 - span, thr_level=thr)
+    stats = lib.compute_floor(psd)
+    src = lib.update_avg(avg_mode, psd, depth, lo, hi, max0=max0)[0] if avg_mode else psd
+    d1, d2 = lib.Display(**kw), lib.Display(**kw)
+    w_rgb, w_lev, _ = lib.display(d1, src, stats)
+    saved = os.environ.get("GLFER_WATERFALL_TILE")
+    try:
+        if tile:
+            os.environ["GLFER_WATERFALL_TILE"] = str(tile)
+        rgb, lev, st = lib.waterfall(d2, psd, avg_mode=avg_mode, depth=depth, minbin=lo, maxbin=hi, max0=max0, want_stats=True)
+    finally:
+        if saved is None:
+            os.environ.pop("GLFER_WATERFALL_TILE", None)
+        else:
+            os.environ["GLFER_WATERFALL_TILE"] = saved
+    assert torch.equal(st, stats)
+    assert (d1.first_buffer, d1.display_max_lvl, d1.display_min_lvl) == (d2.first_buffer, d2.display_max_lvl, d2.display_min_lvl)
+    if avg_mode in (0, lib.AVG_PLAIN):
+        assert torch.equal(rgb, w_rgb) and torch.equal(lev, w_lev)
+    else:   # the chunk restarts of the band statistics fall elsewhere (other chunk length, tiles): ulps, a few cells
+        assert (rgb != w_rgb).float().mean().item() < 2e-4 and (lev != w_lev).float().mean().item() < 2e-4
