@@ -64,22 +64,148 @@ int device_of(const void *d_ptr) {
   }
   return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged ? at.device : -1;
 }
+// ---- scratch.  Three sources, by size:
+//   * under 1 MiB (statistics, tables, level states): a stream-ordered pool of their own, so that
+//     they never carve a piece out of a large free block of the default pool;
+//   * 1 MiB .. 16 MiB: the device's default stream-ordered pool, release threshold raised (by default
+//     it hands everything back at the next synchronisation);
+//   * 16 MiB and more (averaged rows, a mean-corrected copy of a stream, the big-block scratch,
+//     LMP / F-test spectra: hundreds of MB to GB): blocks this library keeps (plain hipMalloc, size
+//     classes a sixteenth of a power of two apart, at most kBigBlocks per device, never returned
+//     before the process ends).  The stream-ordered pool is not made for these: tools/pooltail on this
+//     stack -- 2.2 GiB malloc + touch + free + sync per call, sizes alternating by 64 KB: median 2.0 ms
+//     a call and ONE CALL IN THREE over 10 ms, up to 4 s (a waterfall call with 2 GiB of averaged
+//     rows: 2.3 ms, one in ~100 taking 4.4 s); the same through one kept block: 17 us, never more than
+//     24.  A kept block is handed out under a mutex; giving it back records an event on the stream
+//     that used it, and the next taker on ANOTHER stream waits for that event first (stream order
+//     preserved, nothing synchronised on the host).  When all kept blocks are out (concurrent calls)
+//     or would not fit, the request falls through to the pool.  GLFER_SCRATCH_CACHE=0 turns it off.
+namespace {
+constexpr int kBigBlocks = 6;
+constexpr size_t kBigMin = (size_t)16 << 20;
+struct BigBlock {
+  void *p = nullptr;
+  size_t cap = 0;
+  bool out = false;
+  hipEvent_t freed = nullptr;
+  hipStream_t last = nullptr;
+  bool used = false;                                 // an event has been recorded on it
+};
+struct DeviceScratch {
+  bool init = false;
+  hipMemPool_t small_pool = nullptr;
+  BigBlock big[kBigBlocks];
+};
+std::mutex g_scratch_mu;
+DeviceScratch g_scratch[64];
+bool scratch_cache_on() {
+  static const bool on = [] {
+    const char *e = getenv("GLFER_SCRATCH_CACHE");
+    return !(e && atoi(e) == 0 && *e);
+  }();
+  return on;
+}
+}  // namespace
+
 hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st) {
-  static std::mutex mu;
-  static bool raised[64] = {false};
   int dev = -1;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-    std::lock_guard<std::mutex> lock(mu);
-    if (!raised[dev]) {
-      raised[dev] = true;
-      hipMemPool_t pool = nullptr;
-      uint64_t keep = (uint64_t)8 << 30;
-      if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess ||
-          hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess)
-        (void)hipGetLastError();                 // the pool keeps its default: slower, not wrong
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipMallocAsync(p, bytes, st);
+  std::unique_lock<std::mutex> lock(g_scratch_mu);
+  DeviceScratch &ds = g_scratch[dev];
+  if (!ds.init) {
+    ds.init = true;
+    hipMemPool_t pool = nullptr;
+    uint64_t keep = (uint64_t)8 << 30;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess ||
+        hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess)
+      (void)hipGetLastError();                   // the pool keeps its default: slower, not wrong
+    hipMemPoolProps props = {};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    uint64_t keep_small = (uint64_t)64 << 20;
+    if (hipMemPoolCreate(&ds.small_pool, &props) != hipSuccess ||
+        hipMemPoolSetAttribute(ds.small_pool, hipMemPoolAttrReleaseThreshold, &keep_small) != hipSuccess) {
+      (void)hipGetLastError();                   // no second pool: everything from the default one
+      ds.small_pool = nullptr;
     }
   }
+  if (bytes < ((size_t)1 << 20) && ds.small_pool) {
+    hipMemPool_t from = ds.small_pool;
+    lock.unlock();
+    return hipMallocFromPoolAsync(p, bytes, from, st);
+  }
+  if (bytes >= kBigMin && scratch_cache_on()) {
+    size_t cls = (size_t)1 << 20;                    // size classes: a batch one row longer finds the block of the last call
+    while (cls * 32 <= bytes) cls <<= 1;
+    const size_t want = (bytes + cls - 1) / cls * cls;
+    BigBlock *best = nullptr, *empty = nullptr;
+    for (BigBlock &b : ds.big) {
+      if (!b.p) {
+        if (!empty) empty = &b;
+      } else if (!b.out && b.cap >= want && (!best || b.cap < best->cap)) {
+        best = &b;
+      }
+    }
+    if (!best && !empty) {                           // every slot taken by smaller blocks: the smallest idle one makes room
+      BigBlock *victim = nullptr;
+      for (BigBlock &b : ds.big)
+        if (!b.out && b.cap < want && (!victim || b.cap < victim->cap)) victim = &b;
+      if (victim) {
+        if (victim->used) (void)hipEventSynchronize(victim->freed);
+        (void)hipFree(victim->p);
+        (void)hipEventDestroy(victim->freed);
+        *victim = BigBlock();
+        empty = victim;
+      }
+    }
+    if (!best && empty) {                            // a new kept block (synchronous hipMalloc: once per size class)
+      void *q = nullptr;
+      hipEvent_t ev = nullptr;
+      if (hipMalloc(&q, want) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+        empty->p = q;
+        empty->cap = want;
+        empty->freed = ev;
+        empty->used = false;
+        best = empty;
+      } else {
+        (void)hipGetLastError();
+        if (q) (void)hipFree(q);
+      }
+    }
+    if (best) {
+      best->out = true;
+      hipError_t e = hipSuccess;
+      if (best->used && best->last != st) e = hipStreamWaitEvent(st, best->freed, 0);
+      if (e != hipSuccess) {
+        best->out = false;
+        return e;
+      }
+      *p = best->p;
+      return hipSuccess;
+    }
+  }
+  lock.unlock();
   return hipMallocAsync(p, bytes, st);
+}
+
+// gives back what scratch_malloc handed out (stream-ordered either way)
+void scratch_free(void *q, hipStream_t st) {
+  if (!q) return;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (DeviceScratch &ds : g_scratch)
+      for (BigBlock &b : ds.big)
+        if (b.p == q) {
+          if (hipEventRecord(b.freed, st) != hipSuccess) (void)hipGetLastError();
+          b.used = true;
+          b.last = st;
+          b.out = false;
+          return;
+        }
+  }
+  (void)hipFreeAsync(q, st);
 }
 
 // Dynamic LDS above the default limit has to be allowed per kernel -- and per DEVICE: a process that
@@ -206,7 +332,7 @@ static int display_columns(glfer_hip_display *d, const float *d_psd, const doubl
     e = hipMemcpyAsync(last, levels + (nframes - 1) * 4, sizeof last, hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) fail(e);
   }
-  (void)hipFreeAsync(scratch, st);
+  glfer::scratch_free(scratch, st);
   e = hipStreamSynchronize(st);              // the carried state comes back to the host
   if (e != hipSuccess && rc == GLFER_OK) fail(e);
   if (rc == GLFER_OK) {
@@ -299,9 +425,9 @@ int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, in
       rc = display_columns(d, averaging ? nullptr : d_psd + f0 * (size_t)bins, src_avg, nullptr, tstats, nf, bins, trgb, tlev,
                            nullptr, st);
   }
-  if (avg) (void)hipFreeAsync(avg, st);
-  if (ret) (void)hipFreeAsync(ret, st);
-  if (!d_stats) (void)hipFreeAsync(stats, st);
+  if (avg) glfer::scratch_free(avg, st);
+  if (ret) glfer::scratch_free(ret, st);
+  if (!d_stats) glfer::scratch_free(stats, st);
   return rc;
 }
 
@@ -903,7 +1029,7 @@ static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t fi
     e = glfer_launch_submean_tail(src + (nhops - 1) * (size_t)p->hop * esz, nhops > 1 ? scratch + (nhops - 2) * (size_t)p->hop : nullptr,
                                   scratch + (nhops - 1) * (size_t)p->hop, p->hop, (int)tail_fresh, sp.fmt, st);
   if (e != hipSuccess) {
-    (void)hipFreeAsync(scratch, st);
+    glfer::scratch_free(scratch, st);
     return hip_fail(e, "glfer_launch_submean");
   }
   sp.stream = reinterpret_cast<const char *>(scratch) - hop_lo * (size_t)p->hop * sizeof(float);
@@ -954,7 +1080,7 @@ static int launch_mean_inkernel(const glfer_hip_plan *p, const SpectroParams &sp
       hipError_t e = launch_by_n(hs, p->n, st);
       if (e != hipSuccess) rc = hip_fail(e, "estimator launch (frames through the corrected copy)");
     }
-    if (scratch) (void)hipFreeAsync(scratch, st);
+    if (scratch) glfer::scratch_free(scratch, st);
   };
   by_copy(first, std::min(b0, end));
   if (rc == GLFER_OK && b1 > b0) {
@@ -1008,12 +1134,12 @@ int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, s
         e = glfer_launch_lmp(rows, (long long)(first - back), (long long)first, nframes, p->bins, p->lmp_av, d_psd, st);
         if (e != hipSuccess) rc = hip_fail(e, "lmp launch");
       }
-      (void)hipFreeAsync(rows, st);
+      glfer::scratch_free(rows, st);
       return rc;
     }
     if (rc == GLFER_OK && back && p->cfg.sub_mean) {
       // the extra frames reach further back than the hops corrected above
-      (void)hipFreeAsync(scratch, st);
+      glfer::scratch_free(scratch, st);
       scratch = nullptr;
       sp.stream = d_stream;
       sp.fmt = p->cfg.sample_format;
@@ -1034,8 +1160,8 @@ int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, s
                        : launch_by_n(sp, p->n, st);
     if (e != hipSuccess) rc = hip_fail(e, "estimator launch");
   }
-  if (rows) (void)hipFreeAsync(rows, st);
-  if (scratch) (void)hipFreeAsync(scratch, st);
+  if (rows) glfer::scratch_free(rows, st);
+  if (scratch) glfer::scratch_free(scratch, st);
   return rc;
 }
 
@@ -1077,7 +1203,7 @@ int glfer_hip_prepare_device(glfer_hip_plan *p, const void *d_stream, size_t nsa
     hipError_t e = glfer_launch_prepare(&sp, p->n, p->d_window, d_frames, st);
     if (e != hipSuccess) rc = hip_fail(e, "glfer_launch_prepare");
   }
-  if (scratch) (void)hipFreeAsync(scratch, st);
+  if (scratch) glfer::scratch_free(scratch, st);
   return rc;
 }
 
@@ -1150,7 +1276,7 @@ int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t n
     q.taps = mu_live ? p->d_ftaps_mu_first : p->d_ftaps;
     hipError_t e = launch_packed(q, n, st);
     if (e != hipSuccess) rc = hip_fail(e, "ftest launch");
-    if (scratch) (void)hipFreeAsync(scratch, st);
+    if (scratch) glfer::scratch_free(scratch, st);
     return rc;
   }
   size_t group = ((size_t)256 << 20) / ((size_t)(T + 1) * n * sizeof(float));
@@ -1179,9 +1305,9 @@ int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t n
       e = glfer_launch_ftest(spec, g, n, T, p->d_U0, p->sum_U0_sqr, mu_live ? 1 : 0, d_ftest + done * (size_t)p->bins, st);
     if (e != hipSuccess) rc = hip_fail(e, "ftest launch");
   }
-  if (spec) (void)hipFreeAsync(spec, st);
-  if (dummy) (void)hipFreeAsync(dummy, st);
-  if (scratch) (void)hipFreeAsync(scratch, st);
+  if (spec) glfer::scratch_free(spec, st);
+  if (dummy) glfer::scratch_free(dummy, st);
+  if (scratch) glfer::scratch_free(scratch, st);
   return rc;
 }
 

@@ -40,11 +40,12 @@ class DeviceGuard {
 // the device a device pointer belongs to (-1: not a device pointer HIP knows)
 int device_of(const void *d_ptr);
 
-// Stream-ordered scratch (hipMallocAsync on the current device).  The first call on a device raises
-// its default memory pool's release threshold to 8 GiB: by default the pool hands everything back at
-// the next synchronisation, and a call that takes its gigabyte of scratch again every time pays
-// for the mapping every time.
+// Stream-ordered scratch on the current device: small requests from a pool of their own, middle ones
+// from the default pool (release threshold raised), 16 MiB and more from blocks the library keeps
+// (glfer_hip.cpp: the stream-ordered pool costs milliseconds, and now and then seconds, per GB-sized
+// request).  Always given back through scratch_free on the stream that used it.
 hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st);
+void scratch_free(void *p, hipStream_t st);
 
 // Allow `bytes` of dynamic LDS for `kernel` on the current device (hipFuncSetAttribute, once per
 // device, kernel and size class).

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(64) void combine_kernel(SpectroParams p, int ntap, 
 using namespace glfer;
 
 namespace glfer {
-hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st);   // plan.h / glfer_hip.cpp: stream-ordered, from a pool that keeps its memory
+hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st);   // plan.h / glfer_hip.cpp: stream-ordered; large requests from blocks the library keeps
+void scratch_free(void *p, hipStream_t st);
 }
 
 // frames [p->frame0 .. +nframes) in groups that keep the scratch under ~512 MiB; p->psd is row 0 of the launch
@@ -253,6 +254,6 @@ extern "C" hipError_t glfer_launch_spectro_big(const SpectroParams *p, int n, hi
       e = hipGetLastError();
     }
   }
-  (void)hipFreeAsync(scratch, st);
+  glfer::scratch_free(scratch, st);
   return e;
 }

@@ -13,6 +13,13 @@
  * negative GLFER_E_* code; glfer_hip_strerror() names it.  Nothing here falls back to
  * the CPU: without a usable HIP device every compute entry point fails with
  * GLFER_E_HIP.
+ *
+ * Device memory the library takes by itself: what a plan holds (tables; freed by
+ * glfer_hip_plan_destroy) and per-call scratch, given back in stream order.  Scratch requests of
+ * 16 MiB and more (averaged rows, a mean-corrected stream copy, big-block and LMP / F-test
+ * intermediates) come from up to six blocks per device that the library keeps until the process ends
+ * -- the stream-ordered allocator costs milliseconds, now and then seconds, per GB-sized request.
+ * GLFER_SCRATCH_CACHE=0 in the environment takes them from the stream-ordered pool instead.
  */
 #ifndef GLFER_HIP_H
 #define GLFER_HIP_H
