@@ -30,6 +30,7 @@ VALU_PEAK_TOPS = 78.6        # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-instruc
 # what a stream of independent v_fma_f32 / v_add_f32 actually issues on this chip (tools/kbench,
 # profiles/r01_kbench_ablation.txt): 62.6 T lane-results/s at 8 wavefronts per SIMD, 54.4 at 2, 44.4 at 3
 VALU_STREAM_TOPS = 62.6
+CLOCK_GHZ = 2.4               # MI355X_MICROARCH.md peak engine clock: the issue fractions below are against it
 
 # workload -> (name, n, overlap, nw, kmax, default frames per GPU per step, frames of the CPU sample stream)
 WORKLOADS = {
@@ -276,12 +277,16 @@ def main():
         kernel, pmc_name = KERNELS[args.workload]
         # measured HBM bytes per frame of this kernel, from the committed rocprofv3 PMC passes
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is) -- see profiles/
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu_instr = None, None, None
         for rnd in ("r02_", "r01_"):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", rnd + pmc_name)))
                 traffic = prof["hbm_traffic_bytes_per_frame_corrected"] * frames
                 traffic_src = "profiles/" + rnd + pmc_name
+                # VALU wavefront-instructions per frame, counted by the hardware (SQ_INSTS_VALU pass of the same command)
+                valu_instr = prof.get("sq_counters_per_launch", {}).get("SQ_INSTS_VALU")
+                if valu_instr is not None:
+                    valu_instr /= prof["frames_per_launch"]
                 break
             except Exception:
                 pass
@@ -321,6 +326,16 @@ def main():
                         "frac": frames * lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                         "measured_stream_Tops": VALU_STREAM_TOPS,
                         "frac_of_measured_stream": frames * lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_STREAM_TOPS}
+        if valu_instr is not None:
+            # The same in the hardware's own count: VALU wavefront-instructions per frame (SQ_INSTS_VALU / frames,
+            # committed PMC pass) x frames / kernel time, per CU and clock.  Nominal peak 2 (four SIMDs, a wave64 f32
+            # instruction in two clocks: what peak_Tops assumes); a stream of independent v_fma/v_add reaches 1.59
+            # (tools/kbench, 8 wavefronts per SIMD).
+            per_clock = valu_instr * frames / (kernel_ms * 1e-3) / (256 * CLOCK_GHZ * 1e9)
+            line["valu"]["issue"] = {"wave_instr_per_frame_measured": valu_instr, "lane_instr_per_frame_measured": 64 * valu_instr,
+                                     "per_cu_clock": per_clock, "peak_per_cu_clock": 2.0,
+                                     "measured_stream_per_cu_clock": VALU_STREAM_TOPS * 1e12 / 64 / 256 / (CLOCK_GHZ * 1e9),
+                                     "clock_ghz": CLOCK_GHZ, "source": "SQ_INSTS_VALU, rocprofv3 PMC (%s)" % traffic_src}
         if args.workload == "hparma":
             # HP-ARMA is neither HBM- nor FP32-bound: a counted FP64 model of hparma_do (hparma.c:74-157 +
             # compute_svd, util.c:261-386) at t = 128, p_e = 32: t lags x N double multiply-adds; the
