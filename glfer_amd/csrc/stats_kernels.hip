@@ -9,7 +9,12 @@
 #include <math.h>
 #include <stdint.h>
 #include <type_traits>
+#include <algorithm>
 #include "spectro_params.h"
+
+#ifndef GLFER_LMP_RING
+#define GLFER_LMP_RING 1    /* 0: every frame through lmp_kernel (one thread per frame and bin, nl row reads each) */
+#endif
 
 namespace glfer {
 
@@ -18,7 +23,7 @@ namespace glfer {
 // small integers nl and nl - 1, the dividends sums of a few float32 bins: nothing over- or underflows.
 struct SmallDivisor {
   double d, y;
-  __device__ __forceinline__ explicit SmallDivisor(double dd) : d(dd), y(1.0 / dd) {}
+  __device__ __forceinline__ SmallDivisor(double dd, double recip) : d(dd), y(recip) {}   // recip = RN(1/dd), from the host: IEEE division either side
   __device__ __forceinline__ double operator()(double a) const {
     const double q0 = a * y;
     return __builtin_fma(__builtin_fma(-d, q0, a), y, q0);
@@ -39,7 +44,7 @@ struct SmallDivisor {
 template <int NL>
 __global__ __launch_bounds__(256) void lmp_kernel(const float *__restrict__ rows, long long row0, long long first,
                                                   long long nframes, int bins, int nl_arg, int first_mod, double c_neg,
-                                                  double c_den, float *__restrict__ out) {
+                                                  double c_den, double recip_nl, double recip_nl1, float *__restrict__ out) {
   const int nl = NL > 0 ? NL : nl_arg;
   const unsigned fi = blockIdx.y;                                  // < 65535
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -52,7 +57,8 @@ __global__ __launch_bounds__(256) void lmp_kernel(const float *__restrict__ rows
   }
   const int jl = (int)(((unsigned)first_mod + fi % (unsigned)nl) % (unsigned)nl);   // f mod nl
   const float *col = rows + (size_t)(f - row0) * bins + i;         // this frame's row; frame f - d is d rows up
-  const SmallDivisor by_nl((double)nl), by_nl1((double)(nl - 1));
+  // (the two reciprocals were a true f64 division each, per bin: two fifths of the kernel's instructions)
+  const SmallDivisor by_nl((double)nl, recip_nl), by_nl1((double)(nl - 1), recip_nl1);
   double my = 0.0, sy = 0.0;
   if constexpr (NL > 0) {
     float v[NL];                                                   // v[d]: bin i of frame f - d (zero before the first frame)
@@ -101,6 +107,57 @@ __global__ __launch_bounds__(256) void lmp_kernel(const float *__restrict__ rows
   float r = c_neg + (nl * my) / (c_den * v_hat);
   if (r <= 1.0e-3) r = 1e-3;
   o[i] = r;
+}
+
+// The same statistic, a thread walking G consecutive frames of its bin with the ring in registers,
+// indexed by SLOT as the reference's is (slot = frame mod nl): a group starts at a frame that is a
+// multiple of NL, so the slot a frame goes into is known at compile time and the sums run over the
+// slots in slot order with no rotation at all.  One row read per frame (plus NL - 1 per group)
+// instead of NL: lmp_kernel's blocks of consecutive frames land on different XCDs, each with its own
+// L2, and the re-reads came from HBM -- 40 KB per frame where 16 are needed.
+template <int NL, int G>
+__global__ __launch_bounds__(256) void lmp_ring_kernel(const float *__restrict__ rows, long long row0, long long first,
+                                                       long long nframes, int bins, double c_neg, double c_den,
+                                                       double recip_nl, double recip_nl1, float *__restrict__ out) {
+  static_assert(G % NL == 0, "a group is whole turns of the ring");
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const long long f0 = first + (long long)blockIdx.y * G;          // a multiple of NL (the launcher sees to `first`)
+  const long long end = first + nframes;
+  if (i >= bins || f0 >= end) return;
+  const float *col = rows + (size_t)(f0 - row0) * bins + i;        // row of frame f0; frame f0 + k is k rows down
+  float w[NL], r[G];
+#pragma unroll
+  for (int j = 0; j < NL; j++)     // frame f0 - NL + j sits in slot j; slot 0 is f0's own before it is ever summed (and its old row may lie before `rows`)
+    w[j] = (j > 0 && f0 - NL + j >= 0) ? *(col - (size_t)(NL - j) * bins) : 0.0f;
+#pragma unroll
+  for (int k = 0; k < G; k++) r[k] = f0 + k < end ? col[(size_t)k * bins] : 0.0f;
+  const SmallDivisor by_nl((double)NL, recip_nl), by_nl1((double)(NL - 1), recip_nl1);
+#pragma unroll
+  for (int k = 0; k < G; k++) {
+    if (f0 + k >= end) return;
+    w[k % NL] = r[k];
+    float *o = out + (size_t)(f0 + k - first) * bins;
+    if (i == 0) {                                                  // lmp.c:160
+      o[0] = 1e-3;
+      continue;
+    }
+    double my = 0.0, sy = 0.0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) my += w[j];                       // lmp.c:134-140
+    my = by_nl(my);
+#pragma unroll
+    for (int j = 0; j < NL; j++) {                                 // lmp.c:143-149
+      const double t = w[j] - my;
+      sy += t * t;
+    }
+    sy = by_nl1(sy);
+    double v_hat = my * my - sy;                                   // lmp.c:153-159
+    if (v_hat < 0.0) v_hat = 0.0;
+    v_hat = 0.5 * (my - sqrt(v_hat));
+    float q = c_neg + (NL * my) / (c_den * v_hat);
+    if (q <= 1.0e-3) q = 1e-3;
+    o[i] = q;
+  }
 }
 
 // One thread per (frame, bin).  spec: [ntap + 1][nframes][n] halfcomplex spectra (fft_radix2.c
@@ -181,6 +238,37 @@ extern "C" hipError_t glfer_launch_lmp(const float *rows, long long row0, long l
                                        int nl, float *out, hipStream_t st) {
   if (nframes == 0) return hipSuccess;
   if (nl < 1 || bins < 1 || nframes > 65535u * 65535ull) return hipErrorInvalidValue;
+  const double c_neg = -sqrt(nl / 2.0), c_den = 2.0 * sqrt(2.0 * nl), recip_nl = 1.0 / (double)nl, recip_nl1 = 1.0 / (double)(nl - 1);
+  // the ring sizes with a register form: the frames up to the first multiple of nl one by one (at most
+  // nl - 1 of them, below), the rest in groups through lmp_ring_kernel
+  if ((nl == 2 || nl == 3 || nl == 4 || nl == 8) && GLFER_LMP_RING) {
+    const size_t head = std::min<size_t>(nframes, (size_t)((nl - first % nl) % nl));
+    const size_t body = nframes - head;
+    if (body) {
+      const long long f0 = first + (long long)head;
+      float *o = out + head * (size_t)bins;
+#define GLFER_LMP_RING_LAUNCH(NLC, GC)                                                                               \
+  do {                                                                                                               \
+    const size_t groups = (body + GC - 1) / GC;                                                                      \
+    for (size_t g0 = 0; g0 < groups; g0 += 65535) {                                                                  \
+      const size_t ng = std::min<size_t>(65535, groups - g0);                                                        \
+      const long long fg = f0 + (long long)(g0 * GC);                                                                \
+      hipLaunchKernelGGL((lmp_ring_kernel<NLC, GC>), dim3((unsigned)((bins + 255) / 256), (unsigned)ng), dim3(256), 0, st, rows, row0, \
+                         fg, (long long)std::min<size_t>(ng * GC, body - g0 * GC), bins, c_neg, c_den, recip_nl, recip_nl1,            \
+                         o + g0 * GC * (size_t)bins);                                                                \
+    }                                                                                                                \
+  } while (0)
+      if (nl == 2) GLFER_LMP_RING_LAUNCH(2, 16);
+      else if (nl == 3) GLFER_LMP_RING_LAUNCH(3, 15);
+      else if (nl == 4) GLFER_LMP_RING_LAUNCH(4, 16);
+      else GLFER_LMP_RING_LAUNCH(8, 16);
+#undef GLFER_LMP_RING_LAUNCH
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
+    nframes = head;                                               // what is left for the frame-by-frame kernel
+    if (nframes == 0) return hipSuccess;
+  }
   // blockIdx.y carries the frame: at most 65535 per launch
   for (size_t done = 0; done < nframes; done += 65535) {
     const size_t nf = nframes - done < 65535 ? nframes - done : 65535;
@@ -188,7 +276,7 @@ extern "C" hipError_t glfer_launch_lmp(const float *rows, long long row0, long l
     const dim3 grid((unsigned)((bins + 255) / 256), (unsigned)nf);
 #define GLFER_LMP(NLC)                                                                                       \
   hipLaunchKernelGGL(lmp_kernel<NLC>, grid, dim3(256), 0, st, rows, row0, f0, (long long)nf, bins, nl, (int)(f0 % nl), \
-                     -sqrt(nl / 2.0), 2.0 * sqrt(2.0 * nl), out + done * (size_t)bins)
+                     c_neg, c_den, recip_nl, recip_nl1, out + done * (size_t)bins)
     switch (nl) {
       case 2: GLFER_LMP(2); break;
       case 3: GLFER_LMP(3); break;

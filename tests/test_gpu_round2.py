@@ -70,7 +70,7 @@ def _lmp_numpy(P, nl, first=0):
 
 
 @pytest.mark.parametrize("n,ovl,nl,sub_mean,frames", [(1024, 0.5, 4, 0, 40), (4096, 0.75, 4, 1, 37), (512, 0.0, 7, 0, 50),
-                                                     (2048, 0.9, 3, 0, 33), (256, 0.0, 2, 1, 64)])
+                                                     (2048, 0.9, 3, 0, 33), (256, 0.0, 2, 1, 64), (1024, 0.0, 8, 0, 45)])
 def test_lmp_vs_oracle(lib, oracle, torch_cuda, n, ovl, nl, sub_mean, frames):
     h = oracle.hop(n, ovl)
     x = synth(frames * h, fs=8000.0, seed=n + nl)
