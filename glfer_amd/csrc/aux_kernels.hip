@@ -734,6 +734,8 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
     if (f0 + 1 < f1) fetch(f0 + 1, std::integral_constant<int, 1>{});
   }
   const double span = (double)(maxbin - minbin - 1);
+  const Divisor by_full_depth((double)(depth + 1));          // the plain average's divisor once the window is full (avg.c:138-139,155)
+  const Divisor by_span(span), by_span_full_depth(span * (double)(depth + 1));   // the band mean's divisors: the same every frame
   auto frame = [&](const long long f, auto cur) {
     constexpr int CUR = decltype(cur)::value;
     const int par = (int)(f & 1);
@@ -819,8 +821,8 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
     if (r_max > init) { top = r_max; peak = r_idx; }
     const double low = (r_min < 1.0) ? r_min : 1.0;            // avg.c:165,192-193
     double spec;
-    if (mode == 2) spec = (r_sum - top) / (span * (double)(eff + 1));   // avg.c:147
-    else spec = (r_sum - top) / span;                                    // avg.c:199,260
+    if (mode == 2) spec = eff == depth ? by_span_full_depth(r_sum - top) : (r_sum - top) / (span * (double)(eff + 1));   // avg.c:147
+    else spec = by_span(r_sum - top);                                    // avg.c:199,260
 
     double *row = MAP ? nullptr : avg + (size_t)f * n_out;
     unsigned *prow = pix + (size_t)par * (pix_words / 2);
@@ -842,7 +844,7 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
     // the frame's divisors (the same in every lane); one loop per mode, so that a bin's code is its
     // mode's alone (left inside the loop, the mode tests came out as ~130 branches per frame)
     if (mode == 2) {
-      const Divisor by_depth((double)(eff + 1));
+      const Divisor by_depth = eff == depth ? by_full_depth : Divisor((double)(eff + 1));   // (a true division only while the window fills)
 #pragma unroll
       for (int j = 0; j < BPT; j++) {
         const int b = b0 + NT * j;
