@@ -8,7 +8,7 @@ this rank's batch of frames.  Frames are independent, so N GPUs = N disjoint fra
 data-path collective (weak scaling: frames per GPU fixed); torch.distributed (RCCL) is used only
 for the barrier and the max-over-ranks of the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--workload mtm|fft|mtm16k|hparma]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--workload mtm|fft|mtm16k|mtm75|hparma]
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
 itself (one child process per GPU, started before anything in this process touches the GPU) and
@@ -36,16 +36,20 @@ CLOCK_GHZ = 2.4               # MI355X_MICROARCH.md peak engine clock: the issue
 WORKLOADS = {
     "mtm": ("C3: multitaper N=4096 NW=2.5 mtm_k=4 (5 tapers), overlap 0, 48 kHz mono f32", 4096, 0.0, 2.5, 4, 262144, 16384),
     "fft": ("C2: periodogram Hanning N=4096, overlap 75%, 48 kHz mono f32", 4096, 0.75, 0.0, 0, 1048576, 131072),
+    # SURVEY 8(d)'s secondary row: BASELINE.json does not give C3's overlap; the reference's default (0) is the headline, C2's 75 % this one
+    "mtm75": ("C3 at C2's overlap: multitaper N=4096 NW=2.5 mtm_k=4 (5 tapers), overlap 75%, 48 kHz mono f32", 4096, 0.75, 2.5, 4, 262144, 16384),
     "mtm16k": ("C4: multitaper N=16384 NW=4.5 mtm_k=8 (9 tapers), overlap 0, 48 kHz mono f32", 16384, 0.0, 4.5, 8, 65536, 1024),
     "hparma": ("C5: HP-ARMA t=128 p_e=32 N=4096, overlap 0, 48 kHz mono f32 (compute/latency bound, not HBM)", 4096, 0.0, 0.0, 0, 16384, 4096),
 }
 METRICS = {"mtm": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4",
            "fft": "spectrogram frames/sec + achieved HBM GB/s, N=4096 periodogram",
+           "mtm75": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4, overlap 75 %",
            "mtm16k": "spectrogram frames/sec + achieved HBM GB/s, N=16384 MTM K=8",
            "hparma": "spectrogram frames/sec, HP-ARMA t=128 p_e=32 N=4096"}
 # the kernel that takes the body of the launch (glfer_hip.cpp launch_by_n) and its committed PMC summary
 KERNELS = {"mtm": ("spectro16y_kernel", "hbm_traffic.json"), "fft": ("spectro16h_kernel<12, ..., SHIFT 4> (register reuse across overlapped frames)", "hbm_traffic_fft.json"),
            "mtm16k": ("spectro16w_kernel<14> (multitaper form)", "hbm_traffic_mtm16k.json"),
+           "mtm75": ("spectro16y_kernel", None),
            "hparma": ("hparma_kernel", None)}
 
 
@@ -77,7 +81,7 @@ def cpu_baseline(workload, n, overlap, nw, kmax, frames):
     x = synth(frames * hop, seed=0)
 
     def one_pass(stream):
-        if workload in ("mtm", "mtm16k"):
+        if workload in ("mtm", "mtm16k", "mtm75"):
             O.spectrogram_mtm(stream, n, overlap, nw, kmax)
         elif workload == "hparma":
             O.spectrogram_hparma(stream, n, overlap, 128, 32)
@@ -222,7 +226,7 @@ def main():
     dev = torch.device("cuda", local)
 
     name, n, overlap, nw, kmax, default_frames, cpu_frames = WORKLOADS[args.workload]
-    if args.workload in ("mtm", "mtm16k"):
+    if args.workload in ("mtm", "mtm16k", "mtm75"):
         params = G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax)
     elif args.workload == "hparma":
         params = G.HparmaParams(n=n, overlap=overlap, t=128, p_e=32)
