@@ -908,7 +908,7 @@ static BodyRoute body_route(const SpectroParams &sp, int n) {
   return real_input ? ROUTE_REAL_INPUT : ROUTE_SHARED_ODD;
 }
 // the forms that remove the hop means themselves (SpectroParams::mean_inkernel): the packed kernel,
-// spectro16h.hip's periodogram form, spectro16y.hip, spectro16w.hip's multitaper form at overlap 0
+// spectro16h.hip's periodogram form, spectro16y.hip, spectro16w.hip's multitaper form
 static bool route_takes_mean(BodyRoute r, const SpectroParams &sp, int n) {
   if (n < 256 || n > 16384 || sp.spec || sp.nonlin || sp.history_mode) return false;
   if ((16 * sp.H) % n) return false;
@@ -917,7 +917,7 @@ static bool route_takes_mean(BodyRoute r, const SpectroParams &sp, int n) {
     case ROUTE_PACKED: return k16 == 4 || k16 == 8 || k16 == 16;
     case ROUTE_REAL_INPUT: return sp.npairs == 1 && sp.htapers <= 1 && (k16 == 2 || k16 == 4 || k16 == 8 || k16 == 16);
     case ROUTE_SHARED_ODD: return (n == 4096 || n <= 1024) && (k16 == 4 || k16 == 8 || k16 == 16);   // y; x / xl while a frame sits in one wavefront
-    case ROUTE_WAVE_PRIVATE: return sp.wtapers > 1 && k16 == 16;     // spectro16w.hip's multitaper form, hop = frame
+    case ROUTE_WAVE_PRIVATE: return sp.wtapers > 1 && (k16 == 4 || k16 == 8 || k16 == 16);     // spectro16w.hip's multitaper form
     default: return false;
   }
 }

@@ -85,15 +85,18 @@ struct LaunchW {
 // those cases: N = 32768 (the packed form stops at N = 16384).
 // HIST = 1: history zeroed in every frame (a template parameter: as a run-time test the zeroing
 // becomes 32 unconditional selects per frame).
-// KM = 16 (multitaper form, overlap 0: the hop IS the frame): per-hop mean removal (fft.c:86-96, the
-// reference's default) inside the kernel -- the frame's samples are in registers for all its tapers
-// anyway; before the first taper the lanes' sums go through the wavefronts (butterfly) and the
-// frame's W wavefronts (LDS, one more workgroup barrier per FRAME, not per transform), and x - mu is
-// what every taper multiplies.  Integer samples: the mean is taken on the raw values, the scale
+// KM = 16, 8, 4 (multitaper form; overlap 0, 50, 75 %: a hop is KM of a lane's 16 sample registers):
+// per-hop mean removal (fft.c:86-96, the reference's default) inside the kernel -- the frame's samples
+// are in registers for all its tapers anyway; before the first taper the lanes' sums per hop go
+// through the wavefronts (butterfly) and the frame's W wavefronts (LDS, one more workgroup barrier
+// per FRAME, not per transform), and x - mu[hop] is what every taper multiplies.  A hop seen again in
+// the next frame sits KM registers lower in the same lanes: the same sums in the same order.  Integer samples: the mean is taken on the raw values, the scale
 // (a power of two) sits in the taper tables as before.
 template <int LOGN, int FMT, int MT, int VAR, int SETS, int WPS, int GEN = 0, int HIST = 0, int KM = 0>
 __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(SpectroParams p) {
-  static_assert(KM == 0 || (KM == 16 && MT != 0 && GEN == 0 && HIST == 0), "in-kernel mean removal: the multitaper form, hop = frame");
+  static_assert(KM == 0 || ((KM == 16 || KM == 8 || KM == 4) && MT != 0 && GEN == 0 && HIST == 0),
+                "in-kernel mean removal: the multitaper form, hop = 16, 8 or 4 of a lane's 16 sample registers");
+  constexpr int NH = KM ? 16 / KM : 1;                     // hops per frame
   using L = LaunchW<LOGN>;
   using C = Plan16<10>;
   constexpr int M = L::M, W = L::W, FPB = L::FPB, LF = L::LF, IPL = L::IPL, STRIP = L::STRIP;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
   constexpr int NTMAX = 32;                                // mtm_k <= 31 (glfer_hip_plan_create)
   constexpr int SIDE = MT ? 2 * NTMAX * W : 0, RED = MT ? NTMAX * W / 2 : 0;   // v2f32 entries per frame slot
   __shared__ v2f32 lds[FPB * W * STRIP * SETS + 16 * 17 + (VAR == 2 ? M : 0) + FPB * (SIDE + RED)];
-  __shared__ float mred[KM ? FPB * W : 1];                 // KM: the wavefronts' sums of the frame's samples
+  __shared__ float mred[KM ? FPB * W * NH : 1];            // KM: the wavefronts' sums of the frame's hops
 
   const unsigned tid = threadIdx.x;
   const unsigned t = tid & 63u;
@@ -313,27 +316,38 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
   long long sf = fblk;
   int sj = 0;
   unsigned sit = 0;                                        // transforms started: picks the strip set
-  float mu = 0.0f;                                         // KM: the mean of the frame in px (raw sample units)
+  float mu[NH];                                            // KM: the means of the hops of the frame in px (raw sample units)
+#pragma unroll
+  for (int q = 0; q < NH; q++) mu[q] = 0.0f;
   auto phase_S = [&] {
     const bool last = sj == ntap - 1;
     const long long nf = sf + FPB;
     const bool has_next = nf < fend;
     if constexpr (KM != 0) {
-      if (sj == 0) {                                       // a new frame in px: its mean, once (every wavefront of the workgroup is here)
-        float part = 0.0f;
+      if (sj == 0) {                                       // a new frame in px: its hops' means, once (every wavefront of the workgroup is here)
+        float part[NH];
+#pragma unroll
+        for (int q = 0; q < NH; q++) part[q] = 0.0f;
         static_for<0, 16>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
           const v2f32 x = sample_pair(mc);
-          part += x.x;
-          part += x.y;
+          part[m / KM] += x.x;
+          part[m / KM] += x.y;
         });
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o);
-        if (t == 0) mred[fl * W + w] = part;
-        shared_sync();
-        float sm = 0.0f;
+        for (int q = 0; q < NH; q++) {
 #pragma unroll
-        for (int ww = 0; ww < W; ww++) sm += mred[fl * W + ww];
-        mu = sm / (float)p.H;                              // fft.c:91
+          for (int o = 1; o < 64; o <<= 1) part[q] += __shfl_xor(part[q], o);
+          if (t == 0) mred[(fl * W + w) * NH + q] = part[q];
+        }
+        shared_sync();
+#pragma unroll
+        for (int q = 0; q < NH; q++) {
+          float sm = 0.0f;
+#pragma unroll
+          for (int ww = 0; ww < W; ww++) sm += mred[(fl * W + ww) * NH + q];
+          mu[q] = sm / (float)p.H;                         // fft.c:91
+        }
       }
     }
     v2f32 *xb = lds + ((SETS == 2 ? (sit & 1u) : 0u) * FPB + fl) * (W * STRIP) + w * STRIP;
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
     static_for<0, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       v2f32 x = sample_pair(mc);
-      if constexpr (KM != 0) x = v2f32{x.x - mu, x.y - mu};            // fft.c:93-95
+      if constexpr (KM != 0) x = v2f32{x.x - mu[m / (KM ? KM : 1)], x.y - mu[m / (KM ? KM : 1)]};   // fft.c:93-95
       const v2f32 ww = VAR == 2 ? wv[VAR == 2 ? m : 0] : window_pair(mc) * (GEN ? 1.0f : kSampleScale);
       if (GEN != 0 && p.nonlin) {
         // fft.c:127-156: RA9MB x/(a+x^2), window, then sign(y)|y|^0.1; the unit-power scale comes
@@ -605,8 +619,12 @@ static hipError_t launch16w_fmt(const SpectroParams &p, hipStream_t st) {
   if (p.wtapers > 1) {                             // the multitaper form keeps its sums in registers: two waves per SIMD
     constexpr int WPS_MT = (WPS > 2 && L < 15) ? 2 : WPS;
     if (p.mean_inkernel) {
-      if (p.history_mode || p.H != (1 << L)) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT, 0, 0, 16>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      const int km = (16 * p.H) % (1 << L) == 0 ? 16 * p.H / (1 << L) : 0;
+      if (p.history_mode) return hipErrorInvalidValue;
+      if (km == 16) hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT, 0, 0, 16>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      else if (km == 8) hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT, 0, 0, 8>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      else if (km == 4) hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT, 0, 0, 4>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      else return hipErrorInvalidValue;
     } else if (p.history_mode) hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
     else hipLaunchKernelGGL((spectro16w_kernel<L, FMT, 1, 1, GLFER16W_SETS, WPS_MT, 0, 0>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   } else {

@@ -529,14 +529,15 @@ def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, 
                                                        (4096, 0.5, 5, "f32", 1500), (512, 0.0, 1, "f32", 7000),
                                                        (1024, 0.0, 4, "f32", 9001), (512, 0.5, 2, "s16", 9000), (256, 0.75, 4, "u8", 9001),
                                                        (1024, 0.75, 6, "f32", 5000),
-                                                       (16384, 0.0, 8, "f32", 1100), (8192, 0.0, 4, "s16", 2100), (16384, 0.0, 8, "u8", 70)])
+                                                       (16384, 0.0, 8, "f32", 1100), (8192, 0.0, 4, "s16", 2100), (16384, 0.0, 8, "u8", 70),
+                                                       (16384, 0.5, 8, "f32", 1200), (8192, 0.75, 4, "f32", 2200), (16384, 0.75, 5, "s16", 140)])
 def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, n, overlap, kmax, fmt, frames):
     """The same for spectro16y (N = 4096, odd taper counts: frames taken in pairs, a lone first or last
     frame and the stream's first frames through the corrected copy) and for the packed kernel (even
     taper counts -- N = 1024 with 8 tapers at overlap 0 is the reference's default multitaper
     setting -- and the block sizes whose odd counts it takes) and for spectro16x / xl (odd counts
-    up to N = 1024); hop = 4/8/16 sixteenths of the block.  N = 8192 / 16384 at overlap 0: the
-    wavefront-private multitaper form, the frame's mean across its 4 / 8 wavefronts."""
+    up to N = 1024); hop = 4/8/16 sixteenths of the block.  N = 8192 / 16384 at overlap 0, 50, 75 %: the
+    wavefront-private multitaper form, the hops' means across the frame's 4 / 8 wavefronts."""
     nw = 2.5 if kmax <= 4 else (4.5 if kmax == 8 else 4.0)
     h = oracle.hop(n, overlap)
     x = synth(frames * h + 3, seed=kmax + frames) + np.float32(0.3)
