@@ -92,7 +92,8 @@ struct LaunchH {
 template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0, int SHIFT = 0, int MEAN = 0>
 __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(SpectroParams p) {
   static_assert(SHIFT == 0 || (MT == 0 && HIST == 0), "register reuse: periodogram, history from the stream");
-  static_assert(MEAN == 0 || (MT == 0 && HIST == 0 && GLFER16_BARRIER_AFTER_READS != 0), "in-kernel mean removal: periodogram, history from the stream");
+  static_assert(MEAN == 0 || ((MT == 0 || SHIFT == 0) && HIST == 0 && GLFER16_BARRIER_AFTER_READS != 0),
+                "in-kernel mean removal: the periodogram, or the multitaper form with hop = frame; history from the stream");
   constexpr int KM = SHIFT > 0 ? SHIFT : 16;             // MEAN: register pairs per hop
   constexpr int NH = 16 / KM;                            //       hops per frame
   static_assert(MT == 0 || VAR == 1, "the multitaper form re-reads its window per taper");
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     if constexpr (MEAN != 0) {
       // the next frame's newest hop is in px by now (requested during this frame's passes): its sum
       // crosses the frame's wavefronts over the barrier that ends the iteration
-      if (has_next) {
+      if (has_next && last) {                          // (the multitaper form: after the frame's last taper)
         constexpr int ROTN = (SHIFT == 4 || SHIFT == 8) ? ((decltype(rotc)::value + SHIFT) & 15) : 0;
         next_part = hop_partial(std::integral_constant<int, NH - 1>{}, std::integral_constant<int, ROTN>{});
         publish(next_part, NH - 1);
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     }
     if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();     // mirror entries read: buffer free
     if constexpr (MEAN != 0) {
-      if (has_next) {
+      if (has_next && last) {
         const float mn = collect(next_part, NH - 1);
 #pragma unroll
         for (int h = 0; h + 1 < NH; h++) mu[h] = mu[h + 1];
@@ -479,7 +480,12 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
 #if GLFER_LOGN >= 13
   if (p.htapers > 1) {
-    if (p.mean_inkernel) return hipErrorInvalidValue;
+    if (p.mean_inkernel) {                          // hop = frame (overlap 0): the frame's mean before its first taper
+      if (p.history_mode || p.H != (1 << L)) return hipErrorInvalidValue;
+      // (two wavefronts per SIMD: at three the hop mean pushes the multitaper loop into spills, 152 B of scratch per lane)
+      hipLaunchKernelGGL((spectro16h_kernel<L, FMT, (GLFER16H_WAVES_PER_SIMD > 2 ? 2 : GLFER16H_WAVES_PER_SIMD), 1, 1, 0, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      return hipGetLastError();
+    }
     if (p.history_mode) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, 1, 1, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
     else hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, 1, 1, 0>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
     return hipGetLastError();
