@@ -94,7 +94,8 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   static_assert(SHIFT == 0 || (MT == 0 && HIST == 0), "register reuse: periodogram, history from the stream");
   static_assert(MEAN == 0 || ((MT == 0 || SHIFT == 0) && HIST == 0 && GLFER16_BARRIER_AFTER_READS != 0),
                 "in-kernel mean removal: the periodogram, or the multitaper form with hop = frame; history from the stream");
-  constexpr int KM = SHIFT > 0 ? SHIFT : 16;             // MEAN: register pairs per hop
+  constexpr int KM = SHIFT > 0 ? SHIFT : (MEAN > 1 ? MEAN : 16);   // MEAN: register pairs per hop (MEAN = 8, 4: the multitaper form at 50 / 75 % overlap, no register reuse)
+  static_assert(MEAN <= 1 || (MT != 0 && SHIFT == 0 && LaunchH<LOGN>::FPB == 1 && (MEAN == 8 || MEAN == 4)), "MEAN = 8, 4: multitaper form, a slot walks consecutive frames");
   constexpr int NH = 16 / KM;                            //       hops per frame
   static_assert(MT == 0 || VAR == 1, "the multitaper form re-reads its window per taper");
   using L = LaunchH<LOGN>;
@@ -480,10 +481,15 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
 #if GLFER_LOGN >= 13
   if (p.htapers > 1) {
-    if (p.mean_inkernel) {                          // hop = frame (overlap 0): the frame's mean before its first taper
-      if (p.history_mode || p.H != (1 << L)) return hipErrorInvalidValue;
-      // (two wavefronts per SIMD: at three the hop mean pushes the multitaper loop into spills, 152 B of scratch per lane)
-      hipLaunchKernelGGL((spectro16h_kernel<L, FMT, (GLFER16H_WAVES_PER_SIMD > 2 ? 2 : GLFER16H_WAVES_PER_SIMD), 1, 1, 0, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    if (p.mean_inkernel) {                          // hop = 16, 8 or 4 of a lane's register pairs (overlap 0, 50, 75 %): the hops' means before the frame's first taper
+      const int km = (16 * p.H) % (1 << L) == 0 ? 16 * p.H / (1 << L) : 0;
+      if (p.history_mode) return hipErrorInvalidValue;
+      // (two wavefronts per SIMD: at three the hop means push the multitaper loop into spills, 152 B of scratch per lane)
+      constexpr int W2 = GLFER16H_WAVES_PER_SIMD > 2 ? 2 : GLFER16H_WAVES_PER_SIMD;
+      if (km == 16) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, W2, 1, 1, 0, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      else if (km == 8) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, W2, 1, 1, 0, 0, 8>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      else if (km == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, W2, 1, 1, 0, 0, 4>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      else return hipErrorInvalidValue;
       return hipGetLastError();
     }
     if (p.history_mode) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, 1, 1, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);

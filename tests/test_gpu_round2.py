@@ -530,7 +530,8 @@ def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, 
                                                        (1024, 0.0, 4, "f32", 9001), (512, 0.5, 2, "s16", 9000), (256, 0.75, 4, "u8", 9001),
                                                        (1024, 0.75, 6, "f32", 5000),
                                                        (16384, 0.0, 8, "f32", 1100), (8192, 0.0, 4, "s16", 2100), (16384, 0.0, 8, "u8", 70),
-                                                       (16384, 0.5, 8, "f32", 1200), (8192, 0.75, 4, "f32", 2200), (16384, 0.75, 5, "s16", 140)])
+                                                       (16384, 0.5, 8, "f32", 1200), (8192, 0.75, 4, "f32", 2200), (16384, 0.75, 5, "s16", 140),
+                                                       (8192, 0.5, 7, "s16", 900)])
 def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, n, overlap, kmax, fmt, frames):
     """The same for spectro16y (N = 4096, odd taper counts: frames taken in pairs, a lone first or last
     frame and the stream's first frames through the corrected copy) and for the packed kernel (even
