@@ -918,7 +918,7 @@ static bool route_takes_mean(BodyRoute r, const SpectroParams &sp, int n) {
     case ROUTE_REAL_INPUT: return (sp.npairs == 1 && sp.htapers <= 1 && (k16 == 2 || k16 == 4 || k16 == 8 || k16 == 16)) ||
                                   (sp.htapers > 1 && n >= 8192 && k16 == 16);      // spectro16h.hip's multitaper form, hop = frame (its 50 / 75 % forms exist and lose to the copy: two wavefronts per SIMD against three)
     case ROUTE_SHARED_ODD: return (n == 4096 || n <= 1024) && (k16 == 4 || k16 == 8 || k16 == 16);   // y; x / xl while a frame sits in one wavefront
-    case ROUTE_WAVE_PRIVATE: return sp.wtapers > 1 && (k16 == 4 || k16 == 8 || k16 == 16);     // spectro16w.hip's multitaper form
+    case ROUTE_WAVE_PRIVATE: return sp.wtapers > 1 && (k16 == 8 || k16 == 16);     // spectro16w.hip's multitaper form (at 75 % overlap the copy is a quarter of a frame and wins: 7.50 against 7.36 M frames/s)
     default: return false;
   }
 }
