@@ -823,3 +823,35 @@ def test_waterfall_plain_average_against_the_oracle(lib, oracle, torch_cuda):
                                     want_stats=True)
         assert np.array_equal(lev.cpu().numpy(), w_lev), scale_type
         assert np.array_equal(rgb.cpu().numpy(), w_rgb), scale_type
+
+
+def test_kept_scratch_blocks_across_streams(lib, torch_cuda):
+    """Scratch of 16 MiB and more comes from blocks the library keeps; a block given back on one stream
+    and taken again on another first waits for the event recorded at the give-back.  The staged
+    waterfall (averaged rows as scratch: 20000 x 513 doubles = 82 MB) alternately on two streams with
+    different inputs, no host synchronisation in between, against the same calls on one stream."""
+    torch = torch_cuda
+    rows, bins = 20000, 513
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    inputs = [(torch.rand((rows, bins), device="cuda", generator=g) ** 4 * 1e-3 + 1e-9).contiguous() for _ in range(4)]
+    saved = os.environ.get("GLFER_WATERFALL_FUSED")
+    os.environ["GLFER_WATERFALL_FUSED"] = "0"
+    try:
+        kw = dict(scale_type=lib.SCALE_LOG, autoscale=1, overlap=0.5, palette=1)
+        want = [lib.waterfall(lib.Display(**kw), x, avg_mode=lib.AVG_SUMEXTREME, depth=5, minbin=3, maxbin=500)[0].clone() for x in inputs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        got = []
+        for rep in range(3):
+            for i, x in enumerate(inputs):
+                with torch.cuda.stream(streams[i % 2]):
+                    got.append((i, lib.waterfall(lib.Display(**kw), x, avg_mode=lib.AVG_SUMEXTREME, depth=5, minbin=3, maxbin=500)[0]))
+        torch.cuda.synchronize()
+        for i, rgb in got:
+            assert torch.equal(rgb, want[i]), i
+    finally:
+        if saved is None:
+            os.environ.pop("GLFER_WATERFALL_FUSED", None)
+        else:
+            os.environ["GLFER_WATERFALL_FUSED"] = saved
