@@ -8,7 +8,7 @@ this rank's batch of frames.  Frames are independent, so N GPUs = N disjoint fra
 data-path collective (weak scaling: frames per GPU fixed); torch.distributed (RCCL) is used only
 for the barrier and the max-over-ranks of the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--workload mtm|fft|mtm16k|mtm75|hparma]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--workload mtm|fft|fft1k|mtm16k|mtm75|hparma] [--no-secondary]
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
 itself (one child process per GPU, started before anything in this process touches the GPU) and
@@ -34,6 +34,9 @@ CLOCK_GHZ = 2.4               # MI355X_MICROARCH.md peak engine clock: the issue
 
 # workload -> (name, n, overlap, nw, kmax, default frames per GPU per step, frames of the CPU sample stream)
 WORKLOADS = {
+    # C1 is the reference's own CPU-runnable case (`glfer -f`, glfer.c:238-239,254: N=1024, Hanning, 50 %, 8 kHz): a parity case
+    # first, timed here as a secondary row because BASELINE.md 3 lists it beside the others
+    "fft1k": ("C1: periodogram Hanning N=1024, overlap 50%, 8 kHz mono f32", 1024, 0.5, 0.0, 0, 2097152, 262144),
     "mtm": ("C3: multitaper N=4096 NW=2.5 mtm_k=4 (5 tapers), overlap 0, 48 kHz mono f32", 4096, 0.0, 2.5, 4, 262144, 16384),
     "fft": ("C2: periodogram Hanning N=4096, overlap 75%, 48 kHz mono f32", 4096, 0.75, 0.0, 0, 1048576, 131072),
     # SURVEY 8(d)'s secondary row: BASELINE.json does not give C3's overlap; the reference's default (0) is the headline, C2's 75 % this one
@@ -41,16 +44,28 @@ WORKLOADS = {
     "mtm16k": ("C4: multitaper N=16384 NW=4.5 mtm_k=8 (9 tapers), overlap 0, 48 kHz mono f32", 16384, 0.0, 4.5, 8, 65536, 1024),
     "hparma": ("C5: HP-ARMA t=128 p_e=32 N=4096, overlap 0, 48 kHz mono f32 (compute/latency bound, not HBM)", 4096, 0.0, 0.0, 0, 16384, 4096),
 }
-METRICS = {"mtm": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4",
+METRICS = {"fft1k": "spectrogram frames/sec + achieved HBM GB/s, N=1024 periodogram",
+           "mtm": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4",
            "fft": "spectrogram frames/sec + achieved HBM GB/s, N=4096 periodogram",
            "mtm75": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4, overlap 75 %",
            "mtm16k": "spectrogram frames/sec + achieved HBM GB/s, N=16384 MTM K=8",
            "hparma": "spectrogram frames/sec, HP-ARMA t=128 p_e=32 N=4096"}
 # the kernel that takes the body of the launch (glfer_hip.cpp launch_by_n) and its committed PMC summary
-KERNELS = {"mtm": ("spectro16y_kernel", "hbm_traffic.json"), "fft": ("spectro16h_kernel<12, ..., SHIFT 4> (register reuse across overlapped frames)", "hbm_traffic_fft.json"),
+KERNELS = {"fft1k": ("spectro16h_kernel<10, ..., SHIFT 8> (register reuse across overlapped frames)", None),
+           "mtm": ("spectro16y_kernel", "hbm_traffic.json"), "fft": ("spectro16h_kernel<12, ..., SHIFT 4> (register reuse across overlapped frames)", "hbm_traffic_fft.json"),
            "mtm16k": ("spectro16w_kernel<14> (multitaper form)", "hbm_traffic_mtm16k.json"),
            "mtm75": ("spectro16y_kernel", None),
            "hparma": ("hparma_kernel", None)}
+
+
+ROOFLINE_NOTES = {
+    "mtm": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac",
+    "mtm75": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac",
+    "mtm16k": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac",
+    "fft": "HBM-bound: the copy ceiling on this chip is 0.79 of the 8 TB/s spec (MI355X_MICROARCH.md: 6.29 TB/s measured)",
+    "fft1k": "HBM-bound: the copy ceiling on this chip is 0.79 of the 8 TB/s spec (MI355X_MICROARCH.md: 6.29 TB/s measured)",
+    "hparma": "not HBM-bound (24.6 KB per frame of algorithmic traffic): compute/latency-bound, see valu (FP64)",
+}
 
 
 def synth_on_device(torch, nsamples, device, seed, fs=48000.0):
@@ -117,8 +132,8 @@ def cpu_baseline(workload, n, overlap, nw, kmax, frames):
                       "oracle/glfer_oracle.c (gcc -O2, radix-2 recurrence FFT as fft_radix2.c), %.1f s"
                       % (done, frames, dt),
             "all_cores": {"value": cores * per_thread / dtn, "unit": "frames/s", "cores": cores, "kind": "port",
-                          "sample": "%d threads x %d frames, one estimator instance per thread, %.1f s"
-                                    % (cores, per_thread, dtn)},
+                          "sample": "%d threads (of %d host cores; a 1-GPU box's share is 16) x %d frames, one estimator "
+                                    "instance per thread, %.1f s" % (cores, os.cpu_count() or 0, per_thread, dtn)},
             "host_cores_available": os.cpu_count()}
 
 
@@ -184,6 +199,162 @@ def dry_run(args, world, rank):
                           "warmup": args.warmup, "workload": args.workload}))
 
 
+def cpu_model():
+    """The host CPU's model string (BASELINE.md 3 asks for it beside the CPU baseline)."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def make_params(G, workload):
+    name, n, overlap, nw, kmax, _, _ = WORKLOADS[workload]
+    if workload in ("mtm", "mtm16k", "mtm75"):
+        return G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax)
+    if workload == "hparma":
+        return G.HparmaParams(n=n, overlap=overlap, t=128, p_e=32)
+    return G.FftParams(n=n, window_type=G.WINDOWS["hanning"], overlap=overlap)
+
+
+def pmc_summary(pmc_name):
+    """Committed rocprofv3 PMC summary of a workload (newest round first): (dict, path) or (None, None)."""
+    if pmc_name is None:
+        return None, None
+    for rnd in ("r03_", "r02_", "r01_"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", rnd + pmc_name))), "profiles/" + rnd + pmc_name
+        except Exception:
+            pass
+    return None, None
+
+
+def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local, rehearse):
+    """W untimed + K timed passes of one workload over this rank's frame range; the timed region is
+    bracketed by barrier + synchronize on both sides and the MAX over ranks is taken.  Returns a dict
+    (every rank; only rank 0 uses it)."""
+    name, n, overlap, nw, kmax, default_frames, _ = WORKLOADS[workload]
+    dev = torch.device("cuda", local)
+    frames = frames or default_frames               # SURVEY 8(d): a 2^30-sample stream per GPU
+    fs = 8000.0 if workload == "fft1k" else 48000.0
+    sp = G.Spectrogram(make_params(G, workload), device=local)
+    hop, bins = sp.hop, sp.bins
+    # Weak scaling: the job is world*frames frames of one long stream; this rank owns the
+    # contiguous frame range frame_range() gives it and holds only the samples of its window
+    # (its hops + the N-H history halo on the left; the stream starts with zero history).
+    from glfer_amd.shard import frame_range, run_shard, sample_window
+    first, count = frame_range(frames * world, rank, world)
+    begin, end = sample_window(first, count, hop, n)
+    shard = synth_on_device(torch, end - begin, dev, seed=rank, fs=fs)
+    psd = torch.empty((count, bins), dtype=torch.float32, device=dev)
+
+    def step():
+        run_shard(sp, shard, begin, first, count, out=psd)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    # events on the stream the kernels are launched on (run_shard hands torch's current stream
+    # to the C-ABI, and torch.cuda.Event records on that same stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    res = {"workload": workload, "name": name, "n": n, "overlap": overlap, "hop": hop, "bins": bins, "frames": frames,
+           "ntapers": sp.ntapers, "dt": dt, "kernel_ms": kernel_ms, "fps": frames * world * steps / dt,
+           "ms_per_step": dt / steps * 1e3, "b_alg": 4 * hop + 4 * bins}
+    res["achieved_gbs"] = frames * res["b_alg"] / (kernel_ms * 1e-3) / 1e9
+    del shard, psd
+    sp.close()
+    torch.cuda.empty_cache()
+    return res
+
+
+def valu_view(res):
+    """FP32 VALU view of a launch: butterflies 3*M*log2(M) per complex M-point transform + inter-pass
+    twiddles, taper multiply and |Z|^2.  MTM at N <= 4096: one N-point transform per taper PAIR, the odd
+    taper shared by two frames (ntap/2 transforms per frame); periodogram and MTM at N >= 8192: one
+    N/2-point transform per taper + the real-input split (8 ops per bin)."""
+    import math
+    n, ntap, frames, kernel_ms, workload = res["n"], res["ntapers"], res["frames"], res["kernel_ms"], res["workload"]
+    m = n // 2
+    real_input = 3 * m * math.log2(m) + 4 * (m - m // 64) + 2 * m + 8 * m
+    if workload in ("fft", "fft1k"):
+        lane_ops = real_input
+    elif workload == "mtm16k":
+        lane_ops = ntap * real_input
+    else:
+        lane_ops = (ntap / 2.0) * (3 * n * math.log2(n) + 4 * (n - n // 64) + 2 * n + 2 * n)
+    tops = frames * lane_ops / (kernel_ms * 1e-3) / 1e12
+    return {"lane_ops_per_frame": lane_ops, "achieved_Tops": tops, "peak_Tops": VALU_PEAK_TOPS, "frac": tops / VALU_PEAK_TOPS,
+            "measured_stream_Tops": VALU_STREAM_TOPS, "frac_of_measured_stream": tops / VALU_STREAM_TOPS}
+
+
+def hparma_view(res):
+    """HP-ARMA is neither HBM- nor FP32-bound: a counted FP64 model of hparma_do (hparma.c:74-157 +
+    compute_svd, util.c:261-386) at t = 128, p_e = 32: t lags x N double multiply-adds; the one-sided
+    Jacobi SVD, >= 12 sweeps x 528 column pairs x (three length-t dot products + the rotation of two
+    columns of the t x 33 matrix and of the 33 x 33 accumulator); Horner over N/2+1 bins x 33
+    coefficients, complex.  A LOWER bound (12 sweeps is the minimum the reference runs)."""
+    n, frames, kernel_ms = res["n"], res["frames"], res["kernel_ms"]
+    t_, ncol = 128, 33
+    flops = 2.0 * t_ * n + 12 * (ncol * (ncol - 1) / 2) * (3 * 2 * t_ + 6 * t_ + 6 * ncol) + (n / 2 + 1) * ncol * 8
+    tf = frames * flops / (kernel_ms * 1e-3) / 1e12
+    return {"model": "counted FP64 flops of hparma_do, lower bound (12 Jacobi sweeps)", "flops_per_frame_f64": flops,
+            "achieved_TFLOPs": tf, "peak_TFLOPs": 78.6, "frac": tf / 78.6,
+            "note": "latency-bound: one wavefront per frame walks the Jacobi rotations in the reference's order"}
+
+
+def parity_vs_oracle(torch, G, workload, local, frames=64):
+    """max|d|/max and L2 error of the HIP rows against the CPU oracle on the first
+    `frames` frames of the workload's synthetic stream (seed 0) -- the checker beside the number, not
+    in the timed region."""
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _signals import synth
+    import numpy as np
+    name, n, overlap, nw, kmax, _, _ = WORKLOADS[workload]
+    sp = G.Spectrogram(make_params(G, workload), device=local)
+    x = synth(frames * sp.hop, fs=8000.0 if workload == "fft1k" else 48000.0, seed=0)
+    got = sp.run(torch.from_numpy(x).to("cuda:%d" % local)).cpu().numpy().astype(np.float64)
+    sp.close()
+    if workload in ("mtm", "mtm16k", "mtm75"):
+        want = O.spectrogram_mtm(x, n, overlap, nw, kmax)
+    elif workload == "hparma":
+        want = O.spectrogram_hparma(x, n, overlap, 128, 32)
+    else:
+        want = O.spectrogram_fft(x, n, overlap, O.WINDOWS["hanning"])
+    want = want.astype(np.float64)
+    d = got - want
+    per_frame_max = np.abs(d).max(axis=1) / np.abs(want).max(axis=1)
+    per_frame_l2 = np.sqrt((d * d).sum(axis=1) / (want * want).sum(axis=1))
+    return {"max_rel": float(per_frame_max.max()), "l2_rel": float(per_frame_l2.max()), "frames": int(got.shape[0]),
+            "against": "oracle/glfer_oracle.c (CPU restatement pinned bit-exact to the reference's fft_radix2.c / g-l_dpss.c objects)",
+            "norms": "per frame max|d|/max(ref) and ||d||2/||ref||2, worst frame", "tolerance": 1e-5}
+
+
+# the default run's secondary rows (BASELINE.json configs other than the headline): workload -> timed steps
+SECONDARY = (("fft1k", 5), ("fft", 5), ("mtm75", 5), ("mtm16k", 5), ("hparma", 5))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +363,8 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's default)")
     ap.add_argument("--workload", default="mtm", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary rows (C1, C2, C3 at 75 %% overlap, C4, C5) and the parity object")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -215,6 +388,7 @@ def main():
     rehearse = os.environ.get("GLFER_BENCH_REHEARSE") == "1"
     if rehearse:
         local = 0
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if rehearse:
@@ -223,113 +397,38 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
-    name, n, overlap, nw, kmax, default_frames, cpu_frames = WORKLOADS[args.workload]
-    if args.workload in ("mtm", "mtm16k", "mtm75"):
-        params = G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax)
-    elif args.workload == "hparma":
-        params = G.HparmaParams(n=n, overlap=overlap, t=128, p_e=32)
-    else:
-        params = G.FftParams(n=n, window_type=G.WINDOWS["hanning"], overlap=overlap)
-    frames = args.frames or default_frames          # a 2^30-sample stream per GPU
-    sp = G.Spectrogram(params, device=local)
-    hop, bins = sp.hop, sp.bins
-    # Weak scaling: the job is world*frames frames of one long stream; this rank owns the
-    # contiguous frame range frame_range() gives it and holds only the samples of its window
-    # (its hops + the N-H history halo on the left; the stream starts with zero history).
-    from glfer_amd.shard import frame_range, run_shard, sample_window
-    first, count = frame_range(frames * world, rank, world)
-    begin, end = sample_window(first, count, hop, n)
-    shard = synth_on_device(torch, end - begin, dev, seed=rank)
-    psd = torch.empty((count, bins), dtype=torch.float32, device=dev)
-
-    def step():
-        run_shard(sp, shard, begin, first, count, out=psd)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # events on the stream the kernels are launched on (run_shard hands torch's current stream
-    # to the C-ABI, and torch.cuda.Event records on that same stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()
-        step()
-        b.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+    res = measure(torch, G, dist, args.workload, args.frames, args.steps, args.warmup, world, rank, local, rehearse)
 
     if rank == 0:
-        total_frames = frames * world * args.steps
-        fps = total_frames / dt
-        b_alg = 4 * hop + 4 * bins                      # compulsory read of H new samples + P bins out
-        achieved = frames * b_alg / (kernel_ms * 1e-3) / 1e9
-        ntap = sp.ntapers
+        frames, n, hop, b_alg, kernel_ms = res["frames"], res["n"], res["hop"], res["b_alg"], res["kernel_ms"]
         kernel, pmc_name = KERNELS[args.workload]
         # measured HBM bytes per frame of this kernel, from the committed rocprofv3 PMC passes
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is) -- see profiles/
-        traffic, traffic_src, valu_instr = None, None, None
-        for rnd in ("r02_", "r01_"):
-            try:
-                prof = json.load(open(os.path.join(ROOT, "profiles", rnd + pmc_name)))
-                traffic = prof["hbm_traffic_bytes_per_frame_corrected"] * frames
-                traffic_src = "profiles/" + rnd + pmc_name
-                # VALU wavefront-instructions per frame, counted by the hardware (SQ_INSTS_VALU pass of the same command)
-                valu_instr = prof.get("sq_counters_per_launch", {}).get("SQ_INSTS_VALU")
-                if valu_instr is not None:
-                    valu_instr /= prof["frames_per_launch"]
-                break
-            except Exception:
-                pass
+        prof, traffic_src = pmc_summary(pmc_name)
+        traffic = prof["hbm_traffic_bytes_per_frame_corrected"] * frames if prof else None
+        # VALU wavefront-instructions per frame, counted by the hardware (SQ_INSTS_VALU pass of the same command)
+        valu_instr = prof.get("sq_counters_per_launch", {}).get("SQ_INSTS_VALU") if prof else None
+        if valu_instr is not None:
+            valu_instr /= prof["frames_per_launch"]
         line = {
             "metric": METRICS[args.workload],
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": res["fps"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU)" if rehearse else ""),
-            "config": {"workload": name, "frames_per_gpu_per_step": frames, "n": n, "hop": hop,
-                       "tapers": ntap, "sharding": "frame ranges, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "config": {"workload": res["name"], "frames_per_gpu_per_step": frames, "n": n, "hop": hop,
+                       "tapers": res["ntapers"], "sharding": "frame ranges, no collective"},
+            "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch, rocprofv3 PMC (%s)" % traffic_src,
                          "algorithmic_bytes_per_launch": frames * b_alg,
                          "kernel": kernel,
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_frame": b_alg,
-                         "note": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac"},
-            "hbm_gbs_aggregate": fps * b_alg / 1e9,
+                         "note": ROOFLINE_NOTES.get(args.workload, "")},
+            "hbm_gbs_aggregate": res["fps"] * b_alg / 1e9,
         }
-        # FP32 VALU view of the same launch: butterflies 3*M*log2(M) per complex M-point transform
-        # + inter-pass twiddles, taper multiply and |Z|^2.  MTM at N <= 4096: one N-point transform
-        # per taper PAIR, the odd taper shared by two frames (ntap/2 transforms per frame);
-        # periodogram and MTM at N >= 8192: one N/2-point transform per taper + the real-input
-        # split (8 ops per bin)
-        import math
-        m = n // 2
-        real_input = 3 * m * math.log2(m) + 4 * (m - m // 64) + 2 * m + 8 * m
-        if args.workload == "fft":
-            lane_ops = real_input
-        elif args.workload == "mtm16k":
-            lane_ops = ntap * real_input
-        else:
-            lane_ops = (ntap / 2.0) * (3 * n * math.log2(n) + 4 * (n - n // 64) + 2 * n + 2 * n)
-        line["valu"] = {"lane_ops_per_frame": lane_ops, "achieved_Tops": frames * lane_ops / (kernel_ms * 1e-3) / 1e12,
-                        "peak_Tops": VALU_PEAK_TOPS,
-                        "frac": frames * lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
-                        "measured_stream_Tops": VALU_STREAM_TOPS,
-                        "frac_of_measured_stream": frames * lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_STREAM_TOPS}
+        line["valu"] = valu_view(res)
         if valu_instr is not None:
             # The same in the hardware's own count: VALU wavefront-instructions per frame (SQ_INSTS_VALU / frames,
             # committed PMC pass) x frames / kernel time, per CU and clock.  Nominal peak 2 (four SIMDs, a wave64 f32
@@ -341,20 +440,30 @@ def main():
                                      "measured_stream_per_cu_clock": VALU_STREAM_TOPS * 1e12 / 64 / 256 / (CLOCK_GHZ * 1e9),
                                      "clock_ghz": CLOCK_GHZ, "source": "SQ_INSTS_VALU, rocprofv3 PMC (%s)" % traffic_src}
         if args.workload == "hparma":
-            # HP-ARMA is neither HBM- nor FP32-bound: a counted FP64 model of hparma_do (hparma.c:74-157 +
-            # compute_svd, util.c:261-386) at t = 128, p_e = 32: t lags x N double multiply-adds; the
-            # one-sided Jacobi SVD, >= 12 sweeps x 528 column pairs x (three length-t dot products + the
-            # rotation of two columns of the t x 33 matrix and of the 33 x 33 accumulator); Horner over
-            # N/2+1 bins x 33 coefficients, complex.  A LOWER bound (12 sweeps is the minimum the reference runs).
-            t_, ncol = 128, 33
-            flops = 2.0 * t_ * n + 12 * (ncol * (ncol - 1) / 2) * (3 * 2 * t_ + 6 * t_ + 6 * ncol) + (n / 2 + 1) * ncol * 8
-            line["valu"] = {"model": "counted FP64 flops of hparma_do, lower bound (12 Jacobi sweeps)", "flops_per_frame_f64": flops,
-                            "achieved_TFLOPs": frames * flops / (kernel_ms * 1e-3) / 1e12, "peak_TFLOPs": 78.6,
-                            "frac": frames * flops / (kernel_ms * 1e-3) / 1e12 / 78.6,
-                            "note": "latency-bound: one wavefront per frame walks the Jacobi rotations in the reference's order"}
-            line["roofline"]["note"] = "not HBM-bound (24.6 KB per frame of algorithmic traffic): see valu (FP64)"
+            line["valu"] = hparma_view(res)
+
+    # ---- the other BASELINE.json configs, each timed the same way for a few steps (N = 1 only: they are
+    # single-GPU rows; every rank would have to take part in their barriers otherwise)
+    if world == 1 and not args.no_secondary and args.workload == "mtm":
+        rows = []
+        for wl, k in SECONDARY:
+            r = measure(torch, G, dist, wl, 0, k, 1, world, rank, local, rehearse)
+            row = {"workload": r["name"], "key": wl, "value": r["fps"], "unit": "frames/s", "steps": k, "warmup": 1,
+                   "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"], "kernel": KERNELS[wl][0],
+                   "frames_per_step": r["frames"],
+                   "roofline": {"bound": "hbm", "achieved": r["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": r["achieved_gbs"] / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": r["b_alg"],
+                                "note": ROOFLINE_NOTES.get(wl, "")}}
+            v = hparma_view(r) if wl == "hparma" else valu_view(r)
+            row["valu_frac"] = v["frac"]
+            rows.append(row)
+        line["secondary"] = rows
+        line["parity"] = parity_vs_oracle(torch, G, args.workload, local)
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            _, n, overlap, nw, kmax, _, cpu_frames = WORKLOADS[args.workload]
             line["cpu_baseline"] = cpu_baseline(args.workload, n, overlap, nw, kmax, cpu_frames)
+            line["cpu_baseline"]["cpu_model"] = cpu_model()
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

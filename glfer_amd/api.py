@@ -137,6 +137,12 @@ def lib():
     L.glfer_hip_waterfall_device.argtypes = [C.POINTER(Display), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, C.c_int,
                                              vp, vp, vp, vp]
     L.glfer_hip_waterfall_host.argtypes = [vp, C.POINTER(Display), vp, sz, vp, vp, C.POINTER(sz)]
+    L.glfer_hip_scratch_trim.argtypes = [C.c_int, sz]
+    L.glfer_hip_scratch_trim.restype = sz
+    L.glfer_hip_scratch_held.argtypes = [C.c_int]
+    L.glfer_hip_scratch_held.restype = sz
+    L.glfer_hip_scratch_limit.argtypes = [sz]
+    L.glfer_hip_scratch_limit.restype = None
     for f in ("glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version"):
         getattr(L, f).restype = C.c_char_p
     L.glfer_hip_strerror.argtypes = [C.c_int]

@@ -90,6 +90,7 @@ struct BigBlock {
   hipEvent_t freed = nullptr;
   hipStream_t last = nullptr;
   bool used = false;                                 // an event has been recorded on it
+  int dev = -1;                                      // the device it was allocated on
 };
 struct DeviceScratch {
   bool init = false;
@@ -98,6 +99,38 @@ struct DeviceScratch {
 };
 std::mutex g_scratch_mu;
 DeviceScratch g_scratch[64];
+// Bytes of kept blocks per device above which IDLE blocks are given back before a new one is made
+// (GLFER_SCRATCH_CAP_MB; default 16 GiB of a 288 GB card; glfer_hip_scratch_limit sets it at run time).
+// A single request larger than the cap is still served -- by a kept block that is the only one.
+size_t g_scratch_cap = [] {
+  const char *e = getenv("GLFER_SCRATCH_CAP_MB");
+  return e && *e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)16 << 30;
+}();
+// Frees one idle kept block (after the work recorded on it has completed).  Caller holds the mutex
+// and has the block's device current.
+void drop_block(BigBlock &b) {
+  if (b.used) (void)hipEventSynchronize(b.freed);
+  (void)hipFree(b.p);
+  (void)hipEventDestroy(b.freed);
+  b = BigBlock();
+}
+// Idle kept blocks of a device, smallest first, until at most `keep_bytes` stay (blocks that are out
+// with a call stay and count).  Returns the bytes freed.
+size_t trim_locked(DeviceScratch &ds, size_t keep_bytes) {
+  size_t held = 0, freed = 0;
+  for (BigBlock &b : ds.big)
+    if (b.p) held += b.cap;
+  while (held > keep_bytes) {
+    BigBlock *victim = nullptr;
+    for (BigBlock &b : ds.big)
+      if (b.p && !b.out && (!victim || b.cap < victim->cap)) victim = &b;
+    if (!victim) break;
+    held -= victim->cap;
+    freed += victim->cap;
+    drop_block(*victim);
+  }
+  return freed;
+}
 bool scratch_cache_on() {
   static const bool on = [] {
     const char *e = getenv("GLFER_SCRATCH_CACHE");
@@ -153,21 +186,32 @@ hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st) {
       for (BigBlock &b : ds.big)
         if (!b.out && b.cap < want && (!victim || b.cap < victim->cap)) victim = &b;
       if (victim) {
-        if (victim->used) (void)hipEventSynchronize(victim->freed);
-        (void)hipFree(victim->p);
-        (void)hipEventDestroy(victim->freed);
-        *victim = BigBlock();
+        drop_block(*victim);
         empty = victim;
       }
     }
     if (!best && empty) {                            // a new kept block (synchronous hipMalloc: once per size class)
+      // the byte cap: idle blocks go first (none of them fits -- `best` would have been one)
+      size_t held = 0;
+      for (BigBlock &b : ds.big)
+        if (b.p) held += b.cap;
+      if (held + want > g_scratch_cap) trim_locked(ds, g_scratch_cap > want ? g_scratch_cap - want : 0);
       void *q = nullptr;
       hipEvent_t ev = nullptr;
-      if (hipMalloc(&q, want) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+      hipError_t me = hipMalloc(&q, want);
+      if (me != hipSuccess) {                        // out of memory: every idle kept block goes back, then once more
+        (void)hipGetLastError();
+        q = nullptr;
+        if (trim_locked(ds, 0) > 0) me = hipMalloc(&q, want);
+        for (BigBlock &b : ds.big)                   // the slot may have moved: any empty one will do
+          if (!b.p) { empty = &b; break; }
+      }
+      if (me == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
         empty->p = q;
         empty->cap = want;
         empty->freed = ev;
         empty->used = false;
+        empty->dev = dev;
         best = empty;
       } else {
         (void)hipGetLastError();
@@ -198,14 +242,55 @@ void scratch_free(void *q, hipStream_t st) {
     for (DeviceScratch &ds : g_scratch)
       for (BigBlock &b : ds.big)
         if (b.p == q) {
-          if (hipEventRecord(b.freed, st) != hipSuccess) (void)hipGetLastError();
-          b.used = true;
-          b.last = st;
+          // the event is recorded on the stream that used the block -- a stream of the block's own
+          // device, which need not be the caller's current one
+          int cur = -1;
+          const bool moved = hipGetDevice(&cur) == hipSuccess && cur != b.dev && b.dev >= 0 && hipSetDevice(b.dev) == hipSuccess;
+          if (hipEventRecord(b.freed, st) == hipSuccess) {
+            b.used = true;
+            b.last = st;
+          } else {
+            // no event to order the next taker behind: wait here for the work on `st`, after which
+            // the block is free for any stream (used = false: nothing to wait for)
+            (void)hipGetLastError();
+            if (hipStreamSynchronize(st) != hipSuccess) {
+              (void)hipGetLastError();               // not even that: the block leaves the cache for good
+              (void)hipDeviceSynchronize();
+              (void)hipFree(b.p);
+              (void)hipEventDestroy(b.freed);
+              b = BigBlock();
+              if (moved) (void)hipSetDevice(cur);
+              return;
+            }
+            b.used = false;
+            b.last = nullptr;
+          }
           b.out = false;
+          if (moved) (void)hipSetDevice(cur);
           return;
         }
   }
   (void)hipFreeAsync(q, st);
+}
+
+// glfer_hip_scratch_trim / glfer_hip_scratch_limit (include/glfer_hip.h)
+size_t scratch_trim(int dev, size_t keep_bytes) {
+  if (dev < 0 || dev >= 64) return 0;
+  DeviceGuard guard(dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  return trim_locked(g_scratch[dev], keep_bytes);
+}
+size_t scratch_held(int dev) {
+  if (dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  size_t held = 0;
+  for (BigBlock &b : g_scratch[dev].big)
+    if (b.p) held += b.cap;
+  return held;
+}
+void scratch_set_cap(size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  g_scratch_cap = bytes;
 }
 
 // Dynamic LDS above the default limit has to be allowed per kernel -- and per DEVICE: a process that
@@ -388,7 +473,11 @@ int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, in
   }
   tile = std::min(tile, nframes);
   tile = (nframes + (nframes + tile - 1) / tile - 1) / ((nframes + tile - 1) / tile);   // equal tiles: no short last one
-  if (fused) fused = glfer_avgmap_applies(tile, bins, depth, minbin, maxbin) != 0;
+  // the form's chunking depends on the number of rows it walks, and the last tile may be a few rows
+  // shorter than the others: the fused form is taken only if it applies to BOTH lengths
+  const size_t last_tile = nframes - (nframes - 1) / tile * tile;
+  if (fused) fused = glfer_avgmap_applies(tile, bins, depth, minbin, maxbin) != 0 &&
+                     glfer_avgmap_applies(last_tile, bins, depth, minbin, maxbin) != 0;
   const size_t back = averaging ? (size_t)depth : 0;       // rows re-read in front of a tile to restart the sliding sums
   float *stats = d_stats;
   double *avg = nullptr, *ret = nullptr;
@@ -430,6 +519,10 @@ int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, in
   if (!d_stats) glfer::scratch_free(stats, st);
   return rc;
 }
+
+size_t glfer_hip_scratch_trim(int device, size_t keep_bytes) { return glfer::scratch_trim(device, keep_bytes); }
+size_t glfer_hip_scratch_held(int device) { return glfer::scratch_held(device); }
+void glfer_hip_scratch_limit(size_t bytes) { glfer::scratch_set_cap(bytes); }
 
 const char *glfer_hip_strerror(int code) {
   switch (code) {
@@ -1012,12 +1105,11 @@ static void fill_params(const glfer_hip_plan *p, SpectroParams &sp) {
 // the last hop is rebuilt from the corrected previous hop before its own mean is taken.
 static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t first, size_t nframes, hipStream_t st,
                            float **scratch_out, long tail_fresh = -1) {
-  const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop);
-  // ZERO_ALWAYS frames use only their own hop -- but the kernels that take frames lying wholly inside
-  // the stream LOAD a frame's history before they zero it (spectro16h/x/xl/y: unconditional loads,
-  // masked afterwards), so the copy reaches back over the history hops in that mode too: a copy that
-  // began at the frame's own hop had them read below the allocation (a fault, or not, with the
-  // allocator's mood: found by the 600-case fuzz sweep once the pool kept its memory).
+  // ZERO_ALWAYS frames use only their own hop, and no kernel loads the history it would zero
+  // (round 3: odd_taper.hpp::load_frame16, spectro16h / spectro16w's HIST gathers start their
+  // descriptor at the frame's own hop), so the copy starts there too -- a piece cut for that mode
+  // carries no history below its first hop (glfer_hip.h, "Cutting a stream", rule 2).
+  const size_t hops_back = sp.history_mode ? 0 : (size_t)((p->keep + p->hop - 1) / p->hop);
   size_t hop_lo = (first > hops_back) ? first - hops_back : 0;
   const size_t last = first + nframes - 1;
   if (tail_fresh >= 0 && last > 0 && hop_lo > last - 1) hop_lo = last - 1;   // the stale part needs the hop before

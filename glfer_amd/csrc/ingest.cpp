@@ -438,6 +438,12 @@ int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned devic
 static unsigned rd_u16(const unsigned char *b) { return b[0] | (b[1] << 8); }
 static unsigned rd_u32(const unsigned char *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24); }
 
+// The reference takes the header as one fixed 44-byte struct (wav_fmt.h:34-52: "fmt " at byte 12, "data"
+// at byte 36, samples from byte 44) and reads samples until read() returns 0.  Files written by anything
+// but the simplest tools carry other chunks ("LIST", "fact", "bext" ...) before or after "data", which
+// that layout would play as samples: the chunks are walked here (id + 32-bit little-endian size, padded
+// to even), "fmt " gives the format fields, "data" the offset and length.  A file whose chunks cannot
+// be walked (no "WAVE" tag, no "data" chunk, sizes running past the end) is read the reference's way.
 int glfer_hip_wav_probe(const char *path, glfer_wav_info *info) {
   if (!path || !info) return GLFER_E_ARG;
   FILE *f = fopen(path, "rb");
@@ -446,19 +452,51 @@ int glfer_hip_wav_probe(const char *path, glfer_wav_info *info) {
   const size_t got = fread(hd, 1, sizeof hd, f);
   long end = 0;
   if (fseek(f, 0, SEEK_END) == 0) end = ftell(f);
+  if (got < sizeof hd || memcmp(hd, "RIFF", 4) != 0) {           // "input file less than 20 bytes long" /
+    fclose(f);                                                   // "input file not in WAV format", wav_fmt.c:61-64
+    return GLFER_E_ARG;
+  }
+  // the reference's fixed layout, the fallback
+  const unsigned char *fmt = hd + 20;                            // wav_fmt.h:42-47
+  size_t data_offset = 44, data_bytes = end > 44 ? (size_t)(end - 44) : 0;
+  unsigned char fm[16];
+  if (memcmp(hd + 8, "WAVE", 4) == 0) {
+    long pos = 12;
+    bool have_fmt = false, have_data = false;
+    size_t d_off = 0, d_len = 0;
+    while (pos + 8 <= end) {
+      unsigned char ck[8];
+      if (fseek(f, pos, SEEK_SET) != 0 || fread(ck, 1, 8, f) != 8) break;
+      const size_t len = rd_u32(ck + 4);
+      if (memcmp(ck, "fmt ", 4) == 0 && len >= 16 && !have_fmt) {
+        if (fread(fm, 1, 16, f) != 16) break;
+        have_fmt = true;
+      } else if (memcmp(ck, "data", 4) == 0) {
+        d_off = (size_t)pos + 8;
+        const size_t left = (size_t)end - d_off;
+        // a recorder that was cut off leaves 0 or 0xffffffff here: the data then runs to the end of the file
+        d_len = (len == 0 || len == 0xffffffffu || len > left) ? left : len;
+        have_data = true;
+        break;                                                   // what follows "data" is not samples
+      }
+      pos += 8 + (long)len + (long)(len & 1);
+    }
+    if (have_fmt && have_data) {
+      fmt = fm;
+      data_offset = d_off;
+      data_bytes = d_len;
+    }
+  }
   fclose(f);
-  if (got < sizeof hd) return GLFER_E_ARG;                       // "input file less than 20 bytes long", wav_fmt.c:61-62
-  if (memcmp(hd, "RIFF", 4) != 0) return GLFER_E_ARG;            // "input file not in WAV format", wav_fmt.c:63-64
-  info->format = (int)rd_u16(hd + 20);                           // wav_fmt.h:42
-  info->channels = (int)rd_u16(hd + 22);                         // wav_fmt.h:43
-  info->sample_rate = (int)rd_u32(hd + 24);                      // wav_fmt.h:44  -> *speed, wav_fmt.c:70
-  info->bits_per_sample = (int)rd_u16(hd + 34);                  // wav_fmt.h:47  -> bits, wav_fmt.c:71
-  info->data_offset = 44;
+  info->format = (int)rd_u16(fmt + 0);                           // wav_fmt.h:42
+  info->channels = (int)rd_u16(fmt + 2);                         // wav_fmt.h:43
+  info->sample_rate = (int)rd_u32(fmt + 4);                      // wav_fmt.h:44  -> *speed, wav_fmt.c:70
+  info->bits_per_sample = (int)rd_u16(fmt + 14);                 // wav_fmt.h:47  -> bits, wav_fmt.c:71
+  info->data_offset = data_offset;
   if (info->format != 1) return GLFER_E_ARG;                     // "input is not a PCM WAV file", wav_fmt.c:68-69
   if (info->bits_per_sample != 8 && info->bits_per_sample != 16) return GLFER_E_ARG;   // wav_fmt.c:87-96 handles only these
-  const size_t avail = end > 44 ? (size_t)(end - 44) : 0;
-  info->data_bytes = avail;
-  info->nsamples = avail / (size_t)(info->bits_per_sample / 8);  // the reference reads until read() returns 0
+  info->data_bytes = data_bytes;
+  info->nsamples = data_bytes / (size_t)(info->bits_per_sample / 8);
   return GLFER_OK;
 }
 

@@ -24,6 +24,24 @@ __device__ __forceinline__ void load_frame16(const SpectroParams &p, unsigned t,
   const long long f = fblk + fl;
   const unsigned flc = f < p.nframes ? fl : (unsigned)(p.nframes - 1 - fblk);
   const long long sblk = (p.frame0 + fblk) * (long long)p.H - p.R;
+  if (HIST == 1 || (HIST < 0 && p.history_mode)) {
+    // ZERO_ALWAYS: a frame is R zeros + its own hop (fft.c:99-108), and a piece cut for that mode
+    // carries NO history (glfer_hip.h, "Cutting a stream", rule 2) -- so the history is never
+    // loaded: the descriptor starts at the block's own first hop and the history registers get an
+    // out-of-range offset (they read 0 by the range check; the select is for u8, whose raw 0 is
+    // not sample 0.0).
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + (sblk + p.R) * (long long)esz, 0, 0x7fffffff, 0x00020000);
+    const int d = (int)t - p.R;                       // sample t + T*m of the frame is kept iff d + T*m >= 0
+    const int lrel = (int)(flc * (unsigned)p.H) + d;
+    static_for<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const bool ok = d >= -T * m;
+      const float x = buf_sample<FMT>(hrsrc, ok ? (unsigned)(lrel + T * m) * esz : 0x80000000u, 0u);
+      dst[m] = ok ? x : 0.0f;
+    });
+    return;
+  }
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
   const unsigned lrel = flc * (unsigned)p.H + t;
@@ -31,13 +49,6 @@ __device__ __forceinline__ void load_frame16(const SpectroParams &p, unsigned t,
     constexpr int m = decltype(mc)::value;
     dst[m] = buf_sample<FMT>(xrsrc, lrel * esz, (unsigned)(T * m) * esz);
   });
-  if (HIST == 1 || (HIST < 0 && p.history_mode)) {
-    const int d = (int)t - p.R;
-    static_for<0, 16>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      dst[m] = (d >= -T * m) ? dst[m] : 0.0f;
-    });
-  }
 }
 
 // Sum over the wavefront by DPP (row_shr 1,2,4,8 leave a row's sum in its lane 15, row_bcast 15 / 31

@@ -46,6 +46,10 @@ int device_of(const void *d_ptr);
 // request).  Always given back through scratch_free on the stream that used it.
 hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st);
 void scratch_free(void *p, hipStream_t st);
+// idle kept blocks of `dev` given back until at most keep_bytes stay / bytes kept now / the per-device cap
+size_t scratch_trim(int dev, size_t keep_bytes);
+size_t scratch_held(int dev);
+void scratch_set_cap(size_t bytes);
 
 // Allow `bytes` of dynamic LDS for `kernel` on the current device (hipFuncSetAttribute, once per
 // device, kernel and size class).

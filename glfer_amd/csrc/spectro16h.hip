@@ -182,6 +182,30 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
     const unsigned lrel = relc * (unsigned)p.H + 2u * t;
+    if constexpr (HIST != 0) {
+      // ZERO_ALWAYS: the history is never loaded (a piece cut for this mode carries none: glfer_hip.h,
+      // "Cutting a stream", rule 2).  The descriptor starts at the range's own first hop; pairs that
+      // lie in the history get an out-of-range offset and read 0 -- prefetch_x puts the format's
+      // zero there.  H is even on this kernel (pairs are naturally aligned), so R is, and no pair
+      // straddles the history's end.
+      const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + (sblk + p.R) * (long long)esz, 0, 0x7fffffff, 0x00020000);
+      const int d = 2 * (int)t - p.R;
+      const int hrel = (int)(relc * (unsigned)p.H) + d;
+      static_for<FROM, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value, q = (m + ROT) & 15;
+        const bool ok = d >= -2 * T * m;
+        const unsigned off = ok ? (unsigned)(hrel + 2 * T * m) * (unsigned)esz : 0x80000000u;
+        if constexpr (FMT == GLFER_FMT_F32) {
+          px[q] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(hrsrc, off, 0u, 0));
+        } else if constexpr (FMT == GLFER_FMT_S16) {
+          px[q].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(hrsrc, off, 0u, 0));
+        } else {
+          px[q].x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(hrsrc, off, 0u, 0));
+        }
+      });
+      return;
+    }
     // y[2n] and y[2n+1] are adjacent: ONE load per pair in every format (the launcher sends streams
     // whose pairs are not naturally aligned to spectro16.hip)
     static_for<FROM, 16>([&](auto mc) {

@@ -209,6 +209,28 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
       });
       return;
     }
+    if constexpr (HIST != 0) {
+      // ZERO_ALWAYS: the history is never loaded (a piece cut for this mode carries none: glfer_hip.h,
+      // "Cutting a stream", rule 2): descriptor at the block's own first hop, history pairs out of
+      // range (they read 0; the masks below put the format's zero there).  R is even here (pairs).
+      const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + (sblk + p.R) * (long long)esz, 0, 0x7fffffff, 0x00020000);
+      const int d = 2 * (int)(W * t + w) - p.R;
+      const int hrel = (int)(flc * (unsigned)p.H) + d;
+      static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int off = 2 * W * 64 * m;
+        const bool ok = d + off >= 0;
+        const unsigned vo = ok ? (unsigned)(hrel + off) * (unsigned)esz : 0x80000000u;
+        if constexpr (FMT == GLFER_FMT_F32) {
+          px[m] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(hrsrc, vo, 0u, 0));
+        } else if constexpr (FMT == GLFER_FMT_S16) {
+          px[m].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(hrsrc, vo, 0u, 0));
+        } else {
+          px[m].x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(hrsrc, vo, 0u, 0));
+        }
+      });
+    } else
     static_for<0, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       constexpr unsigned off = 2u * W * 64u * m;           // samples

@@ -100,7 +100,9 @@ typedef struct glfer_hip_config {
  * (2) A piece that starts at frame f > 0 must hold, to the left of sample f*H, the N-H history
  *     ROUNDED UP TO WHOLE HOPS: ceil((N-H)/H)*H samples.  Whole hops because per-hop mean removal
  *     (cfg.sub_mean, fft.c:86-96) corrects every history sample by the mean of the hop it arrived
- *     in, so the engine reads complete hops back.  (history_mode ZERO_ALWAYS needs no history.)
+ *     in, so the engine reads complete hops back.  (history_mode ZERO_ALWAYS needs no history, and
+ *     no kernel loads any: the gathers of that mode start at the frame's own hop -- a piece may
+ *     begin at the first byte of its allocation; tests/test_gpu_round3.py.)
  *     LMP mode adds lmp_av-1 hops: the frames its ring still holds are recomputed, not carried.
  *     The device entries take the stream's VIRTUAL base (address of sample 0), so a piece is
  *     passed as  d_piece - begin*sample_size  with frame indices left global.
@@ -217,15 +219,18 @@ int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *d
  * The canonical 44-byte RIFF/WAVE header of wav_fmt.h:34-52, read with fixed-width fields
  * (the reference's struct uses u_long and mis-parses every file on LP64 hosts).  As in the
  * reference only PCM (format 1) with 8 or 16 bits per sample is accepted and the channel
- * count is not interpreted: interleaved channels are treated as one sample stream. */
+ * count is not interpreted: interleaved channels are treated as one sample stream.  The RIFF
+ * chunks are walked ("fmt ", then "data"; "LIST" / "fact" / ... skipped), so a file with other
+ * chunks before or after its samples is read correctly -- the reference's fixed 44-byte struct
+ * (wav_fmt.h:34-52) would play them as samples; a file that cannot be walked is read its way. */
 typedef struct glfer_wav_info {
   int format;            /* 1 = PCM                                  wav_fmt.h:42 */
   int channels;          /* "modus": 1 mono, 2 stereo                wav_fmt.h:43 */
   int sample_rate;       /* sample_fq                                wav_fmt.h:44 */
   int bits_per_sample;   /* bit_p_spl: 8 or 16                       wav_fmt.h:47 */
-  size_t data_offset;    /* 44                                                     */
-  size_t nsamples;       /* samples present after the header                      */
-  size_t data_bytes;     /* bytes present after the header                        */
+  size_t data_offset;    /* first byte of the "data" chunk's payload (44 in the reference's fixed layout) */
+  size_t nsamples;       /* samples in the data chunk                             */
+  size_t data_bytes;     /* bytes in the data chunk (to the end of the file when the chunk size is 0 / ~0 / too long) */
 } glfer_wav_info;
 int glfer_hip_wav_probe(const char *path, glfer_wav_info *info);
 
@@ -332,6 +337,28 @@ int glfer_hip_waterfall_device(glfer_hip_display *disp, int avg_mode, int depth,
  * instead of 4, and pixels instead of PSD rows.  disp carries the level-tracking state. */
 int glfer_hip_waterfall_host(glfer_hip_plan *plan, glfer_hip_display *disp, const void *h_stream,
                              size_t nsamples, unsigned char *h_rgb, short *h_lev, size_t *nframes_out);
+
+/* Device scratch the library keeps between calls.  Per-call scratch of 16 MiB and more (averaged
+ * rows of a staged waterfall tile, the mean-corrected copy of a stream, big-block and LMP / F-test
+ * spectra) comes from up to six blocks per device that the library allocates with hipMalloc and
+ * KEEPS -- the stream-ordered pool costs milliseconds to seconds per GB-sized request on this stack
+ * (profiles/r02_scratch_tail.txt).  That memory is invisible to the host application's own
+ * allocator, so it is bounded and can be given back:
+ *   glfer_hip_scratch_limit(bytes)        cap per device on kept bytes (default 16 GiB, or
+ *                                         GLFER_SCRATCH_CAP_MB; 0 keeps nothing between calls).  Idle
+ *                                         blocks are freed before a new one would exceed the cap, and
+ *                                         all of them when a hipMalloc for a new block fails.
+ *   glfer_hip_scratch_trim(device, keep)  frees idle kept blocks of `device`, smallest first, until at
+ *                                         most `keep` bytes stay; waits for the work recorded on a
+ *                                         block before freeing it; blocks in use by a running call
+ *                                         stay.  Returns the bytes freed.  (The reference frees its
+ *                                         buffers in fft_close, fft.c:297-306; a GUI host calls this
+ *                                         when a waterfall is closed or the block size changes.)
+ *   glfer_hip_scratch_held(device)        bytes kept right now.
+ * GLFER_SCRATCH_CACHE=0 in the environment disables keeping altogether. */
+size_t glfer_hip_scratch_trim(int device, size_t keep_bytes);
+size_t glfer_hip_scratch_held(int device);
+void glfer_hip_scratch_limit(size_t bytes);
 
 const char *glfer_hip_strerror(int code);
 /* text of the last HIP error seen by this thread ("" if none) */

@@ -1,0 +1,346 @@
+"""GPU parity tests (-m gpu) added in round 3, all through the C-ABI.
+
+* history_mode ZERO_ALWAYS pieces WITHOUT a halo (VERDICT r2 item 3 / ADVICE r2 high): a piece cut by
+  include/glfer_hip.h rule (2) -- no history below its first hop -- living in a device allocation of
+  exactly its own size must give the rows of the full run (fft.c:99-108 with glfer.first_buffer
+  stuck at TRUE: a frame is R zeros + its own hop).
+* adversarial spectral shapes for the kernels that put two frames through one transform
+  (spectro16x / xl / y, mtm.c:189-220): frame pairs (A, B) of EQUAL POWER whose peak factors differ
+  as far as they can -- a bin-centred full-scale tone, a DC frame, a single impulse, silence -> onset
+  -- next to white noise, both orders.  Per frame max|d| / max(ref) <= 1e-5 against the oracle.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _signals import rel_err, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+# ---- device memory of exactly the piece's size (not a slice of torch's cached blocks) ----------------
+class _TightAlloc:
+    """hipMalloc(nbytes) through the HIP runtime itself: the piece starts at the allocation's base,
+    nothing of ours lies below it."""
+
+    _hip = None
+
+    def __init__(self, nbytes):
+        if _TightAlloc._hip is None:
+            _TightAlloc._hip = C.CDLL("libamdhip64.so")
+            _TightAlloc._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            _TightAlloc._hip.hipFree.argtypes = [C.c_void_p]
+            _TightAlloc._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.ptr = C.c_void_p()
+        assert _TightAlloc._hip.hipMalloc(C.byref(self.ptr), nbytes) == 0
+        self.nbytes = nbytes
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host)
+        assert host.nbytes == self.nbytes
+        assert _TightAlloc._hip.hipMemcpy(self.ptr, host.ctypes.data, host.nbytes, 1) == 0   # hipMemcpyHostToDevice
+
+    def free(self):
+        if self.ptr.value:
+            _TightAlloc._hip.hipFree(self.ptr)
+            self.ptr = C.c_void_p()
+
+
+@pytest.mark.parametrize("sub_mean", [0, 1])
+def test_zero_always_pieces_without_a_halo(lib, torch_cuda, sub_mean):
+    """Shards in history_mode ZERO_ALWAYS cut by the documented rule (halo 0), each from a device
+    allocation of exactly its own samples, rank > 0 included: rows identical to the full run."""
+    from glfer_amd.shard import frame_range, halo_samples, sample_window
+    torch = torch_cuda
+    Z = lib.api.HISTORY_ZERO_ALWAYS
+    cases = ((lib.FftParams(n=4096, window_type=1, overlap=0.75, history_mode=Z, sub_mean=sub_mean), 300),      # spectro16h, HIST
+             (lib.MtmParams(n=4096, overlap=0.0, w=2.5, kmax=4, history_mode=Z, sub_mean=sub_mean), 200),        # spectro16y, HIST
+             (lib.MtmParams(n=4096, overlap=0.75, w=2.5, kmax=4, history_mode=Z, sub_mean=sub_mean), 300),
+             (lib.MtmParams(n=1024, overlap=0.5, w=2.5, kmax=4, history_mode=Z, sub_mean=sub_mean), 400),        # spectro16x / xl
+             (lib.MtmParams(n=16384, overlap=0.5, w=4.5, kmax=8, history_mode=Z, sub_mean=sub_mean), 96),        # spectro16w, HIST
+             (lib.FftParams(n=16384, window_type=7, overlap=0.5, history_mode=Z, sub_mean=sub_mean), 96),
+             (lib.FftParams(n=1024, window_type=7, overlap=0.9, history_mode=Z, sub_mean=sub_mean), 333))        # ragged hop
+    for params, frames in cases:
+        sp = lib.Spectrogram(params)
+        assert halo_samples(sp.hop, sp.n, history_mode=1) == 0
+        x = synth(frames * sp.hop, seed=31)
+        full = sp.run(torch.from_numpy(x).cuda())
+        for world in (2, 3):
+            for rank in range(world):
+                first, count = frame_range(frames, rank, world)
+                begin, end = sample_window(first, count, sp.hop, sp.n, history_mode=1)
+                assert begin == first * sp.hop                       # no history below the piece
+                piece = _TightAlloc((end - begin) * 4)
+                try:
+                    piece.upload(x[begin:end])
+                    out = torch.empty((count, sp.bins), dtype=torch.float32, device="cuda")
+                    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    lib.api._check(lib.api.lib().glfer_hip_spectrogram_device(
+                        sp._h, C.c_void_p(piece.ptr.value - begin * 4), end, first, count, out.data_ptr(), st), "shard")
+                    torch.cuda.synchronize()
+                finally:
+                    piece.free()
+                assert torch.equal(out, full[first:first + count]), (type(params).__name__, params.n, world, rank)
+
+
+# ---- adversarial frame shapes for the shared-odd-taper kernels ---------------------------------------
+def _shape(kind, n, rng):
+    """One frame of n samples, before power equalisation."""
+    t = np.arange(n, dtype=np.float64)
+    if kind == "tone":          # bin-centred, full scale: all of its power in ONE bin
+        return 0.999 * np.sin(2 * np.pi * (n // 8) * t / n)
+    if kind == "dc":
+        return np.full(n, 0.9)
+    if kind == "impulse":       # all of its power in ONE sample: flat spectrum, peak factor sqrt(n)
+        x = np.zeros(n)
+        x[n // 3] = 0.999
+        return x
+    if kind == "onset":         # silence, then full scale (what a keyed carrier does under overlap)
+        x = np.zeros(n)
+        x[n // 2:] = 0.999 * np.sin(2 * np.pi * 0.1237 * t[n // 2:])
+        return x
+    if kind == "noise":
+        return rng.standard_normal(n)
+    raise ValueError(kind)
+
+
+def _equal_power_stream(kinds, n, seed):
+    """Frames of the given kinds, back to back, each scaled to the power of the weakest (so the
+    shared transform's power-of-two scales are equal and only the peak factors differ), then to
+    full scale."""
+    rng = np.random.default_rng(seed)
+    frames = [_shape(k, n, rng) for k in kinds]
+    pw = [float(np.mean(f * f)) for f in frames]
+    target = min(pw)
+    frames = [f * np.sqrt(target / p) for f, p in zip(frames, pw)]
+    x = np.concatenate(frames)
+    x *= 0.999 / np.abs(x).max()
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [512, 1024, 4096])
+@pytest.mark.parametrize("kmax", [2, 4, 6])                    # 3, 5, 7 tapers
+def test_shared_odd_taper_adversarial_pairs(lib, oracle, torch_cuda, n, kmax):
+    torch = torch_cuda
+    nw = (kmax + 1) / 2.0
+    worst = 0.0
+    for overlap in (0.0, 0.75):
+        kinds = []
+        for a in ("tone", "dc", "impulse", "onset"):
+            kinds += [a, "noise", "noise", a]                  # (A, B) and (B, A) on the kernels' pair grid
+        kinds += ["tone", "impulse", "dc", "onset", "noise"]   # the shapes against each other; odd count: a lone last frame
+        x = _equal_power_stream(kinds, n, seed=1000 + n + kmax)
+        sp = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax))
+        got = sp.run(torch.from_numpy(x).cuda()).cpu().numpy()
+        want = oracle.spectrogram_mtm(x, n, overlap, nw, kmax)
+        assert got.shape == want.shape
+        for f in range(got.shape[0]):
+            if not want[f].any():                              # digital silence (inside an onset frame's quiet half
+                assert not got[f].any(), (n, kmax, overlap, f)  # under overlap): exactly 0 in the reference, and here
+                continue
+            e_max, e_l2 = rel_err(got[f], want[f])
+            worst = max(worst, e_max)
+            assert e_max <= TOL and e_l2 <= TOL, (n, kmax, overlap, f, e_max, e_l2)
+    print("adversarial pairs N=%d T=%d: worst max|d|/max %.2e" % (n, kmax + 1, worst))
+
+
+def test_shared_odd_taper_adversarial_mean_removal(lib, oracle, torch_cuda):
+    """The same pairs with per-hop mean removal on (the reference's default, glfer.c:275): a DC frame
+    becomes (nearly) silence next to a loud partner -- the scale-0 / tiny-scale corner.
+
+    Bound.  fft.c:88-92 sums a hop's samples one after the other in a float: with a DC level of the
+    order of the signal itself that sum carries ~sqrt(H) roundings at ulp(H * dc), so the mean the
+    reference subtracts is ~1e-6 (relative) away from the hop's true mean, and differently so for
+    every input -- move every sample by at most one float ulp and the roundings are drawn afresh.  A
+    parallel sum cannot reproduce those roundings (and the sequential one costs a second pass over
+    the stream).  Frames in which a DC hop sits next to a signal hop show that residual step at the
+    low bins, so they are held to the bound this repo uses for every ill-conditioned output
+    (test_gpu_round2.py): max(1e-5, 3 x the largest movement of the ORACLE's own rows under such
+    1-ulp perturbations); frames without a DC hop must meet 1e-5 as everywhere."""
+    torch = torch_cuda
+    n, kmax, nw = 4096, 4, 2.5
+    kinds = ["dc", "noise", "noise", "dc", "tone", "dc", "dc", "impulse", "onset", "dc"]
+    x = _equal_power_stream(kinds, n, seed=77)
+    rng = np.random.default_rng(5)
+    for overlap in (0.0, 0.5):
+        sp = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=1))
+        got = sp.run(torch.from_numpy(x).cuda()).cpu().numpy()
+        want = oracle.spectrogram_mtm(x, n, overlap, nw, kmax, sub_mean=1)
+        spread = np.zeros(want.shape[0])
+        for _ in range(6):
+            step = (rng.integers(0, 3, x.size) - 1).astype(np.float32)
+            xp = np.nextafter(x, x + step).astype(np.float32)
+            alt = oracle.spectrogram_mtm(xp, n, overlap, nw, kmax, sub_mean=1).astype(np.float64)
+            spread = np.maximum(spread, np.abs(alt - want).max(axis=1) / np.maximum(np.abs(want).max(axis=1), 1e-300))
+        # which frames contain a DC hop (frame f covers samples [f*H - (N-H), f*H + H))
+        hop = sp.hop
+        is_dc = np.repeat(np.array([k == "dc" for k in kinds]), n)
+        top = np.abs(want).max()
+        worst_plain, worst_dc = 0.0, 0.0
+        for f in range(got.shape[0]):
+            lo, hi = max(0, f * hop - (n - hop)), f * hop + hop
+            has_dc = bool(is_dc[lo:hi].any())
+            ref_max = np.abs(want[f]).max()
+            if ref_max < 1e-9 * top:
+                # all DC: ~0 after mean removal; its own maximum is rounding noise in both implementations
+                assert np.abs(got[f]).max() <= 1e-9 * top, (overlap, f)
+                continue
+            e_max, e_l2 = rel_err(got[f], want[f])
+            if has_dc:
+                worst_dc = max(worst_dc, e_max)
+                assert e_max <= max(TOL, 3.0 * spread[f]), (overlap, f, e_max, spread[f])
+            else:
+                worst_plain = max(worst_plain, e_max)
+                assert e_max <= TOL and e_l2 <= TOL, (overlap, f, e_max, e_l2)
+        print("mean removal, overlap %.2f: worst %.2e (frames without a DC hop), %.2e (with one; the oracle's own 1-ulp spread there: %.2e)"
+              % (overlap, worst_plain, worst_dc, spread.max()))
+
+
+# ---- kept scratch: asynchronous hand-off between streams, the cap, the trim entry ---------------------
+def test_kept_scratch_handoff_between_streams_stays_asynchronous(lib, torch_cuda):
+    """the hand-off of a kept block from stream A to stream B (hipStreamWaitEvent on the
+    event recorded at the give-back) through an entry that does NOT end in a host synchronisation:
+    glfer_hip_spectrogram_device with per-hop mean removal forced through the corrected copy of the
+    stream (GLFER_MEAN_PREPASS=1; 8 Mi samples = 32 MiB of scratch, a kept block), alternately on two
+    streams with different inputs, nothing synchronised until the end."""
+    import os
+    torch = torch_cuda
+    saved = os.environ.get("GLFER_MEAN_PREPASS")
+    os.environ["GLFER_MEAN_PREPASS"] = "1"
+    try:
+        sp = lib.Spectrogram(lib.FftParams(n=1024, window_type=1, overlap=0.5, sub_mean=1))
+        frames = (8 << 20) // sp.hop
+        xs = [torch.from_numpy(synth(frames * sp.hop, seed=40 + i) + np.float32(0.1 * i)).cuda() for i in range(4)]
+        want = [sp.run(x).clone() for x in xs]
+        torch.cuda.synchronize()
+        held = lib.api.lib().glfer_hip_scratch_held(0)
+        assert held >= 32 << 20                          # the copy came from a kept block
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [torch.empty_like(w) for w in want]
+        for rep in range(3):
+            for i, x in enumerate(xs):
+                with torch.cuda.stream(streams[i % 2]):
+                    sp.run(x, out=outs[i])               # asynchronous: returns with the work queued
+        torch.cuda.synchronize()
+        for i in range(4):
+            assert torch.equal(outs[i], want[i]), i
+    finally:
+        if saved is None:
+            os.environ.pop("GLFER_MEAN_PREPASS", None)
+        else:
+            os.environ["GLFER_MEAN_PREPASS"] = saved
+
+
+def test_scratch_trim_and_cap(lib, torch_cuda):
+    """glfer_hip_scratch_trim gives the kept blocks back (hipMemGetInfo sees the memory again);
+    glfer_hip_scratch_limit(0) keeps nothing between calls; results do not change either way."""
+    import os
+    torch = torch_cuda
+    L = lib.api.lib()
+    saved = os.environ.get("GLFER_MEAN_PREPASS")
+    os.environ["GLFER_MEAN_PREPASS"] = "1"
+    try:
+        sp = lib.Spectrogram(lib.FftParams(n=1024, window_type=1, overlap=0.5, sub_mean=1))
+        frames = (16 << 20) // sp.hop
+        x = torch.from_numpy(synth(frames * sp.hop, seed=50)).cuda()
+        want = sp.run(x).clone()
+        torch.cuda.synchronize()
+        held = L.glfer_hip_scratch_held(0)
+        assert held >= 64 << 20
+        free0 = torch.cuda.mem_get_info()[0]
+        freed = L.glfer_hip_scratch_trim(0, 0)
+        assert freed == held and L.glfer_hip_scratch_held(0) == 0
+        assert torch.cuda.mem_get_info()[0] >= free0 + (freed * 3) // 4      # the driver has it back
+        # a cap of 0: the block is made for the call and goes back before the next one is made
+        L.glfer_hip_scratch_limit(0)
+        got = sp.run(x)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        x2 = torch.cat([x, x])                                               # another size class
+        sp.run(x2)
+        torch.cuda.synchronize()
+        assert L.glfer_hip_scratch_held(0) <= 2 * (x2.numel() * 4) * 17 // 16 + (1 << 20)   # only the last call's block
+        L.glfer_hip_scratch_trim(0, 0)
+        assert L.glfer_hip_scratch_held(0) == 0
+    finally:
+        L.glfer_hip_scratch_limit(16 << 30)
+        if saved is None:
+            os.environ.pop("GLFER_MEAN_PREPASS", None)
+        else:
+            os.environ["GLFER_MEAN_PREPASS"] = saved
+
+
+def test_waterfall_short_last_tile_keeps_its_form(lib, torch_cuda):
+    """with small tiles and a deep window the last tile can be too short for the fused
+    average-and-map form; the call must then take the staged form for every tile, not fail."""
+    import os
+    torch = torch_cuda
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    rows, bins = 2100, 513
+    x = (torch.rand((rows, bins), device="cuda", generator=g) ** 4 * 1e-3 + 1e-9).contiguous()
+    kw = dict(scale_type=lib.SCALE_LOG, autoscale=1, overlap=0.5, palette=1)
+    saved = {k: os.environ.get(k) for k in ("GLFER_WATERFALL_TILE", "GLFER_WATERFALL_FUSED")}
+    try:
+        os.environ["GLFER_WATERFALL_FUSED"] = "0"
+        os.environ.pop("GLFER_WATERFALL_TILE", None)
+        want = lib.waterfall(lib.Display(**kw), x, avg_mode=lib.AVG_PLAIN, depth=100, minbin=3, maxbin=500)[0].clone()
+        os.environ.pop("GLFER_WATERFALL_FUSED", None)
+        for tile in (64, 100, 130, 257, 700, 1999):
+            os.environ["GLFER_WATERFALL_TILE"] = str(tile)
+            got = lib.waterfall(lib.Display(**kw), x, avg_mode=lib.AVG_PLAIN, depth=100, minbin=3, maxbin=500)[0]
+            assert torch.equal(got, want), tile
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# ---- WAV files with other chunks around the samples ---------------------------------------------------
+def _riff(chunks):
+    body = b"WAVE" + b"".join(cid + len(data).to_bytes(4, "little") + data + (b"\0" if len(data) & 1 else b"") for cid, data in chunks)
+    return b"RIFF" + len(body).to_bytes(4, "little") + body
+
+
+def test_wav_with_list_chunks_around_the_data(lib, oracle, torch_cuda, tmp_path):
+    """wav_fmt.c:45-121 takes the header as a fixed 44-byte struct; a file with a LIST chunk before
+    "data" (and one after) must still yield the spectrogram of its SAMPLES: the chunks are walked."""
+    import struct
+    x = synth(1024 * 40, fs=8000.0, seed=8)
+    pcm = np.round(x * 32767).astype(np.int16)
+    fmt = struct.pack("<HHIIHH", 1, 1, 8000, 16000, 2, 16)
+    plain = tmp_path / "plain.wav"
+    plain.write_bytes(_riff([(b"fmt ", fmt), (b"data", pcm.tobytes())]))
+    odd = tmp_path / "list.wav"
+    odd.write_bytes(_riff([(b"fmt ", fmt + b"\0\0"),                       # an 18-byte fmt chunk (cbSize = 0)
+                           (b"LIST", b"INFOISFT" + (13).to_bytes(4, "little") + b"some encoder\0"),   # odd length: padded
+                           (b"fact", (pcm.size).to_bytes(4, "little")),
+                           (b"data", pcm.tobytes()),
+                           (b"LIST", b"INFOICMT" + (6).to_bytes(4, "little") + b"after\0")]))
+    info = lib.wav_probe(str(odd))
+    assert info.bits_per_sample == 16 and info.sample_rate == 8000 and info.nsamples == pcm.size and info.data_offset > 44
+    assert lib.wav_probe(str(plain)).data_offset == 44
+    sp = lib.Spectrogram(lib.FftParams(n=1024, window_type=1, overlap=0.5, sample_format=lib.SAMPLES_S16))
+    a = sp.run_wav(str(plain), chunk_frames=32)
+    b = sp.run_wav(str(odd), chunk_frames=32)
+    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    want = oracle.spectrogram_fft((pcm.astype(np.float32) / 32768.0), 1024, 0.5, oracle.WINDOWS["hanning"])
+    for f in range(a.shape[0]):
+        assert max(rel_err(b[f], want[f])) <= TOL
+    # a cut-off recording: the data chunk's size field is 0 -> the data runs to the end of the file
+    cut = tmp_path / "cut.wav"
+    raw = bytearray(_riff([(b"fmt ", fmt), (b"data", pcm.tobytes())]))
+    raw[40:44] = (0).to_bytes(4, "little")
+    cut.write_bytes(bytes(raw))
+    assert lib.wav_probe(str(cut)).nsamples == pcm.size

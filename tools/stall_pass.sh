@@ -1,0 +1,35 @@
+# usage (GPU box): bash tools/stall_pass.sh <workload> <tag>
+# VALU / LDS / VMEM issue and stall counters of one bench workload's spectro16* kernels, the counters
+# in small groups (a pass whose counters do not fit, or whose name this stack does not know, fails
+# alone); the program itself right after `--`.  Output: gpurun_out/stall_<tag>/summary.txt
+W=$1; TAG=$2; R=$PWD
+cd /tmp && export TMPDIR=/tmp && cd $R
+D=gpurun_out/stall_$TAG; rm -rf $D; mkdir -p $D
+i=0
+for G in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" \
+         "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_ANY" \
+         "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
+         "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM" \
+         "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_MOPS_F32" \
+         "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES" \
+         "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_IFETCH SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $D/g$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $W > $D/g$i.log 2>&1 || echo "group $i failed: $G" >> $D/failed.txt
+done
+python3 - $D <<'PY' > $D/summary.txt
+import csv, glob, sys, collections
+d = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(d + "/g*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "spectro16" in r["Kernel_Name"] or "hparma" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, c in agg.items():
+    print(k)
+    for n, v in sorted(c.items()):
+        print("   %-28s %18.0f   (%d dispatches)" % (n, sum(v) / len(v), len(v)))
+PY
+cat $D/summary.txt; cat $D/failed.txt 2>/dev/null
+find $D -name '*_kernel_trace.csv' -size +1M -delete
+find $D -name '*agent_info.csv' -delete
+true
