@@ -39,6 +39,11 @@ EXPORTS = [
     "glfer_hip_host_free", "glfer_hip_spectrogram_host_multi", "glfer_hip_spectrogram_wav_ex",
     "glfer_hip_avg_cum_device", "glfer_hip_waterfall_host", "glfer_hip_waterfall_device",
     "glfer_hip_spectrogram_host_workers",
+    # round 3
+    "glfer_hip_scratch_trim", "glfer_hip_scratch_held", "glfer_hip_scratch_limit", "glfer_hip_spectrogram_wav_range",
+    "glfer_hip_spectrogram_wav_multi", "glfer_hip_spectrogram_wav_workers", "glfer_hip_levels_host",
+    "glfer_hip_waterfall_map_device", "glfer_hip_waterfall_host_workers", "glfer_hip_waterfall_wav_workers",
+    "glfer_hip_waterfall_wav_multi",
 ]
 
 
@@ -137,6 +142,19 @@ def lib():
     L.glfer_hip_waterfall_device.argtypes = [C.POINTER(Display), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, C.c_int,
                                              vp, vp, vp, vp]
     L.glfer_hip_waterfall_host.argtypes = [vp, C.POINTER(Display), vp, sz, vp, vp, C.POINTER(sz)]
+    cfgp, ip, dispp, szp = C.POINTER(Config), C.POINTER(C.c_int), C.POINTER(Display), C.POINTER(sz)
+    L.glfer_hip_spectrogram_wav_range.argtypes = [vp, C.c_char_p, sz, sz, vp, szp, sz, C.c_uint]
+    L.glfer_hip_spectrogram_wav_multi.argtypes = [cfgp, C.c_uint, C.c_char_p, vp, sz, szp, C.c_uint]
+    L.glfer_hip_spectrogram_wav_workers.argtypes = [cfgp, ip, C.c_int, C.c_char_p, vp, sz, szp, C.c_uint]
+    L.glfer_hip_waterfall_host_workers.argtypes = [cfgp, ip, C.c_int, dispp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   vp, sz, vp, vp, szp]
+    L.glfer_hip_waterfall_wav_workers.argtypes = [cfgp, ip, C.c_int, dispp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.c_char_p, sz, vp, vp, szp, C.c_uint]
+    L.glfer_hip_waterfall_wav_multi.argtypes = [cfgp, C.c_uint, dispp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_char_p, sz, vp, vp, szp, C.c_uint]
+    L.glfer_hip_levels_host.argtypes = [dispp, vp, sz, vp, C.c_int]
+    L.glfer_hip_waterfall_map_device.argtypes = [dispp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, sz, C.c_int,
+                                                 vp, vp, vp, vp]
     L.glfer_hip_scratch_trim.argtypes = [C.c_int, sz]
     L.glfer_hip_scratch_trim.restype = sz
     L.glfer_hip_scratch_held.argtypes = [C.c_int]
@@ -409,6 +427,63 @@ def spectrogram_host_multi(params, samples, devices, out=None):
         _check(lib().glfer_hip_spectrogram_host_workers(C.byref(cfg), devs, len(devices), samples.ctypes.data, samples.size,
                                                         out.ctypes.data, C.byref(nf)), "glfer_hip_spectrogram_host_workers")
     return out[:nf.value]
+
+
+def _hop_of(params):
+    return int(params.n * (1.0 - float(np.float32(params.overlap))))
+
+
+def spectrogram_wav_workers(params, path, devices, partial_tail=False, max_frames=None):
+    """glfer_hip_spectrogram_wav_workers / _multi: a WAV file's frames dealt out over `devices` (HIP
+    ordinals; one may repeat), every worker reading its own part of the file; numpy psd [frames][bins]."""
+    info = wav_probe(path)
+    cfg = make_config(params, 0)
+    frames = info.nsamples // _hop_of(params) + (1 if partial_tail else 0)
+    if max_frames is not None:
+        frames = min(frames, max_frames)
+    out = np.empty((frames, params.n // 2 + 1), np.float32)
+    nf = C.c_size_t(0)
+    flags = WAV_PARTIAL_TAIL if partial_tail else 0
+    if len(set(devices)) == len(devices):
+        mask = 0
+        for d in devices:
+            mask |= 1 << d
+        _check(lib().glfer_hip_spectrogram_wav_multi(C.byref(cfg), mask, os.fsencode(path), out.ctypes.data, frames,
+                                                     C.byref(nf), flags), "glfer_hip_spectrogram_wav_multi")
+    else:
+        devs = (C.c_int * len(devices))(*devices)
+        _check(lib().glfer_hip_spectrogram_wav_workers(C.byref(cfg), devs, len(devices), os.fsencode(path), out.ctypes.data,
+                                                       frames, C.byref(nf), flags), "glfer_hip_spectrogram_wav_workers")
+    return out[:nf.value]
+
+
+def waterfall_workers(params, disp, devices, samples=None, path=None, avg_mode=0, depth=1, minbin=0, maxbin=1, max0=0,
+                      want_lev=True, partial_tail=False):
+    """glfer_hip_waterfall_host_workers (samples: numpy array) or glfer_hip_waterfall_wav_workers (path):
+    (rgb uint8 [frames][bins][3], lev int16 [frames][bins] | None), the columns dealt out over `devices`."""
+    cfg = make_config(params, 0)
+    hop, bins = _hop_of(params), params.n // 2 + 1
+    devs = (C.c_int * len(devices))(*devices)
+    nf = C.c_size_t(0)
+    if path is None:
+        want = {SAMPLES_F32: np.float32, SAMPLES_S16: np.int16, SAMPLES_U8: np.uint8}[params.sample_format]
+        samples = np.ascontiguousarray(samples, want)
+        frames = samples.size // hop
+    else:
+        frames = wav_probe(path).nsamples // hop + (1 if partial_tail else 0)
+    rgb = np.empty((frames, bins, 3), np.uint8)
+    lev = np.empty((frames, bins), np.int16) if want_lev else None
+    levp = lev.ctypes.data if want_lev else None
+    if path is None:
+        _check(lib().glfer_hip_waterfall_host_workers(C.byref(cfg), devs, len(devices), C.byref(disp), int(avg_mode), depth, minbin,
+                                                      maxbin, int(max0), samples.ctypes.data, samples.size, rgb.ctypes.data, levp,
+                                                      C.byref(nf)), "glfer_hip_waterfall_host_workers")
+    else:
+        _check(lib().glfer_hip_waterfall_wav_workers(C.byref(cfg), devs, len(devices), C.byref(disp), int(avg_mode), depth, minbin,
+                                                     maxbin, int(max0), os.fsencode(path), frames, rgb.ctypes.data, levp,
+                                                     C.byref(nf), WAV_PARTIAL_TAIL if partial_tail else 0),
+               "glfer_hip_waterfall_wav_workers")
+    return rgb[:nf.value], (lev[:nf.value] if want_lev else None)
 
 
 class PinnedArray:

@@ -355,10 +355,13 @@ struct MapAverages {
 
 // The mapping part of main_window_draw for `nframes` columns: level tracking, then the pixel map of the
 // PSD rows, of averaged rows, or (fused) of the averages taken on the way.
+// d_levels_in: the columns' levels already known (the walk was done elsewhere -- over ALL columns of a
+// waterfall whose rows are spread over several GPUs, glfer_hip_levels_host): no walk, d_stats unused,
+// the carried state in *d untouched.
 static int display_columns(glfer_hip_display *d, const float *d_psd, const double *d_avg, const MapAverages *fused,
                            const float *d_stats, size_t nframes, int bins, unsigned char *d_rgb, short *d_lev,
-                           float *d_levels, void *hip_stream) {
-  if (!d || !d_stats || !d_rgb || bins < 1) return GLFER_E_ARG;
+                           float *d_levels, void *hip_stream, const float *d_levels_in = nullptr) {
+  if (!d || (!d_stats && !d_levels_in) || !d_rgb || bins < 1) return GLFER_E_ARG;
   if ((d_psd != nullptr) + (d_avg != nullptr) + (fused != nullptr) != 1) return GLFER_E_ARG;
   if (d->scale_type < GLFER_SCALE_LIN || d->scale_type > GLFER_SCALE_LOG_MAX0) return GLFER_E_ARG;
   if (nframes == 0) return GLFER_OK;
@@ -369,14 +372,15 @@ static int display_columns(glfer_hip_display *d, const float *d_psd, const doubl
 
   // one stream-ordered allocation: the palette, the table of the dB steps, the levels rows (when
   // the caller does not want them) and the chunk states of the autoscale walk
-  const size_t lev_floats = d_levels ? 0 : nframes * 4, st_floats = d->autoscale ? glfer_levels_scratch_floats(nframes) : 0;
+  const size_t lev_floats = (d_levels || d_levels_in) ? 0 : nframes * 4;
+  const size_t st_floats = (d->autoscale && !d_levels_in) ? glfer_levels_scratch_floats(nframes) : 0;
   const size_t thr_bytes = (2 * glfer::kLogThrK + 1) * sizeof(double);
   unsigned char *scratch = nullptr;
   HIP_TRY(glfer::scratch_malloc((void **)&scratch, 768 + thr_bytes + (lev_floats + st_floats) * sizeof(float), st));
   unsigned char *d_tab = scratch;
   double *d_thr = reinterpret_cast<double *>(scratch + 768);
   float *fs = reinterpret_cast<float *>(scratch + 768 + thr_bytes);
-  float *levels = d_levels ? d_levels : fs;
+  float *levels = d_levels_in ? const_cast<float *>(d_levels_in) : (d_levels ? d_levels : fs);
   float *chunk_state = st_floats ? fs + lev_floats : nullptr;
   int rc = GLFER_OK;
   auto fail = [&](hipError_t err) { rc = hip_fail(err, "glfer_hip_display_device"); };
@@ -387,7 +391,7 @@ static int display_columns(glfer_hip_display *d, const float *d_psd, const doubl
   if (e == hipSuccess) e = hipMemcpyAsync(d_thr, glfer::log_thresholds(), thr_bytes, hipMemcpyHostToDevice, st);
   if (e != hipSuccess) fail(e);
 
-  if (rc == GLFER_OK) {
+  if (rc == GLFER_OK && !d_levels_in) {
     if (d->autoscale) {
       e = glfer_launch_levels(d_stats, nframes, scale_log, 1, d->first_buffer, d->overlap, d->display_max_lvl,
                               d->display_min_lvl, levels, chunk_state, st);
@@ -413,14 +417,14 @@ static int display_columns(glfer_hip_display *d, const float *d_psd, const doubl
     if (e != hipSuccess) fail(e);
   }
   float last[4] = {0, 0, 0, 0};
-  if (rc == GLFER_OK) {
+  if (rc == GLFER_OK && !d_levels_in) {
     e = hipMemcpyAsync(last, levels + (nframes - 1) * 4, sizeof last, hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) fail(e);
   }
   glfer::scratch_free(scratch, st);
   e = hipStreamSynchronize(st);              // the carried state comes back to the host
   if (e != hipSuccess && rc == GLFER_OK) fail(e);
-  if (rc == GLFER_OK) {
+  if (rc == GLFER_OK && !d_levels_in) {
     d->display_max_lvl = last[2];
     d->display_min_lvl = last[3];
     if (d->autoscale) d->first_buffer = 0;                                     // g_main.c:1120
@@ -446,9 +450,15 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
 // measured: 15 M rows/s against 117 M stage by stage over the whole batch
 // (profiles/r02_aux_sweep.txt) -- the chain's latency per tile swamps the saved HBM read.  So the
 // stages run over tiles that only bound the scratch (averaged rows: 8 B/bin, 4 GiB per tile).
-int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, int minbin, int maxbin, int max0,
-                               const float *d_psd, size_t nframes, int bins, unsigned char *d_rgb, short *d_lev,
-                               float *d_stats, void *hip_stream) {
+}  // extern "C"
+
+// Rows [row0, row0 + nframes) of the batch d_psd.  row0 > 0 / d_levels_in: the second phase of a
+// waterfall whose columns are spread over several GPUs (glfer_hip_waterfall_map_device) -- the moving
+// sums of the first rows reach back into the batch's rows before row0, the levels are given.
+static int waterfall_columns(glfer_hip_display *d, int avg_mode, int depth, int minbin, int maxbin, int max0,
+                             const float *d_batch, size_t row0, size_t nframes, int bins, unsigned char *d_rgb, short *d_lev,
+                             float *d_stats, void *hip_stream, const float *d_levels_in) {
+  const float *d_psd = d_batch ? d_batch + row0 * (size_t)bins : nullptr;
   if (!d || !d_psd || !d_rgb || bins < 1 || bins > 32769) return GLFER_E_ARG;
   const bool averaging = avg_mode != 0;
   if (averaging && (avg_mode < GLFER_AVG_SUMAVG || avg_mode > GLFER_AVG_SUMEXTREME || depth < 1 || minbin < 0 ||
@@ -481,7 +491,7 @@ int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, in
   const size_t back = averaging ? (size_t)depth : 0;       // rows re-read in front of a tile to restart the sliding sums
   float *stats = d_stats;
   double *avg = nullptr, *ret = nullptr;
-  if (!stats) HIP_TRY(glfer::scratch_malloc((void **)&stats, tile * 4 * sizeof(float), st));
+  if (!stats && !d_levels_in) HIP_TRY(glfer::scratch_malloc((void **)&stats, tile * 4 * sizeof(float), st));
   int rc = GLFER_OK;
   if (averaging && !fused) {
     hipError_t e = glfer::scratch_malloc((void **)&avg, (tile + back) * (size_t)bins * sizeof(double), st);
@@ -491,33 +501,96 @@ int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, in
   for (size_t f0 = 0; rc == GLFER_OK && f0 < nframes; f0 += tile) {
     const size_t nf = std::min(tile, nframes - f0);
     float *tstats = d_stats ? d_stats + f0 * 4 : stats;
+    const float *tlevels = d_levels_in ? d_levels_in + f0 * 4 : nullptr;
     unsigned char *trgb = d_rgb + f0 * (size_t)bins * 3;
     short *tlev = d_lev ? d_lev + f0 * (size_t)bins : nullptr;
-    rc = glfer_hip_floor_device(d_psd + f0 * (size_t)bins, nf, bins, tstats, st);
+    if (tstats) rc = glfer_hip_floor_device(d_psd + f0 * (size_t)bins, nf, bins, tstats, st);
     if (rc != GLFER_OK) break;
     if (fused) {
       // the sliding sums of the tile's first rows reach back into the rows before it by themselves
-      const MapAverages ma{avg_mode, depth, minbin, maxbin, max0 ? 1 : 0, d_psd, f0};
-      rc = display_columns(d, nullptr, nullptr, &ma, tstats, nf, bins, trgb, tlev, nullptr, st);
+      const MapAverages ma{avg_mode, depth, minbin, maxbin, max0 ? 1 : 0, d_batch, row0 + f0};
+      rc = display_columns(d, nullptr, nullptr, &ma, tstats, nf, bins, trgb, tlev, nullptr, st, tlevels);
       continue;
     }
     const double *src_avg = nullptr;
     if (averaging) {
       // the sums of the tile's first rows reach `depth` rows back: run from there (from an empty
       // state at row 0 of the batch, as update_avg does after alloc_avg) and use the tile's rows
-      const size_t lead = std::min(back, f0);
-      rc = glfer_hip_avg_device(avg_mode, d_psd + (f0 - lead) * (size_t)bins, nf + lead, bins, bins, depth, minbin, maxbin, max0,
+      const size_t lead = std::min(back, row0 + f0);
+      rc = glfer_hip_avg_device(avg_mode, d_batch + (row0 + f0 - lead) * (size_t)bins, nf + lead, bins, bins, depth, minbin, maxbin, max0,
                                 avg, ret, st);
       src_avg = avg + lead * (size_t)bins;
     }
     if (rc == GLFER_OK)
       rc = display_columns(d, averaging ? nullptr : d_psd + f0 * (size_t)bins, src_avg, nullptr, tstats, nf, bins, trgb, tlev,
-                           nullptr, st);
+                           nullptr, st, tlevels);
   }
   if (avg) glfer::scratch_free(avg, st);
   if (ret) glfer::scratch_free(ret, st);
-  if (!d_stats) glfer::scratch_free(stats, st);
+  if (!d_stats && stats) glfer::scratch_free(stats, st);
   return rc;
+}
+
+extern "C" {
+
+int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, int minbin, int maxbin, int max0,
+                               const float *d_psd, size_t nframes, int bins, unsigned char *d_rgb, short *d_lev,
+                               float *d_stats, void *hip_stream) {
+  return waterfall_columns(d, avg_mode, depth, minbin, maxbin, max0, d_psd, 0, nframes, bins, d_rgb, d_lev, d_stats, hip_stream,
+                           nullptr);
+}
+
+// The two halves of glfer_hip_waterfall_device for columns that live on several GPUs.  The level
+// tracking (g_main.c:1111-1124) is ONE chain over all columns, fed by 16 bytes of floor statistics
+// per column; everything else is per column.  So: every GPU computes its rows and their statistics,
+// the statistics meet on the host, ONE walk over them (here: on `device`, the walk of
+// glfer_hip_display_device) gives every column its levels, and every GPU maps its own rows with its
+// slice of the levels.  Nothing but 16 + 16 bytes per column crosses between GPUs, through the host.
+int glfer_hip_levels_host(glfer_hip_display *d, const float *h_stats, size_t nframes, float *h_levels, int device) {
+  if (!d || !h_stats || !h_levels) return GLFER_E_ARG;
+  if (d->scale_type < GLFER_SCALE_LIN || d->scale_type > GLFER_SCALE_LOG_MAX0) return GLFER_E_ARG;
+  if (nframes == 0) return GLFER_OK;
+  DeviceGuard guard(device);
+  HIP_TRY(guard.error());
+  const int scale_log = d->scale_type == GLFER_SCALE_LOG || d->scale_type == GLFER_SCALE_LOG_MAX0;
+  const size_t st_floats = d->autoscale ? glfer_levels_scratch_floats(nframes) : 0;
+  float *buf = nullptr;
+  HIP_TRY(glfer::scratch_malloc((void **)&buf, (nframes * 8 + st_floats) * sizeof(float), nullptr));
+  float *d_stats = buf, *levels = buf + nframes * 4, *chunk_state = st_floats ? buf + nframes * 8 : nullptr;
+  int rc = GLFER_OK;
+  hipError_t e = hipMemcpyAsync(d_stats, h_stats, nframes * 4 * sizeof(float), hipMemcpyHostToDevice, nullptr);
+  if (e == hipSuccess) {
+    if (d->autoscale) {
+      e = glfer_launch_levels(d_stats, nframes, scale_log, 1, d->first_buffer, d->overlap, d->display_max_lvl,
+                              d->display_min_lvl, levels, chunk_state, nullptr);
+    } else {                                                                   // g_main.c:1125-1139
+      float mx = pow(10.0, d->max_level_db / 10.0);
+      float mn = pow(10.0, d->min_level_db / 10.0);
+      mn = (mx > mn ? mn : mx / 10.0);
+      const float dmax = scale_log ? (float)(10.0 * log10(mx)) : mx;
+      const float dmin = scale_log ? (float)(10.0 * log10(mn)) : mn;
+      e = glfer_launch_levels_fixed(nframes, dmax, dmin, mx, mn, levels, nullptr);
+    }
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h_levels, levels, nframes * 4 * sizeof(float), hipMemcpyDeviceToHost, nullptr);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  glfer::scratch_free(buf, nullptr);
+  if (e != hipSuccess) rc = hip_fail(e, "glfer_hip_levels_host");
+  if (rc == GLFER_OK) {
+    d->display_max_lvl = h_levels[(nframes - 1) * 4 + 2];
+    d->display_min_lvl = h_levels[(nframes - 1) * 4 + 3];
+    if (d->autoscale) d->first_buffer = 0;                                     // g_main.c:1120
+  }
+  return rc;
+}
+
+int glfer_hip_waterfall_map_device(const glfer_hip_display *d, int avg_mode, int depth, int minbin, int maxbin, int max0,
+                                   const float *d_batch, size_t first, size_t nframes, int bins, const float *d_levels,
+                                   unsigned char *d_rgb, short *d_lev, void *hip_stream) {
+  if (!d || !d_levels) return GLFER_E_ARG;
+  glfer_hip_display copy = *d;               // the carried state is not touched: the walk was glfer_hip_levels_host's
+  return waterfall_columns(&copy, avg_mode, depth, minbin, maxbin, max0, d_batch, first, nframes, bins, d_rgb, d_lev, nullptr,
+                           hip_stream, d_levels);
 }
 
 size_t glfer_hip_scratch_trim(int device, size_t keep_bytes) { return glfer::scratch_trim(device, keep_bytes); }

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -68,6 +69,11 @@ struct Sink {
   glfer_hip_display *disp = nullptr;     // waterfall mode when set
   unsigned char *h_rgb = nullptr;
   short *h_lev = nullptr;
+  // device sink (the first phase of a waterfall over several workers): the rows stay on the device,
+  // [frames][bins] at d_rows, with their compute_floor statistics [frames][4] at d_stats; nothing
+  // comes back to the host
+  float *d_rows = nullptr;
+  float *d_stats = nullptr;
 };
 
 struct Job {
@@ -104,6 +110,7 @@ int run_job(const Job &job, size_t *frames_done) {
   // chunk boundaries sit on GLOBAL multiples of GLFER_FRAME_ALIGN: the first chunk of a job that
   // starts off the grid is shortened to reach it
   const bool waterfall = job.sink.disp != nullptr;
+  const bool dev_sink = job.sink.d_rows != nullptr;
   const size_t row_bytes = waterfall ? bins * 3 : bins * sizeof(float);
 
   DeviceGuard guard(p->cfg.device);
@@ -124,8 +131,8 @@ int run_job(const Job &job, size_t *frames_done) {
     e = hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking);
     if (e == hipSuccess && !job.pinned_src) e = hipHostMalloc((void **)&h_in[b], in_bytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&d_in[b], in_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_psd[b], rows_cap * bins * sizeof(float));
-    if (e == hipSuccess && !direct_out) e = hipHostMalloc((void **)&h_out[b], rows_cap * row_bytes, hipHostMallocDefault);
+    if (e == hipSuccess && !dev_sink) e = hipMalloc((void **)&d_psd[b], rows_cap * bins * sizeof(float));
+    if (e == hipSuccess && !direct_out && !dev_sink) e = hipHostMalloc((void **)&h_out[b], rows_cap * row_bytes, hipHostMallocDefault);
     if (e == hipSuccess && waterfall) {
       e = hipMalloc((void **)&d_stats[b], rows_cap * 4 * sizeof(float));
       if (e == hipSuccess) e = hipMalloc((void **)&d_rgb[b], rows_cap * bins * 3);
@@ -144,7 +151,7 @@ int run_job(const Job &job, size_t *frames_done) {
     hipError_t err = hipStreamSynchronize(st[b]);
     pend[b].live = false;
     if (err != hipSuccess) return hip_fail(err, "ingest: chunk");
-    if (!direct_out) {
+    if (!direct_out && !dev_sink) {
       const size_t off = pend[b].first - job.frame_lo, nf = pend[b].nf;
       if (waterfall) {
         copy_wide(job.sink.h_rgb + off * bins * 3, h_out[b], nf * bins * 3);
@@ -200,9 +207,13 @@ int run_job(const Job &job, size_t *frames_done) {
       if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
     }
     const unsigned char *vbase = d_in[b] - lo_hop * hop * esz;       // virtual address of stream sample 0
-    rc = glfer_run_device(p, vbase, (cf + nf) * hop, cf, nf, d_psd[b], nullptr, st[b], has_tail ? job.tail_fresh : -1);
+    float *rows = dev_sink ? job.sink.d_rows + (cf - job.frame_lo) * bins : d_psd[b];
+    rc = glfer_run_device(p, vbase, (cf + nf) * hop, cf, nf, rows, nullptr, st[b], has_tail ? job.tail_fresh : -1);
     if (rc) break;
-    if (waterfall) {
+    if (dev_sink) {
+      if (job.sink.d_stats) rc = glfer_hip_floor_device(rows, nf, (int)bins, job.sink.d_stats + (cf - job.frame_lo) * 4, st[b]);
+      if (rc) break;
+    } else if (waterfall) {
       rc = glfer_hip_floor_device(d_psd[b], nf, (int)bins, d_stats[b], st[b]);
       if (rc) break;
       // the level tracking carries its state from column to column (g_main.c:1081, 1111-1124): the
@@ -352,69 +363,123 @@ int glfer_hip_waterfall_host(glfer_hip_plan *p, glfer_hip_display *disp, const v
   return run_job(job, nframes_out);
 }
 
-// ---- multi-GPU: source.c:130-158 over one stream, the frame range dealt out over the GPUs of the
-// node.  One host thread per GPU, each with its own plan, streams and pinned ring (run_job); the
-// ranges come from the same arithmetic as glfer_amd/shard.py; rows land in disjoint ranges of
-// h_psd; nothing is exchanged between GPUs.
-// One worker (host thread + plan + two streams + pinned ring) per entry of devices[]; an ordinal may
-// appear more than once -- several workers then share that GPU, which is how a one-GPU box exercises
-// the whole multi-worker path (frame offsets, halos from the middle of the stream, disjoint rows).
-int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *devices, int nworkers,
-                                       const void *h_stream, size_t nsamples, float *h_psd, size_t *nframes_out) {
-  if (!cfg || !devices || nworkers < 1 || nworkers > 64 || !h_stream || !nframes_out) return GLFER_E_ARG;
+}  // extern "C"
+
+// ---- sources: a stream of whole hops in the raw sample format, readable by several workers at once ----
+namespace {
+
+typedef std::function<size_t(unsigned char *, size_t, size_t)> HopReader;
+
+struct Source {
+  size_t frames = 0;                       // frames the stream yields (the trailing partial block counted when taken)
+  long tail_fresh = -1;                    // >= 0: the LAST frame is a file's trailing partial block with this many fresh samples
+  std::function<HopReader()> open;         // a reader of its own per worker (a file handle each); empty reader = failure
+  const unsigned char *pinned_src = nullptr;
+};
+
+Source array_source(const void *h_stream, size_t frames, size_t hop_bytes, bool pinned) {
+  Source s;
+  s.frames = frames;
+  s.open = [=] { return array_reader(h_stream, hop_bytes); };
+  if (pinned) s.pinned_src = (const unsigned char *)h_stream;
+  return s;
+}
+
+unsigned rd_u16(const unsigned char *b) { return b[0] | (b[1] << 8); }
+unsigned rd_u32(const unsigned char *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24); }
+
+// The block reader of wav_read (wav_fmt.c:81-121) over hop indices: whole blocks from the data chunk;
+// with_tail: the short last read counts as one more block (n_read != 0) whose fresh samples lie over
+// the STALE rest of the reader's buffer -- here the RAW samples of the block before (zeros, the
+// calloc of wav_fmt.c:99, for a file shorter than one block); with per-hop mean removal the device
+// replaces the stale part by the corrected previous hop (submean_tail_kernel).
+struct WavLayout {
+  size_t data_offset = 0, hop_bytes = 0, esz = 1, whole = 0, fresh = 0;
+  bool with_tail = false;
+};
+HopReader wav_reader(const std::string &path, const WavLayout &w) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return HopReader();
+  std::shared_ptr<FILE> fp(f, fclose);
+  return [fp, w](unsigned char *dst, size_t hop_index, size_t nhops) -> size_t {
+    FILE *f = fp.get();
+    const size_t hop_bytes = w.hop_bytes, whole = w.whole;
+    if (fseek(f, (long)(w.data_offset + hop_index * hop_bytes), SEEK_SET) != 0) return 0;
+    const size_t full = hop_index + nhops <= whole ? nhops : (hop_index < whole ? whole - hop_index : 0);
+    if (fread(dst, 1, full * hop_bytes, f) != full * hop_bytes) return 0;
+    if (full == nhops) return nhops;
+    if (!w.with_tail || hop_index + nhops != whole + 1) return full;
+    unsigned char *last = dst + full * hop_bytes;
+    if (whole == 0) {
+      memset(last, w.esz == 1 ? 0x80 : 0, hop_bytes);               // sample value 0.0 (u8: 128)
+    } else if (full > 0) {
+      memcpy(last, last - hop_bytes, hop_bytes);
+    } else {
+      if (fseek(f, (long)(w.data_offset + (whole - 1) * hop_bytes), SEEK_SET) != 0) return full;
+      if (fread(last, 1, hop_bytes, f) != hop_bytes) return full;
+      if (fseek(f, (long)(w.data_offset + whole * hop_bytes), SEEK_SET) != 0) return full;
+    }
+    if (w.fresh && fread(last, 1, w.fresh * w.esz, f) != w.fresh * w.esz) return full;
+    return nhops;
+  };
+}
+
+// probe + layout of a WAV file for an estimator of hop `hop` and sample format `fmt`
+int wav_source(const char *path, int hop, int fmt, int mode, unsigned flags, size_t max_frames, Source *src) {
+  if (!path || (flags & ~(unsigned)GLFER_WAV_PARTIAL_TAIL) || hop <= 0) return GLFER_E_ARG;
+  glfer_wav_info wi;
+  int rc = glfer_hip_wav_probe(path, &wi);
+  if (rc) return rc;
+  if (fmt != (wi.bits_per_sample == 8 ? GLFER_SAMPLES_U8 : GLFER_SAMPLES_S16)) return GLFER_E_ARG;
+  WavLayout w;
+  w.esz = (size_t)wi.bits_per_sample / 8;
+  w.hop_bytes = (size_t)hop * w.esz;
+  w.data_offset = wi.data_offset;
+  w.whole = wi.data_bytes / w.hop_bytes;                           // full blocks, wav_fmt.c:102
+  // wav_fmt.c:102-119: a short last read still counts as a block (n_read != 0) and converts
+  // n_read (8 bit) or n_read/2 (16 bit: an odd last byte is dropped) samples over the stale rest
+  const size_t rest = wi.data_bytes - w.whole * w.hop_bytes;
+  const bool tail = (flags & GLFER_WAV_PARTIAL_TAIL) && rest > 0 && mode != GLFER_MODE_LMP;
+  w.fresh = rest / w.esz;
+  size_t frames = w.whole + (tail ? 1 : 0);
+  w.with_tail = tail;
+  if (frames > max_frames) { frames = max_frames; w.with_tail = false; }
+  src->frames = frames;
+  // (a partial block with no fresh sample at all -- one odd byte of a 16-bit file -- is the previous
+  // block over again: tail_fresh = 0)
+  src->tail_fresh = w.with_tail ? (long)w.fresh : -1;
+  const std::string p(path);
+  src->open = [p, w] { return wav_reader(p, w); };
+  return GLFER_OK;
+}
+
+int check_devices(const int *devices, int nworkers) {
+  if (!devices || nworkers < 1 || nworkers > 64) return GLFER_E_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return hip_fail(hipGetLastError(), "hipGetDeviceCount");
   for (int i = 0; i < nworkers; i++)
     if (devices[i] < 0 || devices[i] >= ndev) return GLFER_E_ARG;
-  // hop and bins as every plan will compute them (fft.c:70)
-  const int hop = (int)(cfg->n * (1.0 - cfg->overlap));
-  if (hop <= 0) return GLFER_E_ARG;
-  const size_t frames = nsamples / (size_t)hop, bins = (size_t)cfg->n / 2 + 1;
-  *nframes_out = frames;
-  if (frames == 0) return GLFER_OK;
-  if (!h_psd) return GLFER_E_ARG;
-  const unsigned world = (unsigned)nworkers;
-  const size_t hop_bytes = (size_t)hop * sample_bytes(cfg->sample_format);
-  bool pinned_in = false;
-  {
-    DeviceGuard g0(devices[0]);                                  // (pointer attributes need a current device)
-    pinned_in = g0.error() == hipSuccess && is_pinned_host(h_stream);
-  }
+  return GLFER_OK;
+}
+
+// runs work(r) for r = 0 .. world-1, one host thread each (this thread takes worker 0); the first
+// failure's code and text are what the caller sees
+int on_workers(unsigned world, const std::function<int(unsigned)> &work) {
   std::vector<int> rcs(world, GLFER_OK);
   std::vector<std::string> msgs(world);
-  std::vector<size_t> done(world, 0);
-  auto work = [&](unsigned r) {
-    size_t first = 0, count = 0;
-    frame_range(frames, r, world, &first, &count);
-    if (count == 0) return;
-    glfer_hip_config c = *cfg;
-    c.device = devices[r];
-    glfer_hip_plan *plan = nullptr;
-    int rc = glfer_hip_plan_create(&c, &plan);
-    if (rc == GLFER_OK) {
-      Job job;
-      job.p = plan;
-      job.frame_lo = first;
-      job.frames = count;
-      job.read = array_reader(h_stream, hop_bytes);
-      if (pinned_in) job.pinned_src = (const unsigned char *)h_stream;
-      job.sink.h_psd = h_psd + first * bins;
-      rc = run_job(job, &done[r]);
-      if (rc == GLFER_OK && done[r] != count) rc = GLFER_E_HIP;
-    }
-    if (rc) msgs[r] = glfer::error_text();
-    glfer_hip_plan_destroy(plan);
-    rcs[r] = rc;
+  auto run = [&](unsigned r) {
+    rcs[r] = work(r);
+    if (rcs[r]) msgs[r] = glfer::error_text();
   };
   std::vector<std::thread> th;
   for (unsigned r = 1; r < world; r++) {
     try {
-      th.emplace_back(work, r);
+      th.emplace_back(run, r);
     } catch (...) {
-      work(r);                                   // no thread to be had: this one does that share too
+      run(r);                                    // no thread to be had: this one does that share too
     }
   }
-  work(0);
+  run(0);
   for (auto &t : th) t.join();
   for (unsigned r = 0; r < world; r++)
     if (rcs[r]) {
@@ -424,19 +489,214 @@ int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *d
   return GLFER_OK;
 }
 
+// ---- multi-GPU: source.c:130-158 over one stream, the frame range dealt out over the GPUs of the
+// node.  One host thread per GPU, each with its own plan, streams, reader and pinned ring (run_job);
+// the ranges come from the same arithmetic as glfer_amd/shard.py; rows land in disjoint ranges of
+// h_psd; nothing is exchanged between GPUs.
+// One worker (host thread + plan + two streams + pinned ring) per entry of devices[]; an ordinal may
+// appear more than once -- several workers then share that GPU, which is how a one-GPU box exercises
+// the whole multi-worker path (frame offsets, halos from the middle of the stream, disjoint rows).
+int psd_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, const Source &src, float *h_psd) {
+  const unsigned world = (unsigned)nworkers;
+  const size_t frames = src.frames, bins = (size_t)cfg->n / 2 + 1;
+  return on_workers(world, [&](unsigned r) -> int {
+    size_t first = 0, count = 0;
+    frame_range(frames, r, world, &first, &count);
+    if (count == 0) return GLFER_OK;
+    glfer_hip_config c = *cfg;
+    c.device = devices[r];
+    glfer_hip_plan *plan = nullptr;
+    int rc = glfer_hip_plan_create(&c, &plan);
+    if (rc == GLFER_OK) {
+      Job job;
+      job.p = plan;
+      job.frame_lo = first;
+      job.frames = count;
+      job.tail_fresh = first + count == frames ? src.tail_fresh : -1;   // the partial block is the stream's last frame
+      job.read = src.open();
+      job.pinned_src = src.pinned_src;
+      job.sink.h_psd = h_psd + first * bins;
+      size_t done = 0;
+      rc = job.read ? run_job(job, &done) : GLFER_E_ARG;
+      if (rc == GLFER_OK && done != count) rc = GLFER_E_HIP;
+    }
+    std::string msg = rc ? glfer::error_text() : std::string();
+    glfer_hip_plan_destroy(plan);
+    if (rc) glfer::set_error_text(msg);
+    return rc;
+  });
+}
+
+// The waterfall of main_window_draw (g_main.c:1099-1236) over several workers.  The level tracking is
+// one chain over ALL columns (g_main.c:1111-1124), fed by the 16 bytes of compute_floor statistics
+// per column; everything else is per column.  Three phases: (1) every worker computes its frames' PSD
+// rows -- they STAY on its GPU -- and their statistics; with a moving average of depth D it
+// recomputes the D rows in front of its range instead of receiving them; (2) the
+// statistics meet on the host and one walk gives every column its levels (glfer_hip_levels_host);
+// (3) every worker maps its own rows with its slice of the levels and sends the pixels home.  What
+// crosses between GPUs, through the host: 16 + 16 bytes per column.
+struct AvgArgs { int mode, depth, minbin, maxbin, max0; };
+int waterfall_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, const Source &src,
+                      glfer_hip_display *disp, const AvgArgs &av, unsigned char *h_rgb, short *h_lev) {
+  const unsigned world = (unsigned)nworkers;
+  const size_t frames = src.frames, bins = (size_t)cfg->n / 2 + 1;
+  struct Worker {
+    glfer_hip_plan *plan = nullptr;
+    size_t first = 0, count = 0, lead = 0;
+    float *d_rows = nullptr, *d_stats = nullptr;
+  };
+  std::vector<Worker> ws(world);
+  std::vector<float> stats(frames * 4), levels(frames * 4);
+  auto release = [&] {
+    for (unsigned r = 0; r < world; r++) {
+      DeviceGuard g(devices[r]);
+      if (ws[r].d_rows) (void)hipFree(ws[r].d_rows);
+      if (ws[r].d_stats) (void)hipFree(ws[r].d_stats);
+      glfer_hip_plan_destroy(ws[r].plan);
+      ws[r] = Worker();
+    }
+  };
+  // (1) rows + statistics, resident
+  int rc = on_workers(world, [&](unsigned r) -> int {
+    Worker &w = ws[r];
+    frame_range(frames, r, world, &w.first, &w.count);
+    if (w.count == 0) return GLFER_OK;
+    w.lead = av.mode ? std::min(w.first, (size_t)av.depth) : 0;
+    glfer_hip_config c = *cfg;
+    c.device = devices[r];
+    int rc = glfer_hip_plan_create(&c, &w.plan);
+    if (rc) return rc;
+    DeviceGuard g(devices[r]);
+    HIP_TRY(g.error());
+    const size_t nrows = w.lead + w.count;
+    hipError_t e = hipMalloc((void **)&w.d_rows, nrows * bins * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&w.d_stats, nrows * 4 * sizeof(float));
+    if (e != hipSuccess) return hip_fail(e, "waterfall workers: rows");
+    Job job;
+    job.p = w.plan;
+    job.frame_lo = w.first - w.lead;
+    job.frames = nrows;
+    job.tail_fresh = w.first + w.count == frames ? src.tail_fresh : -1;
+    job.read = src.open();
+    job.pinned_src = src.pinned_src;
+    job.sink.d_rows = w.d_rows;
+    job.sink.d_stats = w.d_stats;
+    size_t done = 0;
+    rc = job.read ? run_job(job, &done) : GLFER_E_ARG;
+    if (rc == GLFER_OK && done != nrows) rc = GLFER_E_HIP;
+    if (rc) return rc;
+    e = hipMemcpy(stats.data() + w.first * 4, w.d_stats + w.lead * 4, w.count * 4 * sizeof(float), hipMemcpyDeviceToHost);
+    return e == hipSuccess ? GLFER_OK : hip_fail(e, "waterfall workers: statistics");
+  });
+  // (2) one walk over all columns
+  if (rc == GLFER_OK) rc = glfer_hip_levels_host(disp, stats.data(), frames, levels.data(), devices[0]);
+  // (3) the pixel map, each worker its own columns
+  if (rc == GLFER_OK)
+    rc = on_workers(world, [&](unsigned r) -> int {
+      Worker &w = ws[r];
+      if (w.count == 0) return GLFER_OK;
+      DeviceGuard g(devices[r]);
+      HIP_TRY(g.error());
+      float *d_levels = nullptr;
+      unsigned char *d_rgb = nullptr;
+      short *d_lev = nullptr;
+      int rc = GLFER_OK;
+      hipError_t e = hipMalloc((void **)&d_levels, w.count * 4 * sizeof(float));
+      if (e == hipSuccess) e = hipMalloc((void **)&d_rgb, w.count * bins * 3);
+      if (e == hipSuccess && h_lev) e = hipMalloc((void **)&d_lev, w.count * bins * sizeof(short));
+      if (e == hipSuccess) e = hipMemcpy(d_levels, levels.data() + w.first * 4, w.count * 4 * sizeof(float), hipMemcpyHostToDevice);
+      if (e != hipSuccess) rc = hip_fail(e, "waterfall workers: map buffers");
+      if (rc == GLFER_OK)
+        rc = glfer_hip_waterfall_map_device(disp, av.mode, av.depth, av.minbin, av.maxbin, av.max0, w.d_rows, w.lead, w.count,
+                                            (int)bins, d_levels, d_rgb, d_lev, nullptr);
+      if (rc == GLFER_OK) {
+        e = hipMemcpy(h_rgb + w.first * bins * 3, d_rgb, w.count * bins * 3, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && h_lev) e = hipMemcpy(h_lev + w.first * bins, d_lev, w.count * bins * sizeof(short), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "waterfall workers: pixels");
+      }
+      if (d_levels) (void)hipFree(d_levels);
+      if (d_rgb) (void)hipFree(d_rgb);
+      if (d_lev) (void)hipFree(d_lev);
+      return rc;
+    });
+  std::string msg = rc ? glfer::error_text() : std::string();
+  release();
+  if (rc) glfer::set_error_text(msg);
+  return rc;
+}
+
+int mask_to_devices(unsigned device_mask, int devs[32]) {
+  int n = 0;
+  for (int d = 0; d < 32; d++)
+    if (device_mask & (1u << d)) devs[n++] = d;
+  return n;
+}
+
+bool avg_args_ok(const AvgArgs &av, size_t bins) {
+  if (av.mode == 0) return true;
+  return av.mode >= GLFER_AVG_SUMAVG && av.mode <= GLFER_AVG_SUMEXTREME && av.depth >= 1 && av.minbin >= 0 && av.maxbin > av.minbin &&
+         (size_t)av.maxbin <= bins;
+}
+
+}  // namespace
+
+extern "C" {
+
+int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *devices, int nworkers,
+                                       const void *h_stream, size_t nsamples, float *h_psd, size_t *nframes_out) {
+  if (!cfg || !h_stream || !nframes_out) return GLFER_E_ARG;
+  int rc = check_devices(devices, nworkers);
+  if (rc) return rc;
+  // hop and bins as every plan will compute them (fft.c:70)
+  const int hop = (int)(cfg->n * (1.0 - cfg->overlap));
+  if (hop <= 0) return GLFER_E_ARG;
+  const size_t frames = nsamples / (size_t)hop;
+  *nframes_out = frames;
+  if (frames == 0) return GLFER_OK;
+  if (!h_psd) return GLFER_E_ARG;
+  bool pinned_in = false;
+  {
+    DeviceGuard g0(devices[0]);                                  // (pointer attributes need a current device)
+    pinned_in = g0.error() == hipSuccess && is_pinned_host(h_stream);
+  }
+  return psd_workers(cfg, devices, nworkers, array_source(h_stream, frames, (size_t)hop * sample_bytes(cfg->sample_format), pinned_in),
+                     h_psd);
+}
+
 // The GPUs named by a bit mask, one worker each.
 int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned device_mask, const void *h_stream,
                                      size_t nsamples, float *h_psd, size_t *nframes_out) {
   if (device_mask == 0) return GLFER_E_ARG;
-  int devs[32], n = 0;
-  for (int d = 0; d < 32; d++)
-    if (device_mask & (1u << d)) devs[n++] = d;
+  int devs[32];
+  const int n = mask_to_devices(device_mask, devs);
   return glfer_hip_spectrogram_host_workers(cfg, devs, n, h_stream, nsamples, h_psd, nframes_out);
 }
 
+int glfer_hip_waterfall_host_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, glfer_hip_display *disp,
+                                     int avg_mode, int depth, int minbin, int maxbin, int max0, const void *h_stream,
+                                     size_t nsamples, unsigned char *h_rgb, short *h_lev, size_t *nframes_out) {
+  if (!cfg || !disp || !h_stream || !nframes_out) return GLFER_E_ARG;
+  if (disp->scale_type < GLFER_SCALE_LIN || disp->scale_type > GLFER_SCALE_LOG_MAX0) return GLFER_E_ARG;
+  int rc = check_devices(devices, nworkers);
+  if (rc) return rc;
+  const int hop = (int)(cfg->n * (1.0 - cfg->overlap));
+  if (hop <= 0) return GLFER_E_ARG;
+  const AvgArgs av{avg_mode, depth, minbin, maxbin, max0};
+  if (!avg_args_ok(av, (size_t)cfg->n / 2 + 1)) return GLFER_E_ARG;
+  const size_t frames = nsamples / (size_t)hop;
+  *nframes_out = frames;
+  if (frames == 0) return GLFER_OK;
+  if (!h_rgb) return GLFER_E_ARG;
+  bool pinned_in = false;
+  {
+    DeviceGuard g0(devices[0]);
+    pinned_in = g0.error() == hipSuccess && is_pinned_host(h_stream);
+  }
+  return waterfall_workers(cfg, devices, nworkers, array_source(h_stream, frames, (size_t)hop * sample_bytes(cfg->sample_format), pinned_in),
+                           disp, av, h_rgb, h_lev);
+}
+
 // ---- ingest (wav_fmt.c:45-121, source.c:118-128) ------------------------------------------
-static unsigned rd_u16(const unsigned char *b) { return b[0] | (b[1] << 8); }
-static unsigned rd_u32(const unsigned char *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24); }
 
 // The reference takes the header as one fixed 44-byte struct (wav_fmt.h:34-52: "fmt " at byte 12, "data"
 // at byte 36, samples from byte 44) and reads samples until read() returns 0.  Files written by anything
@@ -500,68 +760,93 @@ int glfer_hip_wav_probe(const char *path, glfer_wav_info *info) {
   return GLFER_OK;
 }
 
-int glfer_hip_spectrogram_wav_ex(glfer_hip_plan *p, const char *path, float *h_psd, size_t max_frames,
-                                 size_t *nframes_out, size_t chunk_frames, unsigned flags) {
-  if (!p || !path || !nframes_out || (flags & ~(unsigned)GLFER_WAV_PARTIAL_TAIL)) return GLFER_E_ARG;
-  glfer_wav_info wi;
-  int rc = glfer_hip_wav_probe(path, &wi);
+// One GPU, frames [first_frame, first_frame + max_frames) of the file (clipped to what it holds): rows to
+// h_psd[0 ..).  The read-ahead of the per-hop shims (glfer_compat.cpp) walks a file in such windows.
+int glfer_hip_spectrogram_wav_range(glfer_hip_plan *p, const char *path, size_t first_frame, size_t max_frames, float *h_psd,
+                                    size_t *nframes_out, size_t chunk_frames, unsigned flags) {
+  if (!p || !path || !nframes_out) return GLFER_E_ARG;
+  Source src;
+  int rc = wav_source(path, p->hop, p->cfg.sample_format, p->cfg.mode, flags, (size_t)-1, &src);
   if (rc) return rc;
-  const int fmt = wi.bits_per_sample == 8 ? GLFER_SAMPLES_U8 : GLFER_SAMPLES_S16;
-  if (p->cfg.sample_format != fmt) return GLFER_E_ARG;
-  const size_t esz = (size_t)wi.bits_per_sample / 8, hop = (size_t)p->hop, hop_bytes = hop * esz;
-  const size_t whole = wi.data_bytes / hop_bytes;                // full blocks, wav_fmt.c:102
-  // wav_fmt.c:102-119: a short last read still counts as a block (n_read != 0) and converts
-  // n_read (8 bit) or n_read/2 (16 bit: an odd last byte is dropped) samples over the stale rest
-  const size_t rest = wi.data_bytes - whole * hop_bytes;
-  const bool tail = (flags & GLFER_WAV_PARTIAL_TAIL) && rest > 0 && p->cfg.mode != GLFER_MODE_LMP;
-  const size_t fresh = rest / esz;
-  size_t frames = whole + (tail ? 1 : 0);
-  bool with_tail = tail;
-  if (frames > max_frames) { frames = max_frames; with_tail = false; }
-  *nframes_out = frames;
-  if (frames == 0) return GLFER_OK;
+  size_t count = first_frame < src.frames ? src.frames - first_frame : 0;
+  bool with_tail = src.tail_fresh >= 0;
+  if (count > max_frames) { count = max_frames; with_tail = false; }
+  *nframes_out = count;
+  if (count == 0) return GLFER_OK;
   if (!h_psd) return GLFER_E_ARG;
-  FILE *f = fopen(path, "rb");
-  if (!f) return GLFER_E_ARG;
   Job job;
   job.p = p;
-  job.frames = frames;
+  job.frame_lo = first_frame;
+  job.frames = count;
   job.chunk_frames = chunk_frames;
-  // (a partial block with no fresh sample at all -- one odd byte of a 16-bit file -- is the previous
-  // block over again: tail_fresh = 0)
-  job.tail_fresh = with_tail ? (long)fresh : -1;
+  job.tail_fresh = with_tail ? src.tail_fresh : -1;
   job.sink.h_psd = h_psd;
-  const size_t data_offset = wi.data_offset;
-  job.read = [=](unsigned char *dst, size_t hop_index, size_t nhops) -> size_t {
-    if (fseek(f, (long)(data_offset + hop_index * hop_bytes), SEEK_SET) != 0) return 0;
-    const size_t full = hop_index + nhops <= whole ? nhops : (hop_index < whole ? whole - hop_index : 0);
-    if (fread(dst, 1, full * hop_bytes, f) != full * hop_bytes) return 0;
-    if (full == nhops) return nhops;
-    if (!with_tail || hop_index + nhops != whole + 1) return full;
-    // the trailing partial block: its fresh samples, then the RAW samples of the block before at
-    // the same positions (zeros -- the calloc of wav_fmt.c:99 -- for a file shorter than one block).
-    // With per-hop mean removal the device replaces the stale part by the corrected previous hop.
-    unsigned char *last = dst + full * hop_bytes;
-    if (whole == 0) {
-      memset(last, esz == 1 ? 0x80 : 0, hop_bytes);               // sample value 0.0 (u8: 128)
-    } else if (full > 0) {
-      memcpy(last, last - hop_bytes, hop_bytes);
-    } else {
-      if (fseek(f, (long)(data_offset + (whole - 1) * hop_bytes), SEEK_SET) != 0) return full;
-      if (fread(last, 1, hop_bytes, f) != hop_bytes) return full;
-      if (fseek(f, (long)(data_offset + whole * hop_bytes), SEEK_SET) != 0) return full;
-    }
-    if (fresh && fread(last, 1, fresh * esz, f) != fresh * esz) return full;
-    return nhops;
-  };
-  rc = run_job(job, nframes_out);
-  fclose(f);
-  return rc;
+  job.read = src.open();
+  if (!job.read) return GLFER_E_ARG;
+  return run_job(job, nframes_out);
+}
+
+int glfer_hip_spectrogram_wav_ex(glfer_hip_plan *p, const char *path, float *h_psd, size_t max_frames,
+                                 size_t *nframes_out, size_t chunk_frames, unsigned flags) {
+  return glfer_hip_spectrogram_wav_range(p, path, 0, max_frames, h_psd, nframes_out, chunk_frames, flags);
 }
 
 int glfer_hip_spectrogram_wav(glfer_hip_plan *p, const char *path, float *h_psd, size_t max_frames,
                               size_t *nframes_out, size_t chunk_frames) {
   return glfer_hip_spectrogram_wav_ex(p, path, h_psd, max_frames, nframes_out, chunk_frames, 0);
+}
+
+// BASELINE config 4 as worded -- "1-hour 48 kHz WAV, frame-batch sharded across 8 x MI355X": the file's
+// frames dealt out over the workers, every worker reading its own part of the file (its hops + the
+// history halo) through its own handle and pinned ring; rows to disjoint ranges of h_psd.
+int glfer_hip_spectrogram_wav_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, const char *path,
+                                      float *h_psd, size_t max_frames, size_t *nframes_out, unsigned flags) {
+  if (!cfg || !path || !nframes_out) return GLFER_E_ARG;
+  int rc = check_devices(devices, nworkers);
+  if (rc) return rc;
+  Source src;
+  rc = wav_source(path, (int)(cfg->n * (1.0 - cfg->overlap)), cfg->sample_format, cfg->mode, flags, max_frames, &src);
+  if (rc) return rc;
+  *nframes_out = src.frames;
+  if (src.frames == 0) return GLFER_OK;
+  if (!h_psd) return GLFER_E_ARG;
+  return psd_workers(cfg, devices, nworkers, src, h_psd);
+}
+
+int glfer_hip_spectrogram_wav_multi(const glfer_hip_config *cfg, unsigned device_mask, const char *path, float *h_psd,
+                                    size_t max_frames, size_t *nframes_out, unsigned flags) {
+  if (device_mask == 0) return GLFER_E_ARG;
+  int devs[32];
+  const int n = mask_to_devices(device_mask, devs);
+  return glfer_hip_spectrogram_wav_workers(cfg, devs, n, path, h_psd, max_frames, nframes_out, flags);
+}
+
+int glfer_hip_waterfall_wav_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, glfer_hip_display *disp,
+                                    int avg_mode, int depth, int minbin, int maxbin, int max0, const char *path,
+                                    size_t max_frames, unsigned char *h_rgb, short *h_lev, size_t *nframes_out, unsigned flags) {
+  if (!cfg || !disp || !path || !nframes_out) return GLFER_E_ARG;
+  if (disp->scale_type < GLFER_SCALE_LIN || disp->scale_type > GLFER_SCALE_LOG_MAX0) return GLFER_E_ARG;
+  int rc = check_devices(devices, nworkers);
+  if (rc) return rc;
+  const AvgArgs av{avg_mode, depth, minbin, maxbin, max0};
+  if (!avg_args_ok(av, (size_t)cfg->n / 2 + 1)) return GLFER_E_ARG;
+  Source src;
+  rc = wav_source(path, (int)(cfg->n * (1.0 - cfg->overlap)), cfg->sample_format, cfg->mode, flags, max_frames, &src);
+  if (rc) return rc;
+  *nframes_out = src.frames;
+  if (src.frames == 0) return GLFER_OK;
+  if (!h_rgb) return GLFER_E_ARG;
+  return waterfall_workers(cfg, devices, nworkers, src, disp, av, h_rgb, h_lev);
+}
+
+int glfer_hip_waterfall_wav_multi(const glfer_hip_config *cfg, unsigned device_mask, glfer_hip_display *disp, int avg_mode,
+                                  int depth, int minbin, int maxbin, int max0, const char *path, size_t max_frames,
+                                  unsigned char *h_rgb, short *h_lev, size_t *nframes_out, unsigned flags) {
+  if (device_mask == 0) return GLFER_E_ARG;
+  int devs[32];
+  const int n = mask_to_devices(device_mask, devs);
+  return glfer_hip_waterfall_wav_workers(cfg, devs, n, disp, avg_mode, depth, minbin, maxbin, max0, path, max_frames, h_rgb, h_lev,
+                                         nframes_out, flags);
 }
 
 }  // extern "C"

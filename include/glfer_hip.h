@@ -252,6 +252,24 @@ int glfer_hip_spectrogram_wav(glfer_hip_plan *plan, const char *path, float *h_p
 int glfer_hip_spectrogram_wav_ex(glfer_hip_plan *plan, const char *path, float *h_psd, size_t max_frames,
                                  size_t *nframes_out, size_t chunk_frames, unsigned flags);
 
+/* The same for frames [first_frame, first_frame + max_frames) of the file only: rows to h_psd[0 ..).
+ * (The per-hop shims' read-ahead walks a file in such windows, glfer_compat.h.) */
+int glfer_hip_spectrogram_wav_range(glfer_hip_plan *plan, const char *path, size_t first_frame, size_t max_frames,
+                                    float *h_psd, size_t *nframes_out, size_t chunk_frames, unsigned flags);
+
+/* BASELINE config 4 as worded ("1-hour 48 kHz WAV, frame-batch sharded across 8 x MI355X"): the
+ * file's frames dealt out over the GPUs named in device_mask (glfer_hip_frame_range: contiguous
+ * ranges, boundaries on multiples of GLFER_FRAME_ALIGN), one host thread + plan + pinned ring per
+ * GPU, every worker reading its own part of the file -- its hops and the history halo in front of
+ * them -- through its own handle (source.c:193, wav_fmt.c:45-121); rows land in disjoint ranges of
+ * h_psd [frames][N/2+1]; no collective.  _workers: the workers listed; an ordinal may repeat (several
+ * workers then share that GPU -- how a one-GPU box exercises the path).  cfg->sample_format must
+ * match the file; flags as glfer_hip_spectrogram_wav_ex (the partial block belongs to the last worker). */
+int glfer_hip_spectrogram_wav_multi(const glfer_hip_config *cfg, unsigned device_mask, const char *path, float *h_psd,
+                                    size_t max_frames, size_t *nframes_out, unsigned flags);
+int glfer_hip_spectrogram_wav_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, const char *path,
+                                      float *h_psd, size_t max_frames, size_t *nframes_out, unsigned flags);
+
 /* K0 on its own: per-hop mean removal (fft.c:86-96).  d_out[i] = sample(d_in[i]) - mean of the
  * hop i belongs to; nhops hops of `hop` samples each.  (The spectrogram entries apply it
  * themselves when cfg.sub_mean is set; this entry serves the per-hop shims, which must hand
@@ -331,12 +349,54 @@ int glfer_hip_waterfall_device(glfer_hip_display *disp, int avg_mode, int depth,
                                int max0, const float *d_psd, size_t nframes, int bins,
                                unsigned char *d_rgb, short *d_lev, float *d_stats, void *hip_stream);
 
+/* The two halves of glfer_hip_waterfall_device for a waterfall whose columns live on several GPUs
+ * (or are computed piece by piece).  The level tracking of main_window_draw (g_main.c:1111-1124) is
+ * ONE chain over all columns, fed by the 16 bytes of compute_floor statistics per column; everything
+ * else is per column.  So each GPU computes its rows and their statistics
+ * (glfer_hip_spectrogram_device + glfer_hip_floor_device), the statistics meet on the host,
+ *   glfer_hip_levels_host(disp, h_stats [n][4], n, h_levels [n][4], device)
+ * walks them once (on `device`; disp's carried state in and out, exactly as
+ * glfer_hip_display_device would leave it), and each GPU maps its own rows with its slice of the levels:
+ *   glfer_hip_waterfall_map_device(disp, avg_mode, depth, minbin, maxbin, max0, d_batch, first, n,
+ *                                  bins, d_levels [n][4], d_rgb, d_lev, stream)
+ * maps rows [first, first + n) of the device batch d_batch ([.][bins] floats).  With averaging the
+ * moving sums of the first rows reach back into the batch's rows BEFORE `first` -- a piece that is
+ * not the start of the waterfall carries `depth` recomputed rows in front (recompute,
+ * do not exchange); the state is empty at row 0 of the batch (alloc_avg, avg.c:38-60).  disp is
+ * not modified. */
+int glfer_hip_levels_host(glfer_hip_display *disp, const float *h_stats, size_t nframes, float *h_levels, int device);
+int glfer_hip_waterfall_map_device(const glfer_hip_display *disp, int avg_mode, int depth, int minbin, int maxbin,
+                                   int max0, const float *d_batch, size_t first, size_t nframes, int bins,
+                                   const float *d_levels, unsigned char *d_rgb, short *d_lev, void *hip_stream);
+
 /* Host samples -> waterfall columns: estimator, compute_floor and the display mapping on the
  * device, chunked through the same ring as glfer_hip_spectrogram_host; what comes back is
  * h_rgb [frames][bins][3] (and h_lev [frames][bins] shorts, or NULL): 3-5 bytes per bin over PCIe
  * instead of 4, and pixels instead of PSD rows.  disp carries the level-tracking state. */
 int glfer_hip_waterfall_host(glfer_hip_plan *plan, glfer_hip_display *disp, const void *h_stream,
                              size_t nsamples, unsigned char *h_rgb, short *h_lev, size_t *nframes_out);
+
+/* The waterfall over several GPUs (samples from a host array, or a WAV file): h_rgb [frames][bins][3]
+ * (+ h_lev) identical to the one-GPU call's.  Three phases: every worker computes its frames' rows,
+ * which stay on its GPU, and their compute_floor statistics; the statistics (16 bytes per column)
+ * meet on the host and ONE walk gives every column its levels (glfer_hip_levels_host -- the level
+ * tracking of g_main.c:1111-1124 is a chain over all columns); every worker maps its own rows with
+ * its slice of the levels.  avg_mode != 0: update_avg_* (avg.c:108-298) inside the map; a worker whose
+ * range starts at frame f > 0 RECOMPUTES the `depth` rows in front of it instead of receiving them
+ *  -- the moving average crosses worker boundaries without an exchange.  disp carries
+ * the level-tracking state in and out. */
+int glfer_hip_waterfall_host_workers(const glfer_hip_config *cfg, const int *devices, int nworkers,
+                                     glfer_hip_display *disp, int avg_mode, int depth, int minbin, int maxbin, int max0,
+                                     const void *h_stream, size_t nsamples, unsigned char *h_rgb, short *h_lev,
+                                     size_t *nframes_out);
+int glfer_hip_waterfall_wav_workers(const glfer_hip_config *cfg, const int *devices, int nworkers,
+                                    glfer_hip_display *disp, int avg_mode, int depth, int minbin, int maxbin, int max0,
+                                    const char *path, size_t max_frames, unsigned char *h_rgb, short *h_lev,
+                                    size_t *nframes_out, unsigned flags);
+int glfer_hip_waterfall_wav_multi(const glfer_hip_config *cfg, unsigned device_mask, glfer_hip_display *disp,
+                                  int avg_mode, int depth, int minbin, int maxbin, int max0, const char *path,
+                                  size_t max_frames, unsigned char *h_rgb, short *h_lev, size_t *nframes_out,
+                                  unsigned flags);
 
 /* Device scratch the library keeps between calls.  Per-call scratch of 16 MiB and more (averaged
  * rows of a staged waterfall tile, the mean-corrected copy of a stream, big-block and LMP / F-test

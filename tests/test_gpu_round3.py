@@ -331,7 +331,7 @@ def test_wav_with_list_chunks_around_the_data(lib, oracle, torch_cuda, tmp_path)
     info = lib.wav_probe(str(odd))
     assert info.bits_per_sample == 16 and info.sample_rate == 8000 and info.nsamples == pcm.size and info.data_offset > 44
     assert lib.wav_probe(str(plain)).data_offset == 44
-    sp = lib.Spectrogram(lib.FftParams(n=1024, window_type=1, overlap=0.5, sample_format=lib.SAMPLES_S16))
+    sp = lib.Spectrogram(lib.FftParams(n=1024, window_type=lib.WINDOWS["hanning"], overlap=0.5, sample_format=lib.SAMPLES_S16))
     a = sp.run_wav(str(plain), chunk_frames=32)
     b = sp.run_wav(str(odd), chunk_frames=32)
     assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
@@ -344,3 +344,88 @@ def test_wav_with_list_chunks_around_the_data(lib, oracle, torch_cuda, tmp_path)
     raw[40:44] = (0).to_bytes(4, "little")
     cut.write_bytes(bytes(raw))
     assert lib.wav_probe(str(cut)).nsamples == pcm.size
+
+
+# ---- BASELINE config 4 as worded: a WAV file's frames over several workers ----------------------------
+def _write_wav16(path, pcm, rate=48000):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(rate)
+        w.writeframes(pcm.tobytes())
+
+
+def test_wav_file_over_several_workers(lib, torch_cuda, tmp_path):
+    """glfer_hip_spectrogram_wav_workers: 2 and 3 workers on device 0, each reading its own part of
+    the file (hops + history halo) through its own handle: rows identical to the one-worker run, the
+    trailing partial block (wav_fmt.c:102-119) included; _multi with a one-GPU mask is the same call."""
+    S = lib.SAMPLES_S16
+    x = synth(16384 * 150 + 777, seed=61)
+    pcm = np.round(x * 32767).astype(np.int16)
+    path = tmp_path / "long.wav"
+    _write_wav16(path, pcm)
+    for params in (lib.MtmParams(n=16384, overlap=0.0, w=4.5, kmax=8, sample_format=S),             # C4's estimator
+                   lib.MtmParams(n=4096, overlap=0.75, w=2.5, kmax=4, sub_mean=1, sample_format=S),
+                   lib.FftParams(n=1024, window_type=1, overlap=0.9, sub_mean=1, sample_format=S),   # ragged hop, whole-hop halo
+                   lib.LmpParams(n=1024, overlap=0.5, avg=4, sample_format=S)):
+        for tail in (False, True):
+            if tail and isinstance(params, lib.LmpParams):
+                continue
+            sp = lib.Spectrogram(params)
+            want = sp.run_wav(str(path), partial_tail=tail)
+            one = lib.spectrogram_wav_workers(params, str(path), [0], partial_tail=tail)
+            assert np.array_equal(one.view(np.uint32), want.view(np.uint32))
+            for devices in ([0, 0], [0, 0, 0]):
+                got = lib.spectrogram_wav_workers(params, str(path), devices, partial_tail=tail)
+                assert got.shape == want.shape
+                same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+                assert same.all(), (type(params).__name__, params.n, len(devices), tail)
+
+
+@pytest.mark.parametrize("avg_mode", ["none", "plain", "sumextreme", "sumavg"])
+def test_waterfall_over_several_workers(lib, torch_cuda, tmp_path, avg_mode):
+    """glfer_hip_waterfall_host_workers / _wav_workers: the level tracking walks ALL columns once
+    (statistics gathered on the host), the moving average crosses worker boundaries by recomputing
+    `depth` rows -- pixels and levbuf identical to the one-worker call and, without averaging, to the
+    chunked one-GPU entry glfer_hip_waterfall_host."""
+    torch = torch_cuda
+    mode = {"none": 0, "plain": lib.AVG_PLAIN, "sumextreme": lib.AVG_SUMEXTREME, "sumavg": lib.AVG_SUMAVG}[avg_mode]
+    params = lib.FftParams(n=1024, window_type=7, overlap=0.5, sub_mean=1)
+    hop = 512
+    frames = 9000
+    x = synth(frames * hop, seed=71) * np.float32(0.6)
+    x[2000 * hop:2600 * hop] *= np.float32(0.05)                      # the levels have something to track
+    kw = dict(scale_type=lib.SCALE_LOG, autoscale=1, overlap=0.5, palette=7)
+    av = dict(avg_mode=mode, depth=7, minbin=5, maxbin=500, max0=1)
+    d1 = lib.Display(**kw)
+    want_rgb, want_lev = lib.waterfall_workers(params, d1, [0], samples=x, **av)
+    assert want_rgb.shape == (frames, 513, 3)
+    if mode == 0:
+        d0 = lib.Display(**kw)
+        sp = lib.Spectrogram(params)
+        rgb0, lev0 = sp.waterfall_host(x, d0)
+        assert np.array_equal(rgb0, want_rgb) and np.array_equal(lev0, want_lev)
+        assert (d0.display_max_lvl, d0.display_min_lvl, d0.first_buffer) == (d1.display_max_lvl, d1.display_min_lvl, d1.first_buffer)
+    else:
+        # the one-GPU device entry on the rows of a one-shot run
+        sp = lib.Spectrogram(params)
+        rows = sp.run(torch.from_numpy(x).cuda())
+        dd = lib.Display(**kw)
+        rgb_d, lev_d, _ = lib.waterfall(dd, rows, **av)
+        assert np.array_equal(rgb_d.cpu().numpy(), want_rgb) and np.array_equal(lev_d.cpu().numpy(), want_lev)
+    for devices in ([0, 0], [0, 0, 0]):
+        dn = lib.Display(**kw)
+        rgb, lev = lib.waterfall_workers(params, dn, devices, samples=x, **av)
+        assert np.array_equal(rgb, want_rgb), (avg_mode, len(devices))
+        assert np.array_equal(lev, want_lev), (avg_mode, len(devices))
+        assert (dn.display_max_lvl, dn.display_min_lvl, dn.first_buffer) == (d1.display_max_lvl, d1.display_min_lvl, d1.first_buffer)
+    # the same from a file
+    S = lib.SAMPLES_S16
+    pcm = np.round(x * 32767).astype(np.int16)
+    path = tmp_path / "wf.wav"
+    _write_wav16(path, pcm, rate=8000)
+    fparams = lib.FftParams(n=1024, window_type=7, overlap=0.5, sub_mean=1, sample_format=S)
+    a_rgb, a_lev = lib.waterfall_workers(fparams, lib.Display(**kw), [0], path=str(path), **av)
+    b_rgb, b_lev = lib.waterfall_workers(fparams, lib.Display(**kw), [0, 0, 0], path=str(path), **av)
+    assert np.array_equal(a_rgb, b_rgb) and np.array_equal(a_lev, b_lev)
