@@ -43,7 +43,7 @@ EXPORTS = [
     "glfer_hip_scratch_trim", "glfer_hip_scratch_held", "glfer_hip_scratch_limit", "glfer_hip_spectrogram_wav_range",
     "glfer_hip_spectrogram_wav_multi", "glfer_hip_spectrogram_wav_workers", "glfer_hip_levels_host",
     "glfer_hip_waterfall_map_device", "glfer_hip_waterfall_host_workers", "glfer_hip_waterfall_wav_workers",
-    "glfer_hip_waterfall_wav_multi",
+    "glfer_hip_waterfall_wav_multi", "glfer_hip_submean_exact_device",
 ]
 
 
@@ -122,6 +122,7 @@ def lib():
     L.glfer_hip_wav_probe.argtypes = [C.c_char_p, C.POINTER(WavInfo)]
     L.glfer_hip_spectrogram_wav.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz), sz]
     L.glfer_hip_submean_device.argtypes = [vp, vp, C.c_int, sz, C.c_int, vp]
+    L.glfer_hip_submean_exact_device.argtypes = [vp, vp, C.c_int, sz, C.c_int, vp]
     L.glfer_hip_floor_device.argtypes = [vp, sz, C.c_int, vp, vp]
     L.glfer_hip_palette.argtypes = [C.c_int, vp]
     L.glfer_hip_display_device.argtypes = [C.POINTER(Display), vp, vp, vp, sz, C.c_int, vp, vp, vp, vp]

@@ -15,7 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
+#include <string>
+#include <thread>
 #include <vector>
 
 extern "C" {
@@ -27,6 +30,8 @@ int glfer_compat_autoscale = 1;        // opt.autoscale default, glfer.c:275
 int glfer_compat_first_buffer = 1;     // glfer.first_buffer = TRUE at start-up, g_main.c:990
 int glfer_compat_get_autoscale(void) { return &opt ? opt.autoscale : glfer_compat_autoscale; }
 int glfer_compat_get_first_buffer(void) { return &glfer ? glfer.first_buffer : glfer_compat_first_buffer; }
+int glfer_compat_readahead = 1;        // 0: every hop of a file source goes through the per-hop path
+unsigned long glfer_compat_readahead_served = 0;   // hops served from a device-computed batch (a counter for tests and logs)
 }
 
 namespace {
@@ -49,6 +54,8 @@ struct Engine {
   float *d_frame = nullptr, *d_psd = nullptr, *d_spec = nullptr;
   std::vector<float> psd;          // last PSD, served by fft_psd()
   int n = 0;
+  glfer_hip_config cfg{};          // what the plan was made from (the read-ahead's batch plan starts from it)
+  const fft_params_t *fp = nullptr; // the estimator's frame parameters (overlap, sub_mean)
 };
 std::map<const void *, Engine> g_engines;   // keyed by the caller's params struct
 
@@ -61,19 +68,33 @@ Engine &engine_for(const void *key) {
   return it->second;
 }
 
-void engine_open(const void *key, const glfer_hip_config &cfg, bool want_spec) {
+void reader_prepare();
+void engine_open(const void *key, const glfer_hip_config &cfg, bool want_spec, const fft_params_t *fp) {
   Engine e;
   int rc = glfer_hip_plan_create(&cfg, &e.plan);
   if (rc) die("plan_create", rc);
   e.n = cfg.n;
+  e.cfg = cfg;
+  e.fp = fp;
   hipck(hipMalloc((void **)&e.d_frame, (size_t)cfg.n * sizeof(float)), "hipMalloc frame");
   hipck(hipMalloc((void **)&e.d_psd, (size_t)(cfg.n / 2 + 1) * sizeof(float)), "hipMalloc psd");
   if (want_spec) hipck(hipMalloc((void **)&e.d_spec, (size_t)cfg.n * sizeof(float)), "hipMalloc spec");
   e.psd.assign(cfg.n / 2 + 1, 0.0f);
+  // the library's device code is loaded by its first launch (tens of ms for the whole set of kernels):
+  // here, at *_init, not under the first hop
+  hipck(hipMemset(e.d_psd, 0, (size_t)(cfg.n / 2 + 1) * sizeof(float)), "hipMemset");
+  int wrc = glfer_hip_floor_device(e.d_psd, 1, cfg.n / 2 + 1, e.d_frame, nullptr);
+  if (wrc) die("warm-up launch", wrc);
+  hipck(hipDeviceSynchronize(), "hipDeviceSynchronize");
   g_engines[key] = e;
+  reader_prepare();                 // a file is open already: its first window now, not under the first hop
 }
 
+void reader_forget(const void *owner);
+void reader_bypassed(const float *audio_buf);
+void reader_sync_state(const float *audio_buf, fft_params_t *fp);
 void engine_close(const void *key) {
+  reader_forget(key);
   auto it = g_engines.find(key);
   if (it == g_engines.end()) return;
   glfer_hip_plan_destroy(it->second.plan);
@@ -90,8 +111,10 @@ void assemble(float *audio_buf, fft_params_t *p) {
   const int h = (int)(n * (1.0 - p->overlap));
   const int keep = n - h;
   if (p->sub_mean) {
-    // K0 on the device; the corrected hop goes back into the caller's buffer, which the
-    // reference mutates in place (fft.c:93-95)
+    // K0 on the device, the hop summed in the reference's own order (fft.c:88-92: a float accumulated
+    // sample after sample -- observable on streams with a DC level, glfer_hip.h GLFER_SUBMEAN_EXACT);
+    // the corrected hop goes back into the caller's buffer, which the reference mutates in place
+    // (fft.c:93-95)
     static float *d_hop = nullptr;
     static int d_hop_len = 0;
     if (h > d_hop_len) {
@@ -100,7 +123,7 @@ void assemble(float *audio_buf, fft_params_t *p) {
       d_hop_len = h;
     }
     hipck(hipMemcpy(d_hop, audio_buf, (size_t)h * sizeof(float), hipMemcpyHostToDevice), "H2D hop");
-    int rc = glfer_hip_submean_device(d_hop, d_hop, h, 1, GLFER_SAMPLES_F32, nullptr);
+    int rc = glfer_hip_submean_exact_device(d_hop, d_hop, h, 1, GLFER_SAMPLES_F32, nullptr);
     if (rc) die("submean", rc);
     hipck(hipMemcpy(audio_buf, d_hop, (size_t)h * sizeof(float), hipMemcpyDeviceToHost), "D2H hop");
   }
@@ -108,6 +131,349 @@ void assemble(float *audio_buf, fft_params_t *p) {
   else memset(p->inbuf_audio, 0, (size_t)keep * sizeof(float));
   memcpy(p->inbuf_audio + keep, audio_buf, (size_t)h * sizeof(float));
 }
+
+
+// ---- the file source (wav_fmt.h:24-26) and the read-ahead behind the per-hop entry points ------------
+//
+// glfer's loop over a file is wav_read() -> fft_do() / mtm_do() -> main_window_draw(), one hop at a
+// time (source.c:112-171).  Served hop by hop that is two or three blocking copies and a launch
+// per hop; the batch engine does the same file at the GPU's rate.  So the reader is exported from this
+// library as well (same three functions, same buffer semantics as wav_fmt.c:45-141), and when an
+// estimator is handed the READER'S OWN buffer, untouched, for the file's hops in order, its rows
+// come from a batch the device computed from the file itself (glfer_hip_spectrogram_wav_range, a
+// window of frames at a time, the next window computed on a second host thread while this one is
+// served; per-hop means in the reference's order, GLFER_SUBMEAN_EXACT).  Anything else -- another
+// buffer, samples changed after wav_read, a hop skipped or repeated, the history flag
+// (glfer.first_buffer) not following the pattern of the mode, the scope window open (it reads
+// inbuf_fft), LMP mode -- goes through the per-hop launch as before, from that hop on.  While hops are
+// served the estimator's host-side state (inbuf_audio; the caller's buffer with its mean removed,
+// fft.c:93-95) is NOT touched -- nothing reads it -- and it is rebuilt from the file, once, at the hop
+// where the per-hop path takes over (reader_sync_state), so the hand-over is exact.
+// glfer_compat_readahead = 0 turns the read-ahead off.
+struct Window {
+  std::vector<float> rows;
+  size_t first = 0, count = 0;           // rows holds frames [first, first + count)
+};
+struct Reader {
+  FILE *f = nullptr;
+  std::string path;
+  glfer_wav_info info{};
+  int out_len = 1024;                    // samples per block, wav_fmt.c:42 (FIXME there too)
+  unsigned char *buf = nullptr;          // raw block, wav_fmt.c:90-96
+  float *buff = nullptr;                 // the block as floats, handed to the caller (wav_fmt.c:99)
+  size_t data_left = 0;                  // bytes of the data chunk still to read
+  size_t blocks = 0;                     // blocks handed out; buff holds block number blocks - 1
+  size_t last_samples = 0;               // fresh samples of the block in buff (< out_len: the trailing partial block)
+  unsigned long long stamp = 0;          // checksum of buff as it was handed out
+  bool fresh = false;                    // no estimator has taken the block in buff yet
+  // read-ahead
+  const void *owner = nullptr;           // the estimator the batch belongs to
+  glfer_hip_config cfg{};
+  glfer_hip_plan *plan = nullptr;
+  Window win[2];
+  int cur = 0;                           // win[cur] is being served, win[cur ^ 1] is being computed / waits
+  std::thread fetcher;
+  bool fetching = false;
+  int fetch_rc = GLFER_OK;
+  size_t taken = 0;                      // blocks the owner has taken, all of them in file order from block 0
+  size_t state_hops = 0;                 // the owner's host-side state (inbuf_audio) reflects hops [0, state_hops)
+  bool off = false;                      // given up for this file
+};
+Reader g_rd;
+
+// GLFER_COMPAT_TRACE=1: where the read-ahead's set-up time goes (stderr)
+double trace_now() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+void trace_log(const char *what, double t0) {
+  static const bool on = [] { const char *e = getenv("GLFER_COMPAT_TRACE"); return e && *e == '1'; }();
+  if (on) fprintf(stderr, "glfer_compat: %s %.2f ms\n", what, (trace_now() - t0) * 1e3);
+}
+
+// (four independent chains: a 2 KB block costs ~0.1 us)
+unsigned long long stamp_of(const float *x, int n) {
+  const unsigned *u = reinterpret_cast<const unsigned *>(x);
+  unsigned long long a = 0x9e3779b97f4a7c15ull, b = 0xc2b2ae3d27d4eb4full, c = 0x165667b19e3779f9ull, d = 0x27d4eb2f165667c5ull;
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {
+    a = (a + u[i]) * 0x100000001b3ull;
+    b = (b + u[i + 1]) * 0x100000001b3ull;
+    c = (c + u[i + 2]) * 0x100000001b3ull;
+    d = (d + u[i + 3]) * 0x100000001b3ull;
+  }
+  for (; i < n; i++) a = (a + u[i]) * 0x100000001b3ull;
+  return a ^ (b << 1 | b >> 63) ^ (c << 2 | c >> 62) ^ (d << 3 | d >> 61);
+}
+
+void reader_join() {
+  if (g_rd.fetching) {
+    g_rd.fetcher.join();
+    g_rd.fetching = false;
+  }
+}
+
+void reader_drop_batch() {
+  reader_join();
+  if (g_rd.plan) glfer_hip_plan_destroy(g_rd.plan);
+  g_rd.plan = nullptr;
+  for (Window &w : g_rd.win) {
+    w.rows.clear();
+    w.rows.shrink_to_fit();
+    w.first = w.count = 0;
+  }
+  g_rd.owner = nullptr;
+}
+
+// an entry point without read-ahead took the reader's block: no batch can follow for this file
+void reader_bypassed(const float *audio_buf) {
+  if (g_rd.f && audio_buf == g_rd.buff) g_rd.off = true;
+}
+
+void reader_forget(const void *owner) {            // the estimator is closed: its batch goes with it
+  if (g_rd.owner == owner) {
+    reader_drop_batch();
+    if (g_rd.taken) g_rd.off = true;                // a new estimator would start without this one's history
+  }
+}
+
+bool same_cfg(const glfer_hip_config &a, const glfer_hip_config &b) { return memcmp(&a, &b, sizeof a) == 0; }
+
+// frames [first, ...) into w: 64 MiB of rows at a time (at least 256 frames), through a ring of 4096-frame
+// chunks (a few MB of pinned memory: allocating the default ring's 100 MB costs more than a 10^5-hop
+// file takes).  The first window of a file is one chunk, so that the first column does not wait.
+int fetch_window(Window &w, size_t first, size_t bins) {
+  size_t nwin = ((size_t)64 << 20) / (bins * sizeof(float));
+  if (nwin < 256) nwin = 256;
+  const size_t chunk = 4096;
+  if (first == 0 && nwin > chunk) nwin = chunk;
+  const double tr0 = trace_now();
+  w.rows.resize(nwin * bins);
+  trace_log("read-ahead: rows.resize", tr0);
+  size_t got = 0;
+  const double tf0 = trace_now();
+  int rc = glfer_hip_spectrogram_wav_range(g_rd.plan, g_rd.path.c_str(), first, nwin, w.rows.data(), &got, chunk, GLFER_WAV_PARTIAL_TAIL);
+  trace_log(first == 0 ? "read-ahead: first window" : "read-ahead: window", tf0);
+  w.first = first;
+  w.count = rc == GLFER_OK ? got : 0;
+  return rc;
+}
+
+// the batch plan of an estimator over the open file: its own configuration with the real overlap, the
+// means in the reference's order, the history mode the flag's pattern stands for, the file's format
+glfer_hip_config batch_config(glfer_hip_config want, const fft_params_t *fp) {
+  want.overlap = fp->overlap;
+  want.sub_mean = fp->sub_mean ? GLFER_SUBMEAN_EXACT : GLFER_SUBMEAN_OFF;
+  want.history_mode = fp->sub_mean ? GLFER_HISTORY_ZERO_FIRST : GLFER_HISTORY_ZERO_ALWAYS;
+  want.sample_format = g_rd.info.bits_per_sample == 8 ? GLFER_SAMPLES_U8 : GLFER_SAMPLES_S16;
+  return want;
+}
+
+void start_prefetch(size_t next, size_t bins) {
+  Window *nx = &g_rd.win[g_rd.cur ^ 1];
+  g_rd.fetching = true;
+  g_rd.fetcher = std::thread([nx, next, bins] { g_rd.fetch_rc = fetch_window(*nx, next, bins); });
+}
+
+// "On open, run the batch engine over the file": as soon as a file is open AND one estimator is
+// initialised (source.c:193 and change_params, in either order) the batch plan is made and the file's
+// first window computed -- set-up (device code loaded by its first launch, pinned ring, pools: ~40 ms)
+// that belongs with fft_init / open_wav_file, not under the first column.  Speculative: the first
+// *_do checks the configuration again and starts over if another estimator turns up.
+void reader_prepare() {
+  Reader &r = g_rd;
+  if (!glfer_compat_readahead || !r.f || r.blocks != 0 || r.plan || r.off || g_engines.size() != 1) return;
+  const Engine &e = g_engines.begin()->second;
+  if (!e.fp || e.cfg.mode == GLFER_MODE_LMP) return;
+  if ((int)(e.fp->n * (1.0 - e.fp->overlap)) != r.out_len) return;
+  const glfer_hip_config want = batch_config(e.cfg, e.fp);
+  if (glfer_hip_plan_create(&want, &r.plan) != GLFER_OK) { r.plan = nullptr; return; }
+  r.cfg = want;
+  r.owner = g_engines.begin()->first;
+  const size_t bins = (size_t)e.fp->n / 2 + 1;
+  r.cur = 0;
+  if (fetch_window(r.win[0], 0, bins) != GLFER_OK || r.win[0].count == 0) { reader_drop_batch(); return; }
+  start_prefetch(r.win[0].count, bins);
+}
+
+// Row of the hop in the reader's buffer for estimator `owner`, or false (the caller then takes the
+// per-hop path).  `want`: the batch configuration this estimator needs (mode, sizes, window, tapers;
+// overlap, mean removal, history and sample format are filled in here).  Once per *_do.
+bool readahead_row(const float *audio_buf, const void *owner, const fft_params_t *fp, glfer_hip_config want, float *row_out) {
+  Reader &r = g_rd;
+  if (!r.f || r.off) return false;
+  if (audio_buf != r.buff) {
+    if (owner == r.owner) r.off = true;            // its history now holds samples that are not the file's
+    return false;
+  }
+  const bool was_fresh = r.fresh;
+  r.fresh = false;
+  const size_t k = r.blocks - 1;                   // the hop in the buffer
+  if (r.owner && owner != r.owner) { r.off = true; return false; }
+  if (!was_fresh || k != r.taken) { r.off = true; return false; }          // a hop repeated, or skipped
+  r.taken++;
+  if (!glfer_compat_readahead) { r.off = true; return false; }
+  if (stamp_of(r.buff, r.out_len) != r.stamp) { r.off = true; return false; }   // the caller changed the samples
+  const int h = (int)(fp->n * (1.0 - fp->overlap));
+  if (h != r.out_len) { r.off = true; return false; }                      // the reader was opened for another hop
+  // the history flag must follow the mode's pattern: with autoscale (= sub_mean, fft.c:186) the
+  // drawer clears glfer.first_buffer after the first column (g_main.c:1111-1120) -- history from the
+  // stream; without, it stays TRUE -- history zeroed in every frame
+  const bool zero_always = !fp->sub_mean;
+  const bool expect_first = k == 0 || zero_always;
+  if ((glfer_compat_get_first_buffer() != 0) != expect_first) { r.off = true; return false; }
+  if (&glfer && glfer.scope_window) return false;  // the scope reads inbuf_fft of every hop: per-hop path, this hop
+  want = batch_config(want, fp);
+  if (!r.plan || !same_cfg(want, r.cfg)) {
+    if (r.plan && k != 0) { r.off = true; return false; }                  // the estimator changed under way
+    reader_drop_batch();
+    const double tp0 = trace_now();
+    if (glfer_hip_plan_create(&want, &r.plan) != GLFER_OK) { r.plan = nullptr; r.off = true; return false; }
+    trace_log("read-ahead: plan_create", tp0);
+    r.cfg = want;
+    r.owner = owner;
+  }
+  const size_t bins = (size_t)fp->n / 2 + 1;
+  Window *w = &r.win[r.cur];
+  if (k < w->first || k >= w->first + w->count) {
+    // not in the window being served: the one computed ahead, if it starts here; else a fetch now
+    bool have = false;
+    if (r.fetching) {
+      reader_join();
+      Window &nx = r.win[r.cur ^ 1];
+      if (r.fetch_rc == GLFER_OK && k >= nx.first && k < nx.first + nx.count) {
+        r.cur ^= 1;
+        have = true;
+      }
+    }
+    if (!have && (fetch_window(r.win[r.cur], k, bins) != GLFER_OK || r.win[r.cur].count == 0)) { r.off = true; return false; }
+    w = &r.win[r.cur];
+    // the window after this one, on a second host thread
+    start_prefetch(w->first + w->count, bins);
+  }
+  memcpy(row_out, w->rows.data() + (k - w->first) * bins, bins * sizeof(float));
+  glfer_compat_readahead_served++;
+  return true;
+}
+
+void assemble(float *audio_buf, fft_params_t *p);
+
+// The per-hop path is about to take the hop in the reader's buffer, and hops before it were served
+// from a batch: the estimator's host-side state is rebuilt from the file -- the hops the history
+// reaches back over, read again, their means removed (device, the reference's order) and pushed
+// through the same frame assembly the per-hop path uses -- and, for a trailing partial block, the
+// stale rest of the reader's buffer gets the previous block AS THE ESTIMATOR LEFT IT (fft.c:93-95).
+void reader_sync_state(const float *audio_buf, fft_params_t *fp) {
+  Reader &r = g_rd;
+  if (!r.f || audio_buf != r.buff || r.blocks == 0) return;
+  const size_t k = r.blocks - 1;
+  if (r.state_hops >= k) { r.state_hops = k + 1; return; }
+  const int h = r.out_len, n = fp->n;
+  if (h != (int)(n * (1.0 - fp->overlap))) { r.state_hops = k + 1; return; }
+  const size_t back = (size_t)((n - h + h - 1) / h);                       // hops the history reaches back over
+  size_t j0 = k > back ? k - back : 0;
+  if (j0 < r.state_hops) j0 = r.state_hops;
+  const int bytes_per = r.info.bits_per_sample / 8;
+  const long pos = ftell(r.f);
+  std::vector<unsigned char> raw((size_t)h * bytes_per);
+  std::vector<float> hop((size_t)h);
+  const int saved_first = glfer_compat_get_first_buffer();
+  for (size_t j = j0; j < k; j++) {
+    if (fseek(r.f, (long)(r.info.data_offset + j * raw.size()), SEEK_SET) != 0 || fread(raw.data(), 1, raw.size(), r.f) != raw.size()) break;
+    if (bytes_per == 1) for (int i = 0; i < h; i++) hop[i] = ((float)raw[i] - 128) / 128;
+    else for (int i = 0; i < h; i++) hop[i] = (float)((const short *)raw.data())[i] / 32768;
+    // the flag as it stood when this hop was taken: TRUE at hop 0 and -- without autoscale -- always
+    const int first = (j == 0 || !fp->sub_mean) ? 1 : 0;
+    if (&glfer) glfer.first_buffer = first; else glfer_compat_first_buffer = first;
+    if (j == j0 && j0 > 0 && first == 0) memset(fp->inbuf_audio, 0, (size_t)n * sizeof(float));   // (older hops: out of reach)
+    assemble(hop.data(), fp);
+    if (j + 1 == k && r.last_samples < (size_t)h)
+      memcpy(r.buff + r.last_samples, hop.data() + r.last_samples, ((size_t)h - r.last_samples) * sizeof(float));
+  }
+  if (&glfer) glfer.first_buffer = saved_first; else glfer_compat_first_buffer = saved_first;
+  (void)fseek(r.f, pos, SEEK_SET);
+  r.state_hops = k + 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+// wav_fmt.c:45-79.  The header's chunks are walked (glfer_hip_wav_probe); the return value is a file
+// descriptor, as the reference's (source.c:193 keeps it as audio_fd).
+int open_wav_file(char *fname, int n, int *speed) {
+  Reader &r = g_rd;
+  if (r.f) close_wav_file();
+  r.out_len = n;
+  int rc = glfer_hip_wav_probe(fname, &r.info);
+  if (rc != GLFER_OK) {
+    fprintf(stderr, "error opening %s (or not a PCM WAV file)\n", fname);  // wav_fmt.c:53-56, 63-69
+    exit(-1);
+  }
+  r.f = fopen(fname, "rb");
+  if (!r.f || fseek(r.f, (long)r.info.data_offset, SEEK_SET) != 0) {
+    fprintf(stderr, "error opening %s\n", fname);
+    exit(-1);
+  }
+  setvbuf(r.f, nullptr, _IOFBF, (size_t)1 << 18);                      // a block is 1-32 KB: fewer read() calls
+  r.path = fname;
+  r.data_left = r.info.data_bytes;
+  r.blocks = r.taken = r.state_hops = 0;
+  r.fresh = false;
+  r.off = false;
+  if (speed) *speed = r.info.sample_rate;
+  reader_prepare();                // an estimator is initialised already: the file's first window now
+  return fileno(r.f);
+}
+
+// wav_fmt.c:81-121: one block of out_len samples; a short last read converts what it got over the
+// stale rest of the buffer; n_out = 0 at the end of the data.
+void wav_read(float **buf_out, int *n_out) {
+  Reader &r = g_rd;
+  if (!r.f) { *n_out = 0; *buf_out = r.buff; return; }
+  const int bytes_per = r.info.bits_per_sample / 8;
+  const size_t s_bufsize = (size_t)r.out_len * bytes_per;
+  if (!r.buf) {
+    r.buf = (unsigned char *)calloc(r.out_len, bytes_per);
+    r.buff = (float *)calloc(r.out_len, sizeof(float));
+  }
+  const size_t want = s_bufsize < r.data_left ? s_bufsize : r.data_left;
+  const size_t n_read = want ? fread(r.buf, 1, want, r.f) : 0;
+  r.data_left -= n_read;
+  size_t ns = 0;
+  if (bytes_per == 1) {
+    ns = n_read;
+    for (size_t i = 0; i < ns; i++) r.buff[i] = ((float)r.buf[i] - 128) / 128;               // wav_fmt.c:106-108
+  } else {
+    ns = n_read / 2;
+    const short *b16 = (const short *)r.buf;
+    for (size_t i = 0; i < ns; i++) r.buff[i] = (float)b16[i] / 32768;                      // wav_fmt.c:111-114
+  }
+  *n_out = n_read == 0 ? 0 : 1;
+  *buf_out = r.buff;
+  if (n_read) {
+    r.blocks++;
+    r.fresh = true;
+    r.last_samples = ns;
+    r.stamp = stamp_of(r.buff, r.out_len);
+  }
+}
+
+void close_wav_file(void) {                                        // wav_fmt.c:123-141
+  Reader &r = g_rd;
+  reader_drop_batch();
+  if (r.f) fclose(r.f);
+  r.f = nullptr;
+  free(r.buf); r.buf = nullptr;
+  free(r.buff); r.buff = nullptr;
+  r.blocks = r.taken = r.state_hops = 0;
+  r.fresh = r.off = false;
+}
+
+}  // extern "C"
+
+namespace {
 
 }  // namespace
 
@@ -128,7 +494,7 @@ void fft_init(fft_params_t *p) {                                   // fft.c:168-
   cfg.window_type = p->window_type;
   cfg.limiter_a = p->a;
   cfg.enable_limiter = p->limiter;
-  engine_open(p, cfg, true);
+  engine_open(p, cfg, true, p);
   int rc = glfer_hip_get_window(engine_for(p).plan, p->window);
   if (rc) die("get_window", rc);
 }
@@ -137,6 +503,8 @@ void prepare_audio(float *audio_buf, fft_params_t *p) {            // fft.c:66-1
   // history / mean handling here, then RA9MB, window and limiter on the device into inbuf_fft
   // (what lmp.c:101-120 and the scope, g_scope.c:194-197, read after this call)
   Engine &e = engine_for(p);
+  reader_bypassed(audio_buf);
+  reader_sync_state(audio_buf, p);
   assemble(audio_buf, p);
   if (!e.d_spec) hipck(hipMalloc((void **)&e.d_spec, (size_t)p->n * sizeof(float)), "hipMalloc prepared frame");
   hipck(hipMemcpy(e.d_frame, p->inbuf_audio, (size_t)p->n * sizeof(float), hipMemcpyHostToDevice), "H2D frame");
@@ -147,6 +515,11 @@ void prepare_audio(float *audio_buf, fft_params_t *p) {            // fft.c:66-1
 
 void fft_do(float *audio_buf, fft_params_t *p) {                   // fft.c:190-200
   Engine &e = engine_for(p);
+  // a file's hop in the reader's own buffer: the row comes from the batch the device computed from the
+  // file (outbuf then keeps the last per-hop spectrum: nothing but fft_psd reads it, and the scope
+  // window -- which reads inbuf_fft -- turns the read-ahead off while it is open)
+  if (readahead_row(audio_buf, p, p, e.cfg, e.psd.data())) return;
+  reader_sync_state(audio_buf, p);
   assemble(audio_buf, p);
   hipck(hipMemcpy(e.d_frame, p->inbuf_audio, (size_t)p->n * sizeof(float), hipMemcpyHostToDevice), "H2D frame");
   int rc = glfer_hip_spectrum_device(e.plan, e.d_frame, (size_t)p->n, 0, 1, e.d_psd, e.d_spec, nullptr);
@@ -208,7 +581,7 @@ void mtm_init(mtm_params_t *p) {                                   // mtm.c:88-1
   cfg.overlap = 0.0f;
   cfg.mtm_w = p->w;
   cfg.mtm_k = kmax;
-  engine_open(p, cfg, false);
+  engine_open(p, cfg, false, &p->fft);
   // params->window / sig as the reference lays them out: window[1..n][0..kmax] (mtm.c:118-119)
   std::vector<double> tap((size_t)(kmax + 1) * n);
   p->sig = (double *)malloc((size_t)(kmax + 1) * sizeof(double));
@@ -227,6 +600,8 @@ void mtm_init(mtm_params_t *p) {                                   // mtm.c:88-1
 void mtm_do(float *audio_buf, float *psd_buf, float *phase_buf, mtm_params_t *p) {   // mtm.c:154-239
   (void)phase_buf;                                                 // ignored by the reference too
   Engine &e = engine_for(p);
+  if (readahead_row(audio_buf, p, &p->fft, e.cfg, psd_buf)) return;
+  reader_sync_state(audio_buf, &p->fft);
   assemble(audio_buf, &p->fft);
   hipck(hipMemcpy(e.d_frame, p->fft.inbuf_audio, (size_t)p->fft.n * sizeof(float), hipMemcpyHostToDevice), "H2D frame");
   int rc = glfer_hip_spectrogram_device(e.plan, e.d_frame, (size_t)p->fft.n, 0, 1, e.d_psd, nullptr);
@@ -258,12 +633,14 @@ void hparma_init(hparma_params_t *p) {                             // hparma.c:4
   cfg.overlap = 0.0f;
   cfg.hparma_t = p->t;
   cfg.hparma_p_e = p->p_e;
-  engine_open(p, cfg, false);
+  engine_open(p, cfg, false, &p->fft);
 }
 
 void hparma_do(float *audio_buf, float *psd_buf, float *phase_buf, hparma_params_t *p) {   // hparma.c:74-157
   (void)phase_buf;
   Engine &e = engine_for(p);
+  if (readahead_row(audio_buf, p, &p->fft, e.cfg, psd_buf)) return;
+  reader_sync_state(audio_buf, &p->fft);
   assemble(audio_buf, &p->fft);
   hipck(hipMemcpy(e.d_frame, p->fft.inbuf_audio, (size_t)p->fft.n * sizeof(float), hipMemcpyHostToDevice), "H2D frame");
   int rc = glfer_hip_spectrogram_device(e.plan, e.d_frame, (size_t)p->fft.n, 0, 1, e.d_psd, nullptr);
@@ -300,7 +677,7 @@ void lmp_init(lmp_params_t *p) {                                   // lmp.c:59-9
   cfg.n = n;
   cfg.overlap = 0.0f;                    // frames arrive assembled: one block per call
   cfg.lmp_av = p->avg;                                             // nl = params->avg, lmp.c:85
-  engine_open(p, cfg, false);
+  engine_open(p, cfg, false, &p->fft);
   LmpDev d;
   hipck(hipMalloc((void **)&d.d_hist, (size_t)2 * p->avg * n * sizeof(float)), "hipMalloc lmp history");
   g_lmp[p] = d;
@@ -311,6 +688,7 @@ void lmp_do(float *audio_buf, float *psd_buf, float *phase_buf, lmp_params_t *p)
   Engine &e = engine_for(p);
   LmpDev &d = g_lmp[p];
   const int n = p->fft.n, nl = p->avg;
+  reader_bypassed(audio_buf);                                      // LMP: per hop only (its ring lives on the device, hop by hop)
   assemble(audio_buf, &p->fft);
   // the engine recomputes the periodograms the ring still holds from the frames themselves, so
   // the last nl assembled frames stay on the device, in time order

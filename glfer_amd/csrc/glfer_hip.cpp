@@ -38,8 +38,9 @@ extern "C" hipError_t glfer_launch_lmp(const float *rows, long long row0, long l
                                        int nl, float *out, hipStream_t st);
 extern "C" hipError_t glfer_launch_ftest(const float *spec, size_t nframes, int n, int ntap, const double *U0,
                                          float sum_U0_sqr, int mu_live, float *ftest, hipStream_t st);
-extern "C" hipError_t glfer_launch_submean_tail(const void *raw_last, const float *prev, float *out, int H, int fresh,
-                                                int fmt, hipStream_t st);
+extern "C" hipError_t glfer_launch_submean_tail_ex(const void *raw_last, const float *prev, float *out, int H, int fresh, int exact,
+                                                   int fmt, hipStream_t st);
+extern "C" hipError_t glfer_launch_hop_means_seq(const void *in, float *means, int H, long long nhops, int fmt, hipStream_t st);
 extern "C" hipError_t glfer_launch_prepare(const SpectroParams *p, int n, const float *window, float *out,
                                            hipStream_t st);
 
@@ -930,6 +931,7 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (p->d_ltaps) (void)hipFree(p->d_ltaps);
   if (p->d_lagmap) (void)hipFree(p->d_lagmap);
   if (p->d_unit) (void)hipFree(p->d_unit);
+  glfer::ingest_ring_free(p->ring);
   delete p;
 }
 
@@ -1191,10 +1193,20 @@ static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t fi
   HIP_TRY(glfer::scratch_malloc((void **)&scratch, nhops * (size_t)p->hop * sizeof(float), st));
   const size_t esz = sp.fmt == GLFER_FMT_F32 ? 4 : (sp.fmt == GLFER_FMT_S16 ? 2 : 1);
   const char *src = (const char *)sp.stream + hop_lo * (size_t)p->hop * esz;
-  hipError_t e = glfer_launch_submean(src, scratch, p->hop, (long long)nhops, sp.fmt, st);
+  // GLFER_SUBMEAN_EXACT: the hop means first, accumulated sample after sample as fft.c:88-92 does
+  // (submean_seq.hip: one more read of the stream), then the copy with those means
+  const bool exact = p->cfg.sub_mean == GLFER_SUBMEAN_EXACT;
+  float *means = nullptr;
+  hipError_t e = hipSuccess;
+  if (exact) {
+    e = glfer::scratch_malloc((void **)&means, nhops * sizeof(float), st);
+    if (e == hipSuccess) e = glfer_launch_hop_means_seq(src, means, p->hop, (long long)nhops, sp.fmt, st);
+  }
+  if (e == hipSuccess) e = glfer_launch_submean(src, scratch, p->hop, (long long)nhops, sp.fmt, st, means);
   if (e == hipSuccess && tail_fresh >= 0)
-    e = glfer_launch_submean_tail(src + (nhops - 1) * (size_t)p->hop * esz, nhops > 1 ? scratch + (nhops - 2) * (size_t)p->hop : nullptr,
-                                  scratch + (nhops - 1) * (size_t)p->hop, p->hop, (int)tail_fresh, sp.fmt, st);
+    e = glfer_launch_submean_tail_ex(src + (nhops - 1) * (size_t)p->hop * esz, nhops > 1 ? scratch + (nhops - 2) * (size_t)p->hop : nullptr,
+                                     scratch + (nhops - 1) * (size_t)p->hop, p->hop, (int)tail_fresh, exact ? 1 : 0, sp.fmt, st);
+  if (means) glfer::scratch_free(means, st);
   if (e != hipSuccess) {
     glfer::scratch_free(scratch, st);
     return hip_fail(e, "glfer_launch_submean");
@@ -1212,6 +1224,7 @@ static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t fi
 // keeps the pre-pass (A/B runs, and the tests that compare the two).
 static bool mean_inkernel_ok(const glfer_hip_plan *p, const SpectroParams &sp, const float *d_spec, long tail_fresh) {
   if (p->nonlin || d_spec || tail_fresh >= 0 || sp.history_mode) return false;
+  if (p->cfg.sub_mean == GLFER_SUBMEAN_EXACT) return false;     // the kernels sum a hop in another order than fft.c:88-92
   if (p->cfg.mode != GLFER_MODE_FFT && p->cfg.mode != GLFER_MODE_LMP && p->cfg.mode != GLFER_MODE_MTM) return false;
   const char *e = getenv("GLFER_MEAN_PREPASS");
   if (e && *e == '1') return false;
@@ -1483,8 +1496,24 @@ int glfer_hip_submean_device(const void *d_in, float *d_out, int hop, size_t nho
   if (!d_in || !d_out || hop < 1 || sample_format < 0 || sample_format > 2) return GLFER_E_ARG;
   DeviceGuard guard(data_device(d_out));
   HIP_TRY(guard.error());
-  HIP_TRY(glfer_launch_submean(d_in, d_out, hop, (long long)nhops, sample_format, (hipStream_t)hip_stream));
+  HIP_TRY(glfer_launch_submean(d_in, d_out, hop, (long long)nhops, sample_format, (hipStream_t)hip_stream, nullptr));
   return GLFER_OK;
+}
+
+// The same with every hop summed in the reference's own order (fft.c:88-92; submean_seq.hip).
+int glfer_hip_submean_exact_device(const void *d_in, float *d_out, int hop, size_t nhops, int sample_format,
+                                   void *hip_stream) {
+  if (!d_in || !d_out || hop < 1 || sample_format < 0 || sample_format > 2) return GLFER_E_ARG;
+  if (nhops == 0) return GLFER_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  DeviceGuard guard(data_device(d_out));
+  HIP_TRY(guard.error());
+  float *means = nullptr;
+  HIP_TRY(glfer::scratch_malloc((void **)&means, nhops * sizeof(float), st));
+  hipError_t e = glfer_launch_hop_means_seq(d_in, means, hop, (long long)nhops, sample_format, st);
+  if (e == hipSuccess) e = glfer_launch_submean(d_in, d_out, hop, (long long)nhops, sample_format, st, means);
+  glfer::scratch_free(means, st);
+  return e == hipSuccess ? GLFER_OK : hip_fail(e, "glfer_hip_submean_exact_device");
 }
 
 int glfer_hip_floor_device(const float *d_psd, size_t nframes, int bins, float *d_stats, void *hip_stream) {

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,7 +26,28 @@
 using glfer::DeviceGuard;
 using glfer::hip_fail;
 
+namespace glfer {
+void ingest_ring_free(IngestRing *r) {          // with the ring's device current (plan_destroy, run_job)
+  if (!r) return;
+  for (int i = 0; i < 2; i++) {
+    if (r->st[i]) (void)hipStreamSynchronize(r->st[i]);
+    if (r->h_in[i]) (void)hipHostFree(r->h_in[i]);
+    if (r->h_out[i]) (void)hipHostFree(r->h_out[i]);
+    if (r->h_lev[i]) (void)hipHostFree(r->h_lev[i]);
+    if (r->d_in[i]) (void)hipFree(r->d_in[i]);
+    if (r->d_psd[i]) (void)hipFree(r->d_psd[i]);
+    if (r->d_stats[i]) (void)hipFree(r->d_stats[i]);
+    if (r->d_rgb[i]) (void)hipFree(r->d_rgb[i]);
+    if (r->d_lev[i]) (void)hipFree(r->d_lev[i]);
+    if (r->st[i]) (void)hipStreamDestroy(r->st[i]);
+  }
+  delete r;
+}
+}  // namespace glfer
+
 namespace {
+
+std::mutex g_ring_mu;
 
 size_t sample_bytes(int fmt) { return fmt == GLFER_SAMPLES_F32 ? 4 : (fmt == GLFER_SAMPLES_S16 ? 2 : 1); }
 
@@ -117,28 +139,54 @@ int run_job(const Job &job, size_t *frames_done) {
   HIP_TRY(guard.error());
   const bool direct_out = waterfall ? is_pinned_host(job.sink.h_rgb) && (!job.sink.h_lev || is_pinned_host(job.sink.h_lev))
                                     : is_pinned_host(job.sink.h_psd);
-  unsigned char *h_in[2] = {nullptr, nullptr}, *d_in[2] = {nullptr, nullptr};
-  unsigned char *h_out[2] = {nullptr, nullptr};
-  short *h_lev[2] = {nullptr, nullptr};
-  float *d_psd[2] = {nullptr, nullptr}, *d_stats[2] = {nullptr, nullptr};
-  unsigned char *d_rgb[2] = {nullptr, nullptr};
-  short *d_lev[2] = {nullptr, nullptr};
-  hipStream_t st[2] = {nullptr, nullptr};
+  // The ring's buffers and streams belong to the PLAN and stay with it between calls (a call used to
+  // spend ~17 ms allocating and freeing pinned and device memory around ~10 ms of work: the
+  // read-ahead of the per-hop shims walks a file in many such calls); a second job running on the
+  // same plan at the same time gets a ring of its own for the call.
+  glfer::IngestRing *ring = nullptr;
+  bool own_ring = false;
+  {
+    std::lock_guard<std::mutex> lock(g_ring_mu);
+    if (!p->ring) p->ring = new glfer::IngestRing();
+    if (!p->ring->busy) {
+      p->ring->busy = true;
+      ring = p->ring;
+    }
+  }
+  if (!ring) {
+    ring = new glfer::IngestRing();
+    ring->busy = true;
+    own_ring = true;
+  }
+  glfer::IngestRing &R = *ring;
+  unsigned char **h_in = R.h_in, **d_in = R.d_in, **h_out = R.h_out, **d_rgb = R.d_rgb;
+  short **h_lev = R.h_lev, **d_lev = R.d_lev;
+  float **d_psd = R.d_psd, **d_stats = R.d_stats;
+  hipStream_t *st = R.st;
   const size_t in_bytes = (halo_hops + chunk + 1) * hop * esz;       // + 1: a trailing partial block rides on the last chunk
   const size_t rows_cap = chunk + 1;
   hipError_t e = hipSuccess;
+  // a buffer of at least `bytes`: the one the ring has, or a new one (kind: 0 pinned host, 1 device)
+  auto ensure = [&](void **ptr, size_t *cap, size_t bytes, int kind) {
+    if (e != hipSuccess || (*ptr && *cap >= bytes)) return;
+    if (*ptr) (void)(kind == 0 ? hipHostFree(*ptr) : hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    e = kind == 0 ? hipHostMalloc(ptr, bytes, hipHostMallocDefault) : hipMalloc(ptr, bytes);
+    if (e == hipSuccess) *cap = bytes;
+  };
   for (int b = 0; b < 2 && e == hipSuccess; b++) {
-    e = hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking);
-    if (e == hipSuccess && !job.pinned_src) e = hipHostMalloc((void **)&h_in[b], in_bytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_in[b], in_bytes);
-    if (e == hipSuccess && !dev_sink) e = hipMalloc((void **)&d_psd[b], rows_cap * bins * sizeof(float));
-    if (e == hipSuccess && !direct_out && !dev_sink) e = hipHostMalloc((void **)&h_out[b], rows_cap * row_bytes, hipHostMallocDefault);
-    if (e == hipSuccess && waterfall) {
-      e = hipMalloc((void **)&d_stats[b], rows_cap * 4 * sizeof(float));
-      if (e == hipSuccess) e = hipMalloc((void **)&d_rgb[b], rows_cap * bins * 3);
-      if (e == hipSuccess && job.sink.h_lev) {
-        e = hipMalloc((void **)&d_lev[b], rows_cap * bins * sizeof(short));
-        if (e == hipSuccess && !direct_out) e = hipHostMalloc((void **)&h_lev[b], rows_cap * bins * sizeof(short), hipHostMallocDefault);
+    if (!st[b]) e = hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking);
+    if (!job.pinned_src) ensure((void **)&h_in[b], &R.cap[b][0], in_bytes, 0);
+    ensure((void **)&d_in[b], &R.cap[b][1], in_bytes, 1);
+    if (!dev_sink) ensure((void **)&d_psd[b], &R.cap[b][2], rows_cap * bins * sizeof(float), 1);
+    if (!direct_out && !dev_sink) ensure((void **)&h_out[b], &R.cap[b][3], rows_cap * row_bytes, 0);
+    if (waterfall) {
+      ensure((void **)&d_stats[b], &R.cap[b][4], rows_cap * 4 * sizeof(float), 1);
+      ensure((void **)&d_rgb[b], &R.cap[b][5], rows_cap * bins * 3, 1);
+      if (job.sink.h_lev) {
+        ensure((void **)&d_lev[b], &R.cap[b][6], rows_cap * bins * sizeof(short), 1);
+        if (!direct_out) ensure((void **)&h_lev[b], &R.cap[b][7], rows_cap * bins * sizeof(short), 0);
       }
     }
   }
@@ -243,17 +291,13 @@ int run_job(const Job &job, size_t *frames_done) {
   // the two chunks still in flight, oldest first
   if (rc == GLFER_OK) rc = drain(b);
   if (rc == GLFER_OK) rc = drain(b ^ 1);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 2; i++)
     if (st[i]) (void)hipStreamSynchronize(st[i]);
-    if (h_in[i]) (void)hipHostFree(h_in[i]);
-    if (h_out[i]) (void)hipHostFree(h_out[i]);
-    if (h_lev[i]) (void)hipHostFree(h_lev[i]);
-    if (d_in[i]) (void)hipFree(d_in[i]);
-    if (d_psd[i]) (void)hipFree(d_psd[i]);
-    if (d_stats[i]) (void)hipFree(d_stats[i]);
-    if (d_rgb[i]) (void)hipFree(d_rgb[i]);
-    if (d_lev[i]) (void)hipFree(d_lev[i]);
-    if (st[i]) (void)hipStreamDestroy(st[i]);
+  if (own_ring) {
+    glfer::ingest_ring_free(ring);
+  } else {
+    std::lock_guard<std::mutex> lock(g_ring_mu);
+    ring->busy = false;
   }
   return rc;
 }

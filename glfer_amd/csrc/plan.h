@@ -55,6 +55,20 @@ void scratch_set_cap(size_t bytes);
 // device, kernel and size class).
 hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);
 
+// The host-to-host entries' chunk ring (ingest.cpp run_job): two pinned sample buffers, two device
+// sample buffers, two device row buffers, two pinned row buffers (+ the waterfall's), two streams.
+// Kept with the plan between calls, freed by glfer_hip_plan_destroy.
+struct IngestRing {
+  unsigned char *h_in[2] = {nullptr, nullptr}, *d_in[2] = {nullptr, nullptr}, *h_out[2] = {nullptr, nullptr};
+  unsigned char *d_rgb[2] = {nullptr, nullptr};
+  short *h_lev[2] = {nullptr, nullptr}, *d_lev[2] = {nullptr, nullptr};
+  float *d_psd[2] = {nullptr, nullptr}, *d_stats[2] = {nullptr, nullptr};
+  hipStream_t st[2] = {nullptr, nullptr};
+  size_t cap[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+  bool busy = false;
+};
+void ingest_ring_free(IngestRing *r);
+
 }  // namespace glfer
 
 #define HIP_TRY(call)                                          \
@@ -95,6 +109,7 @@ struct glfer_hip_plan {
   float sum_U0_sqr = 0.0f;
   float spec_unscale = 1.0f;
   bool nonlin = false;
+  glfer::IngestRing *ring = nullptr;   // the host entries' chunk ring, kept between calls (ingest.cpp)
 };
 
 // frames [first, first+nframes) of a device-resident stream (virtual base allowed); psd and/or

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
 // K0: per-hop mean removal (fft.c:86-96).  One block per hop; writes a float copy of the
 // stream (the reference mutates the caller's hop buffer in place).
 template <int FMT>
-__global__ __launch_bounds__(256) void submean_kernel(const void *in, float *out, int H, long long nhops) {
+__global__ __launch_bounds__(256) void submean_kernel(const void *in, float *out, int H, long long nhops, const float *means) {
   __shared__ float part[256];
   const long long hop = blockIdx.x;
   if (hop >= nhops) return;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void submean_kernel(const void *in, float *out
     if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
     __syncthreads();
   }
-  const float mean = part[0] / (float)H;
+  const float mean = means ? means[hop] : part[0] / (float)H;   // means: taken in the reference's order (submean_seq.hip)
   for (int i = threadIdx.x; i < H; i += 256) dst[i] = cvt_sample<FMT>(src, (unsigned)i) - mean;
 }
 
@@ -391,7 +391,7 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 }
 
 template <int FMT, int GROUP, int EPL>
-__global__ __launch_bounds__(256) void submean_reg_kernel(const void *in, float *out, int H, long long nhops) {
+__global__ __launch_bounds__(256) void submean_reg_kernel(const void *in, float *out, int H, long long nhops, const float *means) {
   constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
   __shared__ float part[4];
   const unsigned l = GROUP == 64 ? (threadIdx.x & 63u) : threadIdx.x;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void submean_reg_kernel(const void *in, float 
     __syncthreads();
     s = (part[0] + part[1]) + (part[2] + part[3]);
   }
-  const float mean = s / (float)H;
+  const float mean = means ? means[hop] : s / (float)H;           // means: taken in the reference's order (submean_seq.hip)
   const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(out + hop * (long long)H, 0, (unsigned)H * 4u, 0x00020000);
 #pragma unroll
   for (int j = 0; j < EPL; j++)                    // (stores past the hop's end are dropped by the descriptor)
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void submean_reg_kernel(const void *in, float 
 // calloc zeros, wav_fmt.c:99).  Then this block's own mean removal.  One block.
 template <int FMT>
 __global__ __launch_bounds__(256) void submean_tail_kernel(const void *raw_last, const float *prev, float *out, int H,
-                                                           int fresh) {
+                                                           int fresh, int exact) {
   __shared__ float part[256];
   float s = 0.0f;
   for (int i = threadIdx.x; i < H; i += 256) {
@@ -442,7 +442,17 @@ __global__ __launch_bounds__(256) void submean_tail_kernel(const void *raw_last,
     if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
     __syncthreads();
   }
-  const float mean = part[0] / (float)H;
+  float mean = part[0] / (float)H;
+  if (exact) {                             // GLFER_SUBMEAN_EXACT: the reference's own order (fft.c:88-92), one thread; once per file
+    __shared__ float seq;
+    if (threadIdx.x == 0) {
+      float a = 0.0f;
+      for (int i = 0; i < H; i++) a += out[i];
+      seq = a / (float)H;
+    }
+    __syncthreads();
+    mean = seq;
+  }
   for (int i = threadIdx.x; i < H; i += 256) out[i] -= mean;       // each thread revisits its own elements
 }
 
@@ -504,16 +514,16 @@ extern "C" hipError_t GLFER_CAT(glfer_launch_spectro16_n, GLFER_LOGN)(const Spec
 
 #if GLFER_LOGN == 12
 extern "C" hipError_t glfer_launch_submean(const void *in, float *out, int H, long long nhops, int fmt,
-                                           hipStream_t st) {
+                                           hipStream_t st, const float *means) {
   if (nhops <= 0) return hipSuccess;
   if (fmt != GLFER_FMT_F32 && fmt != GLFER_FMT_S16 && fmt != GLFER_FMT_U8) return hipErrorInvalidValue;
   // hops up to 16384 samples: held in registers (a wavefront per hop up to 1024 samples, a workgroup above)
 #define GLFER_SUBMEAN_REG(G, E)                                                                                     \
   do {                                                                                                              \
     const unsigned grid = G == 64 ? (unsigned)((nhops + 3) / 4) : (unsigned)nhops;                                  \
-    if (fmt == GLFER_FMT_F32) hipLaunchKernelGGL((submean_reg_kernel<GLFER_FMT_F32, G, E>), dim3(grid), dim3(256), 0, st, in, out, H, nhops); \
-    else if (fmt == GLFER_FMT_S16) hipLaunchKernelGGL((submean_reg_kernel<GLFER_FMT_S16, G, E>), dim3(grid), dim3(256), 0, st, in, out, H, nhops); \
-    else hipLaunchKernelGGL((submean_reg_kernel<GLFER_FMT_U8, G, E>), dim3(grid), dim3(256), 0, st, in, out, H, nhops); \
+    if (fmt == GLFER_FMT_F32) hipLaunchKernelGGL((submean_reg_kernel<GLFER_FMT_F32, G, E>), dim3(grid), dim3(256), 0, st, in, out, H, nhops, means); \
+    else if (fmt == GLFER_FMT_S16) hipLaunchKernelGGL((submean_reg_kernel<GLFER_FMT_S16, G, E>), dim3(grid), dim3(256), 0, st, in, out, H, nhops, means); \
+    else hipLaunchKernelGGL((submean_reg_kernel<GLFER_FMT_U8, G, E>), dim3(grid), dim3(256), 0, st, in, out, H, nhops, means); \
     return hipGetLastError();                                                                                       \
   } while (0)
   if (H <= 64 * 2) GLFER_SUBMEAN_REG(64, 2);
@@ -526,20 +536,20 @@ extern "C" hipError_t glfer_launch_submean(const void *in, float *out, int H, lo
   if (H <= 256 * 64) GLFER_SUBMEAN_REG(256, 64);
 #undef GLFER_SUBMEAN_REG
   switch (fmt) {
-    case GLFER_FMT_F32: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_F32>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
-    case GLFER_FMT_S16: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_S16>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
-    case GLFER_FMT_U8: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_U8>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops); break;
+    case GLFER_FMT_F32: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_F32>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops, means); break;
+    case GLFER_FMT_S16: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_S16>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops, means); break;
+    case GLFER_FMT_U8: hipLaunchKernelGGL((submean_kernel<GLFER_FMT_U8>), dim3((unsigned)nhops), dim3(256), 0, st, in, out, H, nhops, means); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-extern "C" hipError_t glfer_launch_submean_tail(const void *raw_last, const float *prev, float *out, int H, int fresh,
+extern "C" hipError_t glfer_launch_submean_tail_ex(const void *raw_last, const float *prev, float *out, int H, int fresh, int exact,
                                                 int fmt, hipStream_t st) {
   switch (fmt) {
-    case GLFER_FMT_F32: hipLaunchKernelGGL((submean_tail_kernel<GLFER_FMT_F32>), dim3(1), dim3(256), 0, st, raw_last, prev, out, H, fresh); break;
-    case GLFER_FMT_S16: hipLaunchKernelGGL((submean_tail_kernel<GLFER_FMT_S16>), dim3(1), dim3(256), 0, st, raw_last, prev, out, H, fresh); break;
-    case GLFER_FMT_U8: hipLaunchKernelGGL((submean_tail_kernel<GLFER_FMT_U8>), dim3(1), dim3(256), 0, st, raw_last, prev, out, H, fresh); break;
+    case GLFER_FMT_F32: hipLaunchKernelGGL((submean_tail_kernel<GLFER_FMT_F32>), dim3(1), dim3(256), 0, st, raw_last, prev, out, H, fresh, exact); break;
+    case GLFER_FMT_S16: hipLaunchKernelGGL((submean_tail_kernel<GLFER_FMT_S16>), dim3(1), dim3(256), 0, st, raw_last, prev, out, H, fresh, exact); break;
+    case GLFER_FMT_U8: hipLaunchKernelGGL((submean_tail_kernel<GLFER_FMT_U8>), dim3(1), dim3(256), 0, st, raw_last, prev, out, H, fresh, exact); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -88,7 +88,7 @@ hipError_t glfer_launch_map(const float *psd, const double *avg, size_t nframes,
                             const unsigned char *colortab, const double *log_thr, unsigned char *rgb, short *lev,
                             hipStream_t st);
 hipError_t glfer_launch_submean(const void *in, float *out, int H, long long nhops, int fmt,
-                                hipStream_t st);
+                                hipStream_t st, const float *means /* NULL: summed by the kernel */);
 #ifdef __cplusplus
 }
 #endif

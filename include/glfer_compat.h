@@ -100,6 +100,24 @@ void lmp_init(lmp_params_t *params);
 void lmp_do(float *audio_buf, float *psd_buf, float *phase_buf, lmp_params_t *params);
 void lmp_close(lmp_params_t *params);
 
+/* wav_fmt.h:24-26 -- the file source.  Exported here so that the file loop of source.c:112-171 runs
+ * at the GPU's rate UNCHANGED (link this library instead of wav_fmt.o too): when fft_do / mtm_do /
+ * hparma_do are handed the reader's own buffer, untouched, for a file's hops in order, the row comes
+ * from a batch the device computed from the file itself (a window of frames at a time, per-hop means in
+ * the reference's order); anything else -- another buffer, samples changed after wav_read, a hop
+ * skipped or repeated, glfer.first_buffer not following the mode's pattern (cleared after the first
+ * column with autoscale, g_main.c:1111-1120; stuck TRUE without), the scope window open, LMP mode --
+ * takes the per-hop launch from that hop on.  inbuf_audio and the caller's buffer (mean removed in
+ * place, fft.c:93-95) are kept hop by hop either way; inbuf_fft / outbuf hold the last PER-HOP
+ * frame only (their one reader, the scope window, turns the read-ahead off while open).
+ * The header's RIFF chunks are walked; 8/16-bit PCM as wav_fmt.c:104-117; a short last block
+ * counts as a block with its fresh samples over the stale rest of the buffer (wav_fmt.c:102-119). */
+int open_wav_file(char *fname, int n, int *speed);
+void close_wav_file(void);
+void wav_read(float **buf_out, int *n_out);
+extern int glfer_compat_readahead;                 /* 1 (default); 0 = every hop through the per-hop path */
+extern unsigned long glfer_compat_readahead_served;   /* hops served from a batch so far */
+
 /* avg.h:38-43 */
 void init_avg(avg_data_t *avgdata);
 void alloc_avg(avg_data_t *avgdata, int width, int depth);

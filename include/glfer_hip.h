@@ -82,7 +82,7 @@ typedef struct glfer_hip_config {
   int window_type;     /* opt.window_type (FFT mode; MTM forces rectangular, source.c:344) */
   float limiter_a;     /* opt.limiter_a  -> fft_params_t.a        (FFT mode only acts)  */
   int enable_limiter;  /* opt.enable_limiter -> fft_params_t.limiter                    */
-  int sub_mean;        /* per-hop mean removal, fft.c:86-96                             */
+  int sub_mean;        /* per-hop mean removal, fft.c:86-96: 0 off, GLFER_SUBMEAN_FAST (1), GLFER_SUBMEAN_EXACT (2) */
   int history_mode;    /* GLFER_HISTORY_*                                               */
   float mtm_w;         /* opt.mtm_w = N*W time-bandwidth product (g-l_dpss.c:295-297)   */
   int mtm_k;           /* opt.mtm_k = kmax; kmax+1 tapers are used (mtm.c:189)          */
@@ -92,6 +92,23 @@ typedef struct glfer_hip_config {
   int hparma_p_e;      /* opt.hparma_p_e: number of poles (source.c:374); q_e is fixed to -1 (source.c:375) */
   int lmp_av;          /* opt.lmp_av: periodograms in the LMP estimator's ring (source.c:397, lmp.c:85) */
 } glfer_hip_config;
+
+/* cfg.sub_mean.  The reference sums a hop sample after sample in a float (fft.c:88-92).
+ *   GLFER_SUBMEAN_FAST   the hop is summed inside the estimator kernels (lane partials, then across
+ *                        the lanes): the more accurate sum, 1-3 % over no mean removal -- and not
+ *                        the reference's.  Indistinguishable (<= 1e-6 of a row's maximum) while a
+ *                        hop's mean is small against its rms, i.e. for AC-coupled audio; on a hop
+ *                        with a DC level the reference's sum drifts by up to ~H*eps/4 of the mean
+ *                        and the rows differ at the low bins by up to ~7e-4 x |mean|/rms of the row
+ *                        maximum (measured at |mean| = rms: 6.6e-4 Hanning periodogram, 7e-5
+ *                        multitaper, N = 4096, 50 % overlap; tests/test_gpu_round3.py) -- so above
+ *                        |mean|/rms ~ 0.01 take the other one.
+ *   GLFER_SUBMEAN_EXACT  the means are accumulated in the reference's own order (one lane walks a
+ *                        hop, 64 hops side by side; one more read of the stream) and the estimator
+ *                        reads a corrected copy: the reference's rows to the usual 1e-5 whatever
+ *                        the input; costs the copy (C3: 52 instead of 71 M frames/s).
+ * The per-hop shims (glfer_compat.h) always take the reference's order. */
+enum { GLFER_SUBMEAN_OFF = 0, GLFER_SUBMEAN_FAST = 1, GLFER_SUBMEAN_EXACT = 2 };
 
 /* Cutting a stream into launches, chunks or shards.
  * (1) Cut at frame indices that are multiples of GLFER_FRAME_ALIGN and every frame's PSD is
@@ -276,6 +293,10 @@ int glfer_hip_spectrogram_wav_workers(const glfer_hip_config *cfg, const int *de
  * the corrected hop back to the caller as the reference does.) */
 int glfer_hip_submean_device(const void *d_in, float *d_out, int hop, size_t nhops, int sample_format,
                              void *hip_stream);
+/* The same with every hop summed in the reference's own order (GLFER_SUBMEAN_EXACT above): what the
+ * per-hop shim's prepare_audio() uses. */
+int glfer_hip_submean_exact_device(const void *d_in, float *d_out, int hop, size_t nhops, int sample_format,
+                                   void *hip_stream);
 
 /* compute_floor (fft.c:240-294) for a batch of PSD rows on the device.
  * d_stats: [nframes][4] floats = {sig (max bin), floor, peak value, peak bin as float}. */
