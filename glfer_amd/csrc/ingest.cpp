@@ -780,8 +780,22 @@ int glfer_hip_wav_probe(const char *path, glfer_wav_info *info) {
         const size_t left = (size_t)end - d_off;
         // a recorder that was cut off leaves 0 or 0xffffffff here: the data then runs to the end of the file
         d_len = (len == 0 || len == 0xffffffffu || len > left) ? left : len;
+        if (d_len < left) {
+          // Bytes after the declared data: another chunk ("LIST" ...: id of four printable characters and
+          // a size that fits the file) is not samples; anything else is -- a header that was not
+          // updated, a stray byte: the reference reads on to the end of the file (wav_fmt.c:102)
+          const long after = (long)(d_off + d_len + (d_len & 1));
+          unsigned char nx[8];
+          bool chunk = false;
+          if (after + 8 <= end && fseek(f, after, SEEK_SET) == 0 && fread(nx, 1, 8, f) == 8) {
+            chunk = true;
+            for (int i = 0; i < 4; i++) chunk = chunk && nx[i] >= 0x20 && nx[i] < 0x7f;
+            chunk = chunk && (long)rd_u32(nx + 4) <= end - after - 8;
+          }
+          if (!chunk) d_len = left;
+        }
         have_data = true;
-        break;                                                   // what follows "data" is not samples
+        break;
       }
       pos += 8 + (long)len + (long)(len & 1);
     }

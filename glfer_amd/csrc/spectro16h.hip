@@ -186,8 +186,8 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       // ZERO_ALWAYS: the history is never loaded (a piece cut for this mode carries none: glfer_hip.h,
       // "Cutting a stream", rule 2).  The descriptor starts at the range's own first hop; pairs that
       // lie in the history get an out-of-range offset and read 0 -- prefetch_x puts the format's
-      // zero there.  H is even on this kernel (pairs are naturally aligned), so R is, and no pair
-      // straddles the history's end.
+      // zero there.  (Integer formats: H is even on this kernel -- pairs are naturally aligned -- so R
+      // is, and no pair straddles the history's end; f32: below.)
       const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + (sblk + p.R) * (long long)esz, 0, 0x7fffffff, 0x00020000);
       const int d = 2 * (int)t - p.R;
@@ -197,7 +197,12 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
         const bool ok = d >= -2 * T * m;
         const unsigned off = ok ? (unsigned)(hrel + 2 * T * m) * (unsigned)esz : 0x80000000u;
         if constexpr (FMT == GLFER_FMT_F32) {
-          px[q] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(hrsrc, off, 0u, 0));
+          // an odd hop (f32 only: 8-byte loads need no alignment) makes R odd, and ONE pair of the frame
+          // straddles the history's end: its second sample is the hop's first.  That pair is fetched
+          // one sample up (the hop's samples 0, 1) and its first sample moved into place.
+          const bool strad = d + 2 * T * m == -1;
+          const v2f32 v = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(hrsrc, strad ? (unsigned)(hrel + 2 * T * m + 1) * 4u : off, 0u, 0));
+          px[q] = strad ? v2f32{0.0f, v.x} : v;
         } else if constexpr (FMT == GLFER_FMT_S16) {
           px[q].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(hrsrc, off, 0u, 0));
         } else {

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
     if constexpr (HIST != 0) {
       // ZERO_ALWAYS: the history is never loaded (a piece cut for this mode carries none: glfer_hip.h,
       // "Cutting a stream", rule 2): descriptor at the block's own first hop, history pairs out of
-      // range (they read 0; the masks below put the format's zero there).  R is even here (pairs).
+      // range (they read 0; the masks below put the format's zero there).
       const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + (sblk + p.R) * (long long)esz, 0, 0x7fffffff, 0x00020000);
       const int d = 2 * (int)(W * t + w) - p.R;
@@ -223,7 +223,11 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
         const bool ok = d + off >= 0;
         const unsigned vo = ok ? (unsigned)(hrel + off) * (unsigned)esz : 0x80000000u;
         if constexpr (FMT == GLFER_FMT_F32) {
-          px[m] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(hrsrc, vo, 0u, 0));
+          // odd hop (f32 only) => odd R: the one pair that straddles the history's end is fetched one
+          // sample up and its first sample moved into place (spectro16h.hip)
+          const bool strad = d + off == -1;
+          const v2f32 v = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(hrsrc, strad ? (unsigned)(hrel + off + 1) * 4u : vo, 0u, 0));
+          px[m] = strad ? v2f32{0.0f, v.x} : v;
         } else if constexpr (FMT == GLFER_FMT_S16) {
           px[m].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(hrsrc, vo, 0u, 0));
         } else {
