@@ -14,7 +14,7 @@ for G in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTI
          "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES" \
          "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_IFETCH SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $D/g$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $W > $D/g$i.log 2>&1 || echo "group $i failed: $G" >> $D/failed.txt
+  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $D/g$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --workload $W > $D/g$i.log 2>&1 || echo "group $i failed: $G" >> $D/failed.txt
 done
 python3 - $D <<'PY' > $D/summary.txt
 import csv, glob, sys, collections
@@ -30,6 +30,7 @@ for k, c in agg.items():
         print("   %-28s %18.0f   (%d dispatches)" % (n, sum(v) / len(v), len(v)))
 PY
 cat $D/summary.txt; cat $D/failed.txt 2>/dev/null
-find $D -name '*_kernel_trace.csv' -size +1M -delete
+find $D -name '*_kernel_trace.csv' -delete
+find $D -name '*_counter_collection.csv' -delete
 find $D -name '*agent_info.csv' -delete
 true
