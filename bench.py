@@ -59,8 +59,11 @@ KERNELS = {"fft1k": ("spectro16h_kernel<10, ..., SHIFT 8> (register reuse across
 
 
 ROOFLINE_NOTES = {
-    "mtm": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac",
-    "mtm75": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac",
+    "mtm": "not HBM-bound (traffic 1.02x algorithmic): FP32 VALU at two wavefronts per SIMD (256 VGPRs, 2 x 35 KB LDS). "
+           "Counters (profiles/r03_stall_picture.txt): a wavefront executes VALU 48 % / LDS 10.5 % of its time and waits 38 %; "
+           "VALU pipe 46 %, LDS array 39 % busy. Measured ceiling of this instruction stream with the exchange removed "
+           "(tools/xbench GLFER_ABL, profiles/r01_xbench_exchange_ablation.txt): 98 M frames/s = 0.30 of the HBM roofline",
+    "mtm75": "FP32-VALU-bound at two wavefronts per SIMD, as the headline (profiles/r03_stall_picture.txt): see valu.frac",
     "mtm16k": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac",
     "fft": "HBM-bound: the copy ceiling on this chip is 0.79 of the 8 TB/s spec (MI355X_MICROARCH.md: 6.29 TB/s measured)",
     "fft1k": "HBM-bound: the copy ceiling on this chip is 0.79 of the 8 TB/s spec (MI355X_MICROARCH.md: 6.29 TB/s measured)",
