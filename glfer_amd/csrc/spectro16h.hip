@@ -51,6 +51,18 @@
 #define GLFER16H_STORE_AUX (GLFER_LOGN_OR(12) >= 12 ? 2 : 0)   /* non-temporal from N = 4096 up (rows written once; +3 %, N = 8192 +25 %); below that a store covers only part of a line per frame and must merge in L2 (nt: -17 % at N = 1024, -40 % at N = 512) */
 #endif
 
+// Rows staged through LDS and stored 16 bytes per lane from a 64-byte boundary (round 3).  A PSD row is
+// N/2+1 floats, so rows start 4 bytes further into a 64-byte granule with every frame: stored bin by
+// bin, every wavefront store straddles a granule boundary (HBM writes 1.09x the row bytes, 33 store
+// instructions per frame).  Staged: the row's floats go into the free half of the frame's exchange
+// buffer at the offset they have inside their 64-byte granule in memory, one barrier, and a lane
+// reads 16 aligned bytes and stores them; the row's first and last few floats (the parts of a
+// 16-byte chunk it shares with its neighbours) go out as single floats.
+#ifndef GLFER16H_STAGE_ROWS
+#define GLFER16H_STAGE_ROWS 0   /* measured, C2: 320 -> 264 M frames/s (HBM writes 1.09x -> see profiles/r03_c2_staged_rows.txt): one more barrier, 8 KB more LDS
+                                   writes per frame and 24 spilled VGPRs cost more than the aligned stores save; kept for A/B builds */
+#endif
+
 namespace glfer {
 
 template <int LOGN>
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   // load would wait for it: no prefetch), and their power-of-two scale (wav_fmt.c:104-117) rides in
   // the window -- (x/32768)*w and x*(w/32768) are the same float
   constexpr float kSampleScale = FMT == GLFER_FMT_F32 ? 1.0f : (FMT == GLFER_FMT_S16 ? 1.0f / 32768.0f : 1.0f / 128.0f);
-  __shared__ v2f32 lds[L::LDS_WORDS + (VAR == 2 ? M : 0)];
+  __shared__ __attribute__((aligned(16))) v2f32 lds[L::LDS_WORDS + (VAR == 2 ? M : 0)];
   constexpr int WPF = T > 64 ? T / 64 : 1;               // wavefronts per frame
   __shared__ float mred[MEAN ? FPB * WPF * NH : 1];      // MEAN: the frame's wavefronts' partial sums
 
@@ -406,11 +418,45 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
           p.psd + (size_t)start * (M + 1), 0, (unsigned)((left > span ? span : left) * (long long)ROWB), 0x00020000);
       const unsigned row = (unsigned)rel_of(it) * ROWB;
       const unsigned vup = row + t * 4u, vdown = row + (unsigned)(M - 7 * T - (int)t) * 4u;
+      // STAGE: the row's floats into the exchange buffer's free upper part (the mirror step uses entries
+      // 0 .. M/2), at the offset s16 they have inside their 64-byte granule in memory
+      constexpr bool STAGE = GLFER16H_STAGE_ROWS != 0 && T >= 64 && (PADM - M / 2 - 8) * 2 >= M + 1 + 16 + 4 && !(GLFER_H_ABL & 1);
+      float *stg = reinterpret_cast<float *>(xb + (M / 2 + 8));
+      const unsigned long long gfl = (unsigned long long)(start + rel_of(it)) * (unsigned long long)(M + 1) +
+                                     (unsigned long long)(reinterpret_cast<__SIZE_TYPE__>(p.psd) >> 2);
+      const unsigned s16 = (unsigned)gfl & 15u;          // (uniform over the frame's wavefronts)
+      float *sup = stg + (s16 + t), *sdown = stg + (s16 + (unsigned)(M - 7 * T - (int)t));   // the staged bins t and M - 7T - t
       auto put = [&](float v, unsigned voff, unsigned soff) {
         if constexpr (GLFER_H_ABL & 1) {               // timing ablation: arithmetic kept live, no store traffic
           if (v == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, voff, soff, GLFER16H_STORE_AUX);
+        } else if constexpr (STAGE) {
+          (voff == vup ? sup : sdown)[soff >> 2] = v;  // (every call passes vup or vdown: folded at compile time)
         } else {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, voff, soff, GLFER16H_STORE_AUX);
+        }
+      };
+      // the staged row out: after the barrier that follows the last put
+      auto flush_row = [&] {
+        if constexpr (STAGE) {
+          frame_sync<T>();
+          typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+          const unsigned head = (4u - (s16 & 3u)) & 3u;             // floats in front of the first whole 16-byte chunk
+          const unsigned full = ((unsigned)(M + 1) - head) >> 2;   // whole chunks: 4 T or 4 T - 1 ... (M + 1 = 16 T + 1 floats)
+          const unsigned tail = ((unsigned)(M + 1) - head) & 3u;
+          const v4f32 *chunks = reinterpret_cast<const v4f32 *>(stg + (s16 + head));   // 16-byte aligned: s16 + head = 0 mod 4
+          static_assert(M + 1 == 16 * T + 1, "a row is 4 T whole chunks, or 4 T - 1 and ragged ends");
+          static_for<0, 4>([&](auto jc) {                          // chunk c = t + T j; the last pass may have one chunk too many
+            constexpr int j = decltype(jc)::value;
+            const unsigned c = t + (unsigned)(T * j);
+            const v4f32 q = chunks[c];
+            const unsigned off = row + (head + 4u * c) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, q), orsrc, (j < 3 || c < full) ? off : 0x80000000u, 0, GLFER16H_STORE_AUX);
+          });
+          if (t < 8u) {                                            // the frame's first wavefront: the row's ragged ends, float by float
+            if (t < head) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(stg[s16 + t]), orsrc, row + t * 4u, 0, GLFER16H_STORE_AUX);
+            const unsigned i = head + 4u * full + (t - 4u);
+            if (t >= 4u && t - 4u < tail) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(stg[s16 + i]), orsrc, row + i * 4u, 0, GLFER16H_STORE_AUX);
+          }
         }
       };
       static_for<0, 8>([&](auto mc) {
@@ -453,6 +499,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
           if (t == 0) put(nyq, vup, (unsigned)(M / 2) * 4u);
         }
       }
+      if (MT == 0 || last) flush_row();
     }
     float next_part = 0.0f;
     if constexpr (MEAN != 0) {
