@@ -5,7 +5,7 @@
 #include "stockham16.hpp"
 
 #ifndef GLFER_PSD_STORE_AUX
-#define GLFER_PSD_STORE_AUX 2      /* non-temporal: PSD rows are written once, never re-read by the kernel */
+#define GLFER_PSD_STORE_AUX 0      /* default cache policy: the non-temporal path wrote 1.07-1.26x the row bytes to HBM and is ~1 % slower (profiles/r03_store_policy.txt) */
 #endif
 
 namespace glfer {

@@ -48,7 +48,11 @@
 #define GLFER16H_SHIFT_BUILDS 1    /* build the register-reuse forms for 75 % and 50 % overlap */
 #endif
 #ifndef GLFER16H_STORE_AUX
-#define GLFER16H_STORE_AUX (GLFER_LOGN_OR(12) >= 12 ? 2 : 0)   /* non-temporal from N = 4096 up (rows written once; +3 %, N = 8192 +25 %); below that a store covers only part of a line per frame and must merge in L2 (nt: -17 % at N = 1024, -40 % at N = 512) */
+#define GLFER16H_STORE_AUX 0   /* default cache policy at every size.  Rounds 1-2 stored rows non-temporally from N = 4096 up (+3 % then,
+                                  N = 8192 +25 %); with the register reuse and the contiguous frame ranges of round 2 in place the
+                                  default policy is the faster one (N = 4096: +4...9 % at overlap 75 / 50 / 0 %, N = 8192: 0...5 %, N = 16384
+                                  equal) and the non-temporal path is what wrote 1.09x the row bytes to HBM (default policy: 1.005x) --
+                                  profiles/r03_store_policy.txt */
 #endif
 
 // Rows staged through LDS and stored 16 bytes per lane from a 64-byte boundary (round 3).  A PSD row is

@@ -45,7 +45,7 @@
 #define GLFER16W_DEPHASE 0        /* 1: workgroups of >= 8 wavefronts run S before C in their upper half (measured: -4 %, profiles/r02_spectro16w_variants.txt) */
 #endif
 #ifndef GLFER16W_STORE_AUX
-#define GLFER16W_STORE_AUX (GLFER_LOGN >= 12 ? 2 : 0)   /* non-temporal rows from N = 4096 up (spectro16h.hip measured it) */
+#define GLFER16W_STORE_AUX 0   /* default cache policy (round 3: equal speed, and no write excess; profiles/r03_store_policy.txt) */
 #endif
 
 // GLFER16W_STAMPS (diagnostic builds only, tools/build_variant.sh): lane 0 of every wavefront of one
