@@ -44,6 +44,9 @@
 #ifndef GLFER16H_PREFETCH_TOP
 #define GLFER16H_PREFETCH_TOP 0    /* 1: next frame's samples requested at the top of the iteration, not after exchange 0's writes */
 #endif
+#ifndef GLFER16H_PREFETCH2
+#define GLFER16H_PREFETCH2 0        /* 1: register-reuse forms (SHIFT 4 / 8, no mean removal): a frame's new pairs are requested TWO frames ahead, into landing registers */
+#endif
 #ifndef GLFER16H_SHIFT_BUILDS
 #define GLFER16H_SHIFT_BUILDS 1    /* build the register-reuse forms for 75 % and 50 % overlap */
 #endif
@@ -189,9 +192,12 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   long long start = 0;                                   // first frame of the workgroup's range
   // Pair m of the frame at rotation ROT lives in px[(m + ROT) & 15] (ROT != 0 only with SHIFT 4 / 8,
   // where the frame loop is unrolled over the rotations instead of moving registers).
-  auto load_pairs = [&](long long rel, auto fromc, auto rotc) {
+  constexpr bool PF2 = GLFER16H_PREFETCH2 != 0 && (SHIFT == 4 || SHIFT == 8) && MEAN == 0 && MT == 0 && HIST == 0;
+  v2f32 pb[PF2 ? 2 : 1][PF2 ? SHIFT : 1];               // PF2: the new pairs of frames f+1 / f+2 land here (frame parity picks the set)
+  auto load_pairs = [&](long long rel, auto fromc, auto rotc, auto destc) {
     constexpr int FROM = decltype(fromc)::value;         // pairs FROM..15 are loaded
     constexpr int ROT = decltype(rotc)::value;
+    constexpr int DEST = decltype(destc)::value;         // 0: px (rotated); 1, 2: landing set DEST - 1
     const long long last_rel = (long long)p.nframes - 1 - start;
     const unsigned relc = (unsigned)(rel < last_rel ? rel : last_rel);
     const long long sblk = (p.frame0 + start) * (long long)p.H - p.R;
@@ -231,31 +237,33 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     // whose pairs are not naturally aligned to spectro16.hip)
     static_for<FROM, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value, q = (m + ROT) & 15;
+      v2f32 &dst = DEST == 0 ? px[q] : pb[DEST > 0 ? DEST - 1 : 0][PF2 ? m - FROM : 0];
       if constexpr (FMT == GLFER_FMT_F32) {
-        px[q] = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, lrel * 4u, (unsigned)(2 * T * m) * 4u, 0));
+        dst = __builtin_bit_cast(v2f32, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, lrel * 4u, (unsigned)(2 * T * m) * 4u, 0));
       } else if constexpr (FMT == GLFER_FMT_S16) {
-        px[q].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, lrel * 2u, (unsigned)(2 * T * m) * 2u, 0));
+        dst.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, lrel * 2u, (unsigned)(2 * T * m) * 2u, 0));
       } else {
-        px[q].x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, lrel, (unsigned)(2 * T * m), 0));
+        dst.x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, lrel, (unsigned)(2 * T * m), 0));
       }
     });
   };
+  constexpr std::integral_constant<int, 0> kToPx{};
   // the next frame of this slot: with SHIFT its first 16-SHIFT pairs are already here
   constexpr bool UNROLL = SHIFT == 4 || SHIFT == 8;      // 16/SHIFT copies of the frame loop's body
   auto prefetch_next = [&](long long rel, auto rotc) {
     constexpr int ROT = decltype(rotc)::value;             // the rotation of the frame in flight
     if constexpr (UNROLL) {
-      load_pairs(rel, std::integral_constant<int, 16 - SHIFT>{}, std::integral_constant<int, (ROT + SHIFT) & 15>{});
+      load_pairs(rel, std::integral_constant<int, 16 - SHIFT>{}, std::integral_constant<int, (ROT + SHIFT) & 15>{}, kToPx);
     } else if constexpr (SHIFT > 0) {
 #pragma unroll
       for (int m = 0; m < 16 - SHIFT; m++) px[m] = px[m + SHIFT];
-      load_pairs(rel, std::integral_constant<int, 16 - SHIFT>{}, rotc);
+      load_pairs(rel, std::integral_constant<int, 16 - SHIFT>{}, rotc, kToPx);
     } else {
-      load_pairs(rel, std::integral_constant<int, 0>{}, rotc);
+      load_pairs(rel, std::integral_constant<int, 0>{}, rotc, kToPx);
     }
   };
   auto prefetch_x = [&](long long rel) {
-    load_pairs(rel, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    load_pairs(rel, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, kToPx);
     if constexpr (HIST != 0) {   // history_mode 1: sample j = 2*(t + T*m) + e is kept iff j >= R.  Zeroed in
       const int d = 2 * (int)t - p.R;                  // place (this waits for the loads; a rare mode)
       static_for<0, 16>([&](auto mc) {
@@ -301,6 +309,9 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   auto rel_of = [&](long long i) { return SHIFT > 0 ? (long long)fl * per + i : i * FPB + (long long)fl; };
   long long it = 0;                                        // frames done by every slot
   prefetch_x(rel_of(0));
+  if constexpr (PF2) {                                     // frame 1's new pairs: landing set 1
+    load_pairs(rel_of(1), std::integral_constant<int, 16 - SHIFT>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+  }
 
   // ---- MEAN: sums over the hop held in registers [q KM, (q+1) KM) of the frame at rotation ROT
   float mu[MEAN ? NH : 1];                               // the frame's hop means, oldest first (unscaled sample units)
@@ -350,6 +361,16 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   const int ntap = MT ? p.htapers : 1;
   auto frame_body = [&](auto rotc) -> bool {
     const bool has_next = it + 1 < per;
+    if constexpr (PF2) {
+      // this frame's new pairs were requested two frames ago (frame 1's: before the loop) into the landing
+      // set of its parity; their px slots -- the previous frame's oldest pairs -- are free since that frame's
+      // samples were formed
+      constexpr int ROT = decltype(rotc)::value, PAR = (ROT / SHIFT) & 1;
+      if (it > 0) {
+#pragma unroll
+        for (int i = 0; i < SHIFT; i++) px[(16 - SHIFT + i + ROT) & 15] = pb[PAR][i];
+      }
+    }
     float acc[MT ? 17 : 1];                            // MT: bins k = t + T*m (m < 8), M - k (8 + m), M/2 (16)
     if constexpr (MT != 0) {
 #pragma unroll
@@ -390,6 +411,10 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       }
     }
     if constexpr (GLFER16H_PREFETCH_TOP != 0 && !(GLFER_H_ABL & 2)) {
+      if constexpr (PF2) {
+        constexpr int PAR = (decltype(rotc)::value / SHIFT) & 1;
+        if (it + 2 < per) load_pairs(rel_of(it + 2), std::integral_constant<int, 16 - SHIFT>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, PAR + 1>{});
+      } else
       if (has_next && last) prefetch_next(rel_of(it + 1), rotc);   // px is free as soon as xs is formed
     }
 
@@ -398,6 +423,10 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
 #pragma unroll
         for (int m = 0; m < 16; m++) px[m] = px[m] * 0.999f;
       } else if constexpr (GLFER16H_PREFETCH_TOP == 0) {
+        if constexpr (PF2) {                               // frame it + 2's new pairs into this frame's (emptied) landing set
+          constexpr int PAR = (decltype(rotc)::value / SHIFT) & 1;
+          if (it + 2 < per) load_pairs(rel_of(it + 2), std::integral_constant<int, 16 - SHIFT>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, PAR + 1>{});
+        } else
         if (has_next && last) prefetch_next(rel_of(it + 1), rotc);   // the frame's last use of px is behind us
       }
     });
