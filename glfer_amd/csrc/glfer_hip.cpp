@@ -1091,6 +1091,17 @@ static bool route_takes_mean(BodyRoute r, const SpectroParams &sp, int n) {
   }
 }
 
+// ... and of those, the forms that subtract GIVEN means (round 3): spectro16h.hip's periodogram form, the packed
+// kernel, spectro16y.hip
+static bool route_takes_table(BodyRoute r, const SpectroParams &sp, int n) {
+  switch (r) {
+    case ROUTE_PACKED: return true;
+    case ROUTE_REAL_INPUT: return sp.npairs == 1 && sp.htapers <= 1;
+    case ROUTE_SHARED_ODD: return n == 4096;
+    default: return false;
+  }
+}
+
 static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   if (n > 16384) return launch_wave_private(sp, n, st);        // its general form takes every case itself
   const BodyRoute route = body_route(sp, n);
@@ -1117,6 +1128,7 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
     q.nframes = (int)(to - from);
     q.psd = sp.psd + (size_t)(from - lo) * (size_t)(n / 2 + 1);
     q.mean_inkernel = 0;                           // (head and tail frames: never with mean_inkernel, see above)
+    q.means = nullptr;
     return q;
   };
   if (b0 > lo) {
@@ -1131,6 +1143,7 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
   }
   SpectroParams body = sub(b0, b1);
   body.mean_inkernel = sp.mean_inkernel;
+  body.means = sp.means;
   if (wave_private) return launch_wave_private(body, n, st);
   return real_input ? launch_real_input(body, n, st) : launch_shared_odd(body, n, st);
 }
@@ -1224,11 +1237,15 @@ static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t fi
 // keeps the pre-pass (A/B runs, and the tests that compare the two).
 static bool mean_inkernel_ok(const glfer_hip_plan *p, const SpectroParams &sp, const float *d_spec, long tail_fresh) {
   if (p->nonlin || d_spec || tail_fresh >= 0 || sp.history_mode) return false;
-  if (p->cfg.sub_mean == GLFER_SUBMEAN_EXACT) return false;     // the kernels sum a hop in another order than fft.c:88-92
   if (p->cfg.mode != GLFER_MODE_FFT && p->cfg.mode != GLFER_MODE_LMP && p->cfg.mode != GLFER_MODE_MTM) return false;
   const char *e = getenv("GLFER_MEAN_PREPASS");
   if (e && *e == '1') return false;
-  return route_takes_mean(body_route(sp, p->n), sp, p->n);
+  const BodyRoute r = body_route(sp, p->n);
+  if (!route_takes_mean(r, sp, p->n)) return false;
+  // GLFER_SUBMEAN_EXACT: the kernels sum a hop in another order than fft.c:88-92, so they are handed the means
+  // (SpectroParams::means) -- the forms that take a table: the periodogram, the packed kernel, spectro16y
+  if (p->cfg.sub_mean == GLFER_SUBMEAN_EXACT && !route_takes_table(r, sp, p->n)) return false;
+  return true;
 }
 
 // Periodograms of frames [first, first + nframes) with the mean removal (fft.c:86-96) done inside the
@@ -1270,7 +1287,21 @@ static int launch_mean_inkernel(const glfer_hip_plan *p, const SpectroParams &sp
     bs.psd = d_psd + (b0 - first) * (size_t)p->bins;
     bs.spec = nullptr;
     bs.mean_inkernel = 1;
-    hipError_t e = launch_by_n(bs, p->n, st);
+    float *means = nullptr;
+    hipError_t e = hipSuccess;
+    if (p->cfg.sub_mean == GLFER_SUBMEAN_EXACT) {
+      // the means of the hops the body's frames touch, in the reference's order; the kernel indexes them by
+      // GLOBAL hop (= frame) index
+      const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop);
+      const size_t hop_lo = b0 - hops_back, nhops = b1 - hop_lo;                  // (b0 >= first_inside >= hops_back)
+      const size_t esz = sp.fmt == GLFER_FMT_F32 ? 4 : (sp.fmt == GLFER_FMT_S16 ? 2 : 1);
+      e = glfer::scratch_malloc((void **)&means, nhops * sizeof(float), st);
+      if (e == hipSuccess)
+        e = glfer_launch_hop_means_seq((const char *)sp.stream + hop_lo * (size_t)p->hop * esz, means, p->hop, (long long)nhops, sp.fmt, st);
+      bs.means = means ? means - hop_lo : nullptr;
+    }
+    if (e == hipSuccess) e = launch_by_n(bs, p->n, st);
+    if (means) glfer::scratch_free(means, st);
     if (e != hipSuccess) rc = hip_fail(e, "estimator launch (mean removal in the kernel)");
   }
   by_copy(std::max(b1, std::min(b0, end)), end);

@@ -177,6 +177,14 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
 
   while (true) {
     if constexpr (KM > 0) {
+      if (pair == 0 && p.means) {
+        // GLFER_SUBMEAN_EXACT: the hop means are given (taken in the reference's own order by hop_means_seq_kernel,
+        // means[global hop index]; the newest hop of frame F of the stream is hop F; px holds sample units here)
+        const long long fc = fblk + fl < p.nframes ? fblk + fl : (long long)p.nframes - 1;   // (the clamp of prefetch_x)
+        const long long F = p.frame0 + fc;
+#pragma unroll
+        for (int m = 0; m < 16; m++) px[m] = px[m] - p.means[F - (NH - 1) + m / KM];          // fft.c:93-95
+      } else
       if (pair == 0) {                               // a new frame's samples: x <- x - (mean of the hop x arrived in)
         float sm[NH];
 #pragma unroll

@@ -343,15 +343,30 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       return sm / (float)p.H;
     }
   };
+  // p.means (GLFER_SUBMEAN_EXACT): the hop means are GIVEN -- taken in the reference's own order by
+  // hop_means_seq_kernel -- as means[global hop index] in sample units; here they are used in the units
+  // the samples are held in (integer formats: raw, the power-of-two scale rides in the window: exact).
+  // The newest hop of frame F of the stream is hop F.
+  const bool mean_table = MEAN != 0 && p.means != nullptr;
+  auto table_mean = [&](long long rel, int back) -> float {      // the mean of the hop `back` hops before frame rel's newest
+    const long long last_rel = (long long)p.nframes - 1 - start;
+    const long long F = p.frame0 + start + (rel < last_rel ? rel : last_rel);
+    return p.means[F - back] * (1.0f / kSampleScale);
+  };
   if constexpr (MEAN != 0) {
-    float part[NH];
-    static_for<0, NH>([&](auto qc) {
-      part[decltype(qc)::value] = hop_partial(qc, std::integral_constant<int, 0>{});
-      publish(part[decltype(qc)::value], decltype(qc)::value);
-    });
-    frame_sync<T>();
-    static_for<0, NH>([&](auto qc) { mu[decltype(qc)::value] = collect(part[decltype(qc)::value], decltype(qc)::value); });
-    frame_sync<T>();                                     // mred is free again
+    if (mean_table) {
+#pragma unroll
+      for (int q = 0; q < NH; q++) mu[q] = table_mean(rel_of(0), NH - 1 - q);
+    } else {
+      float part[NH];
+      static_for<0, NH>([&](auto qc) {
+        part[decltype(qc)::value] = hop_partial(qc, std::integral_constant<int, 0>{});
+        publish(part[decltype(qc)::value], decltype(qc)::value);
+      });
+      frame_sync<T>();
+      static_for<0, NH>([&](auto qc) { mu[decltype(qc)::value] = collect(part[decltype(qc)::value], decltype(qc)::value); });
+      frame_sync<T>();                                     // mred is free again
+    }
   }
 
   constexpr int RL = C::radix(NPASS - 1), BL = 16 / RL;
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     if constexpr (MEAN != 0) {
       // the next frame's newest hop is in px by now (requested during this frame's passes): its sum
       // crosses the frame's wavefronts over the barrier that ends the iteration
-      if (has_next && last) {                          // (the multitaper form: after the frame's last taper)
+      if (has_next && last && !mean_table) {           // (the multitaper form: after the frame's last taper)
         constexpr int ROTN = (SHIFT == 4 || SHIFT == 8) ? ((decltype(rotc)::value + SHIFT) & 15) : 0;
         next_part = hop_partial(std::integral_constant<int, NH - 1>{}, std::integral_constant<int, ROTN>{});
         publish(next_part, NH - 1);
@@ -547,7 +562,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();     // mirror entries read: buffer free
     if constexpr (MEAN != 0) {
       if (has_next && last) {
-        const float mn = collect(next_part, NH - 1);
+        const float mn = mean_table ? table_mean(rel_of(it + 1), 0) : collect(next_part, NH - 1);
 #pragma unroll
         for (int h = 0; h + 1 < NH; h++) mu[h] = mu[h + 1];
         mu[NH - 1] = mn;

@@ -144,11 +144,29 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
       xB[m] = xB[m] - mu[m / (KM ? KM : 1) + 1];
     }
   };
+  // p.means (GLFER_SUBMEAN_EXACT): the hop means are given -- taken in the reference's own order by
+  // hop_means_seq_kernel, means[global hop index]; the newest hop of frame F of the stream is hop F
+  auto subtract_table_means = [&](long long fa) {      // fa: frame A's index in the launch
+    float mu[NH + 1];
+    const long long F = p.frame0 + fa;
+#pragma unroll
+    for (int q = 0; q < NH; q++) mu[q] = p.means[F - (NH - 1) + q];
+    mu[NH] = p.means[fa + 1 < p.nframes ? F + 1 : F];  // frame B's newest hop (no frame B: its registers are zeroed afterwards)
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      xA[m] = xA[m] - mu[m / (KM ? KM : 1)];
+      xB[m] = xB[m] - mu[m / (KM ? KM : 1) + 1];
+    }
+  };
   if constexpr (KM > 0) {
-    publish_hop_sums();
-    __syncthreads();
-    subtract_hop_means();
-    __syncthreads();                                 // mred is free again
+    if (p.means) {
+      subtract_table_means(fA);
+    } else {
+      publish_hop_sums();
+      __syncthreads();
+      subtract_hop_means();
+      __syncthreads();                               // mred is free again
+    }
     if (fA + 1 >= p.nframes) {
 #pragma unroll
       for (int m = 0; m < 16; m++) xB[m] = 0.0f;
@@ -280,14 +298,17 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
       }
     });
     if constexpr (KM > 0) {
-      if (has_next) publish_hop_sums();              // the next iteration's samples are in registers (requested during the passes above)
+      if (has_next && !p.means) publish_hop_sums();  // the next iteration's samples are in registers (requested during the passes above)
     }
     separate_and_store<12, 1>(p, zr, zi, xbA, t, 0u, fA, hxA, hxB,
                               [&](auto mc) { if constexpr (decltype(mc)::value == 8) return nyqA; else return psdA[decltype(mc)::value]; },
                               [&](auto mc) { if constexpr (decltype(mc)::value == 8) return nyqB; else return psdB[decltype(mc)::value]; });
     GLFER_STAMP(15);                                 // shared round end (separated, stored)
     if constexpr (KM > 0) {
-      if (has_next) subtract_hop_means();            // (separate_and_store's barriers lie between the sums and this)
+      if (has_next) {                                // (separate_and_store's barriers lie between the sums and this)
+        if (p.means) subtract_table_means(nfA);
+        else subtract_hop_means();
+      }
     }
     if (!has_next) break;
     fA = nfA;

@@ -47,6 +47,9 @@ struct SpectroParams {
   int ft_mu_live;          /* 0: mu is all zeros (the reference build without FFTW, mtm.c:173) */
   int mean_inkernel;       /* per-hop mean removal (fft.c:86-96) inside spectro16h.hip: the stream is the RAW one;
                               only where the hop is 2, 4, 8 or 16 sixteenths of N               */
+  const float *means;      /* device, optional (with mean_inkernel): means[h] = the mean of hop h of the whole stream (virtual
+                              base), taken in the reference's own order (submean_seq.hip, GLFER_SUBMEAN_EXACT); the kernel
+                              subtracts these instead of summing the hops itself                */
 };
 
 #ifdef __cplusplus

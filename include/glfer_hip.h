@@ -103,10 +103,12 @@ typedef struct glfer_hip_config {
  *                        maximum (measured at |mean| = rms: 6.6e-4 Hanning periodogram, 7e-5
  *                        multitaper, N = 4096, 50 % overlap; tests/test_gpu_round3.py) -- so above
  *                        |mean|/rms ~ 0.01 take the other one.
- *   GLFER_SUBMEAN_EXACT  the means are accumulated in the reference's own order (one lane walks a
- *                        hop, 64 hops side by side; one more read of the stream) and the estimator
- *                        reads a corrected copy: the reference's rows to the usual 1e-5 whatever
- *                        the input; costs the copy (C3: 52 instead of 71 M frames/s).
+ *   GLFER_SUBMEAN_EXACT  the means are accumulated in the reference's own order (hop_means_seq_kernel: one
+ *                        lane walks a hop, 64 hops side by side; one more read of the stream) and handed
+ *                        to the estimator kernels as a table (periodograms, even taper counts, 5 / 7 ...
+ *                        tapers at N = 4096; the other forms read a corrected copy): the reference's rows
+ *                        to the usual 1e-5 whatever the input.  Cost: the extra read -- C3 64 against 75,
+ *                        C2 230 against 277, C1 772 against 1 108 M frames/s (tools/exact_mean_time.py).
  * The per-hop shims (glfer_compat.h) always take the reference's order. */
 enum { GLFER_SUBMEAN_OFF = 0, GLFER_SUBMEAN_FAST = 1, GLFER_SUBMEAN_EXACT = 2 };
 

@@ -159,7 +159,7 @@ def _dc_frames(kinds, n, hop, nframes):
     return [bool(is_dc[max(0, f * hop - (n - hop)):f * hop + hop].any()) for f in range(nframes)]
 
 
-@pytest.mark.parametrize("n,kmax,nw", [(4096, 4, 2.5), (1024, 4, 2.5), (4096, 0, 0.0)])
+@pytest.mark.parametrize("n,kmax,nw", [(4096, 4, 2.5), (1024, 4, 2.5), (4096, 0, 0.0), (1024, 3, 2.0), (4096, 7, 4.0), (2048, 0, 0.0)])
 def test_adversarial_pairs_with_mean_removal(lib, oracle, torch_cuda, n, kmax, nw):
     """The same shapes with per-hop mean removal on (the reference's default, glfer.c:275): a DC frame
     becomes (nearly) silence next to a loud partner -- the scale-0 / tiny-scale corner -- and a DC
@@ -230,6 +230,20 @@ def test_exact_order_means_on_dc_heavy_streams(lib, oracle, torch_cuda):
             assert max(rel_err(got[f], want[f])) <= TOL, (n, overlap, fmt, f, rel_err(got[f], want[f]))
         part = sp.run(d, first_frame=37, nframes=20).cpu().numpy()
         assert np.array_equal(part.view(np.uint32), got[37:57].view(np.uint32))
+    # the multitaper forms that take the means as a table (spectro16y: 5 tapers at N = 4096; the packed kernel: 8
+    # tapers) and one that takes the copy (spectro16xl: 5 tapers at N = 1024), launches inside the stream included
+    for n, overlap, kmax, nw in ((4096, 0.0, 4, 2.5), (4096, 0.75, 4, 2.5), (1024, 0.5, 7, 4.0), (1024, 0.5, 4, 2.5)):
+        hop = int(n * (1.0 - float(np.float32(overlap))))
+        frames = 71
+        x = (0.45 + 0.3 * rng.standard_normal(frames * hop)).clip(-0.99, 0.99).astype(np.float32)
+        want = oracle.spectrogram_mtm(x, n, overlap, nw, kmax, sub_mean=1)
+        sp = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=2))
+        d = torch.from_numpy(x).cuda()
+        got = sp.run(d).cpu().numpy()
+        for f in range(frames):
+            assert max(rel_err(got[f], want[f])) <= TOL, (n, overlap, kmax, f, rel_err(got[f], want[f]))
+        part = sp.run(d, first_frame=32, nframes=32).cpu().numpy()
+        assert np.array_equal(part.view(np.uint32), got[32:64].view(np.uint32))
 
 
 # ---- kept scratch: asynchronous hand-off between streams, the cap, the trim entry ---------------------
