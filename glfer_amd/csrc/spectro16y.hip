@@ -20,6 +20,10 @@
 #ifndef GLFER16Y_DPP_SUM
 #define GLFER16Y_DPP_SUM 1
 #endif
+#ifndef GLFER16Y_TW1_REGS
+#define GLFER16Y_TW1_REGS 1       /* the lane's 15 pass-1 twiddles in registers instead of 15 LDS reads per transform (where they fit without a spill:
+                                     not with history zeroed per frame, not the 75 % mean form): +1.5...2 %, profiles/r03_y_tw1_regs.txt */
+#endif
 
 namespace glfer {
 
@@ -74,6 +78,12 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
   }
   __syncthreads();
   const v2f32 *tw1row = tw1 + (t & 15) * 17;
+  constexpr bool TW1R = GLFER16Y_TW1_REGS != 0 && HIST == 0 && KM != 4;
+  v2f32 tw1reg[16];
+  if constexpr (TW1R) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) tw1reg[q] = tw1row[q];
+  }
 
   const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(p.taps), 0, p.npairs * 2 * N * 4, 0x00020000);
@@ -196,10 +206,14 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
           zrB[m] = xB[m] * pt[m].x;
           ziB[m] = xB[m] * pt[m].y;
         }
-        stockham16_passes2<12, NT>(zrA, ziA, xbA, zrB, ziB, xbB, t, tw1row, twr, twi, [&] {
-          if (pair + 1 < NP) prefetch_taps(pair + 1);
-          else prefetch_last();
-        });
+        auto dual = [&](const auto &tw1sel) {
+          stockham16_passes2<12, NT>(zrA, ziA, xbA, zrB, ziB, xbB, t, tw1sel, twr, twi, [&] {
+            if (pair + 1 < NP) prefetch_taps(pair + 1);
+            else prefetch_last();
+          });
+        };
+        if constexpr (TW1R) dual(tw1reg);
+        else dual(tw1row);
         if (pair == 0) {                             // the first pair starts the sums (no zeroing pass)
 #pragma unroll
           for (int r = 0; r < 16; r++) {
@@ -290,13 +304,17 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
       }
     }
     // the next iteration's samples and first taper pair go out after the first exchange's writes
-    stockham16_passes<12, NT>(zr, zi, xbA, t, tw1row, twr, twi, [&] {
-      if (has_next) {
-        prefetch_taps(0);
-        load_x(xA, nfA);
-        load_x(xB, nfA + 1);
-      }
-    });
+    auto shared_round = [&](const auto &tw1sel) {
+      stockham16_passes<12, NT>(zr, zi, xbA, t, tw1sel, twr, twi, [&] {
+        if (has_next) {
+          prefetch_taps(0);
+          load_x(xA, nfA);
+          load_x(xB, nfA + 1);
+        }
+      });
+    };
+    if constexpr (TW1R) shared_round(tw1reg);
+    else shared_round(tw1row);
     if constexpr (KM > 0) {
       if (has_next && !p.means) publish_hop_sums();  // the next iteration's samples are in registers (requested during the passes above)
     }

@@ -153,9 +153,9 @@ __device__ __forceinline__ void lds_read16_strided(const v2f32 *base, v2f32 (&v)
 // (M + M/16 entries), tw1row: the lane's row of the shared pass-1 table, twr/twi: the
 // lane's later-pass twiddles.  after_first_write() runs between the first exchange's writes
 // and its barrier: the place where the next round's global loads are issued.
-template <int LOGM, int NT, class Hook>
+template <int LOGM, int NT, class Tw1, class Hook>
 __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[16], v2f32 *xb, unsigned t,
-                                                  const v2f32 *tw1row, const float (&twr)[NT],
+                                                  const Tw1 &tw1row, const float (&twr)[NT],
                                                   const float (&twi)[NT], Hook &&after_first_write) {
   using C = Plan16<LOGM>;
   constexpr int T = C::T, NPASS = C::NPASS, TW1 = 15;
@@ -271,9 +271,11 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
 // pipe under B's arithmetic, and each barrier serves both transforms (4 per pair of transforms
 // instead of 8).  Same arithmetic per stream as stockham16_passes; requires the
 // barrier-after-reads scheme and radix-16 passes in front of every exchange.
-template <int LOGM, int NT, class Hook>
+// tw1row: the lane's pass-1 twiddles, tw1row[q], q = 1..15 -- a row of the shared LDS table (const v2f32 *) or the
+// lane's own registers (const v2f32 (&)[16]: GLFER16Y_TW1_REGS)
+template <int LOGM, int NT, class Tw1, class Hook>
 __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA)[16], v2f32 *xbA, float (&zrB)[16],
-                                                   float (&ziB)[16], v2f32 *xbB, unsigned t, const v2f32 *tw1row,
+                                                   float (&ziB)[16], v2f32 *xbB, unsigned t, const Tw1 &tw1row,
                                                    const float (&twr)[NT], const float (&twi)[NT],
                                                    Hook &&after_first_write) {
   using C = Plan16<LOGM>;
