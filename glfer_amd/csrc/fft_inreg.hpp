@@ -118,6 +118,27 @@ __device__ __forceinline__ void dit(float (&re)[LEN], float (&im)[LEN]) {
 // dit<R,...> whose LAST stage hands every finished output to emit(k, reg) -- X[k] sits in register
 // reg -- as soon as its butterfly is done (two outputs per butterfly: k and k + R/2), so that the
 // consumer (an LDS store) is issued between butterflies instead of in one burst after the transform.
+// dit_emit in two halves, for callers that put something (a barrier) in front of the last stage: head = all stages
+// but the last, tail = the last stage with its emits.  head + tail is dit_emit, operation for operation.
+template <int R, int S, int OFF, int LEN>
+__device__ __forceinline__ void dit_head(float (&re)[LEN], float (&im)[LEN]) {
+  static_assert(R >= 2, "radix");
+  dit<R / 2, 2 * S, OFF, LEN>(re, im);
+  dit<R / 2, 2 * S, OFF + S, LEN>(re, im);
+}
+template <int R, int S, int OFF, int LEN, class F>
+__device__ __forceinline__ void dit_tail(float (&re)[LEN], float (&im)[LEN], F &&emit) {
+  static_for<0, R / 2>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int pa = OFF + 2 * S * brev(k, R / 2);
+    bfly<R, k, pa, pa + S, LEN>(re, im);
+    emit(std::integral_constant<int, k>{}, std::integral_constant<int, pa>{});
+    emit(std::integral_constant<int, k + R / 2>{}, std::integral_constant<int, pa + S>{});
+    if constexpr (GLFER_BFLY_GROUP > 0 && (k % GLFER_BFLY_GROUP) == GLFER_BFLY_GROUP - 1)
+      __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
 template <int R, int S, int OFF, int LEN, class F>
 __device__ __forceinline__ void dit_emit(float (&re)[LEN], float (&im)[LEN], F &&emit) {
   static_assert(R >= 2, "radix");

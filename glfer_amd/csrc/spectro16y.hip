@@ -20,6 +20,10 @@
 #ifndef GLFER16Y_DPP_SUM
 #define GLFER16Y_DPP_SUM 1
 #endif
+#ifndef GLFER16Y_SKEW
+#define GLFER16Y_SKEW 1           /* stockham16_passes2s: frame B's exchange reads and the buffer-release barrier under frame A's arithmetic (+1.5 %,
+                                     profiles/r03_y_skew.txt); 2: the shared round's barrier in front of its last stage too (stockham16_passes1s) */
+#endif
 #ifndef GLFER16Y_TW1_REGS
 #define GLFER16Y_TW1_REGS 1       /* the lane's 15 pass-1 twiddles in registers instead of 15 LDS reads per transform (where they fit without a spill:
                                      not with history zeroed per frame, not the 75 % mean form): +1.5...2 %, profiles/r03_y_tw1_regs.txt */
@@ -207,10 +211,12 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
           ziB[m] = xB[m] * pt[m].y;
         }
         auto dual = [&](const auto &tw1sel) {
-          stockham16_passes2<12, NT>(zrA, ziA, xbA, zrB, ziB, xbB, t, tw1sel, twr, twi, [&] {
+          auto hook = [&] {
             if (pair + 1 < NP) prefetch_taps(pair + 1);
             else prefetch_last();
-          });
+          };
+          if constexpr (GLFER16Y_SKEW != 0) stockham16_passes2s<12, NT>(zrA, ziA, xbA, zrB, ziB, xbB, t, tw1sel, twr, twi, hook);
+          else stockham16_passes2<12, NT>(zrA, ziA, xbA, zrB, ziB, xbB, t, tw1sel, twr, twi, hook);
         };
         if constexpr (TW1R) dual(tw1reg);
         else dual(tw1row);
@@ -305,13 +311,15 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
     }
     // the next iteration's samples and first taper pair go out after the first exchange's writes
     auto shared_round = [&](const auto &tw1sel) {
-      stockham16_passes<12, NT>(zr, zi, xbA, t, tw1sel, twr, twi, [&] {
+      auto hook = [&] {
         if (has_next) {
           prefetch_taps(0);
           load_x(xA, nfA);
           load_x(xB, nfA + 1);
         }
-      });
+      };
+      if constexpr (GLFER16Y_SKEW >= 2) stockham16_passes1s<12, NT>(zr, zi, xbA, t, tw1sel, twr, twi, hook);
+      else stockham16_passes<12, NT>(zr, zi, xbA, t, tw1sel, twr, twi, hook);
     };
     if constexpr (TW1R) shared_round(tw1reg);
     else shared_round(tw1row);

@@ -147,6 +147,28 @@ __device__ __forceinline__ void lds_read16_strided(const v2f32 *base, v2f32 (&v)
                : "memory");
 }
 
+// The same reads issued WITHOUT the wait, and the wait on its own: lds_wait16<K>(v) returns when at most K LDS
+// operations issued after v's reads are still outstanding (LDS operations complete in order), and ties v's
+// registers to that point for the compiler.  Between the issue and the wait the compiler must have no reason to
+// touch v (callers keep it out of every expression until the wait).
+template <int STRIDE>
+__device__ __forceinline__ void lds_issue16_strided(const v2f32 *base, v2f32 (&v)[16]) {
+  static_assert(15 * STRIDE * 8 < 65536, "ds offset field");
+  const unsigned addr = (unsigned)(__SIZE_TYPE__)(const __attribute__((address_space(3))) char *)base;
+  static_for<0, 16>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    lds_read_b64_asm<m * STRIDE * 8>(addr, v[m]);
+  });
+}
+template <int K>
+__device__ __forceinline__ void lds_wait16(v2f32 (&v)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(%16)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                 "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+               : "n"(K)
+               : "memory");
+}
+
 // The Stockham passes of one complex 2^LOGM-point transform held 16 points per lane
 // (lane t of T = 2^LOGM/16: points t + T*m on entry; on exit register b + B*brev(q',R) holds
 // bin t + T*(b + B*q'), R = last radix, B = 16/R).  xb: this frame's exchange buffer
@@ -377,6 +399,183 @@ __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA
       }
       frame_sync<T>();                       // both buffers read: free for the next writes
       GLFER_STAMP(4 * i + 4);                // both streams' reads landed, through the barrier
+    }
+  });
+}
+
+// stockham16_passes2 with stream B's exchange reads and the buffer-release barrier moved under stream A's
+// arithmetic (round 3).  After an exchange's writes are in LDS: both streams' reads are ISSUED; A's sixteen are
+// waited for alone and A runs its twiddles and all butterfly stages but the last while B's land; then the barrier
+// that frees the buffers (every wavefront reaches it with arithmetic done, so the skew between them is absorbed
+// there instead of stalling the reads), A's last stage with its exchange writes, and B's whole pass.  Per stream
+// the operations and their order are those of stockham16_passes2: bit-identical results.  Radix-16 passes only.
+template <int LOGM, int NT, class Tw1, class Hook>
+__device__ __forceinline__ void stockham16_passes2s(float (&zrA)[16], float (&ziA)[16], v2f32 *xbA, float (&zrB)[16],
+                                                    float (&ziB)[16], v2f32 *xbB, unsigned t, const Tw1 &tw1row,
+                                                    const float (&twr)[NT], const float (&twi)[NT],
+                                                    Hook &&after_first_write) {
+  using C = Plan16<LOGM>;
+  constexpr int T = C::T, NPASS = C::NPASS, TW1 = 15;
+  static_assert(GLFER16_BARRIER_AFTER_READS != 0 && GLFER16_X0_ROWS != 0 && T >= 32 && T % 32 == 0 && !(GLFER_ABL & 7), "the product configuration");
+  static_for<0, NPASS>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int R = C::radix(i), Ls = C::ls(i);
+    static_assert(R == 16, "radix-16 passes");
+    auto twiddle = [&](float (&zr)[16], float (&zi)[16]) {
+      if constexpr (i == 1) {
+        static_for<1, 16>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const v2f32 w = tw1row[q];
+          const float a = zr[q], c = zi[q];
+          zr[q] = __builtin_fmaf(a, w.x, -c * w.y);
+          zi[q] = __builtin_fmaf(a, w.y, c * w.x);
+        });
+      } else if constexpr (i > 1) {
+        static_for<1, R>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          constexpr int e = C::tw_offset(i) - TW1 + (q - 1);
+          const float a = zr[q], c = zi[q];
+          zr[q] = __builtin_fmaf(a, twr[e], -c * twi[e]);
+          zi[q] = __builtin_fmaf(a, twi[e], c * twr[e]);
+        });
+      }
+    };
+    // the last stage: with the exchange writes (a pass that an exchange follows) or plain
+    auto tail = [&](float (&zr)[16], float (&zi)[16], v2f32 *xb) {
+      if constexpr (i < NPASS - 1) {
+        const int k = (int)t & (Ls - 1);
+        const int a0 = ((int)t - k) * R + k;
+        constexpr bool kRows = i == 0;
+        v2f32 *wbase = kRows ? xb + t : xb + a0 + (a0 >> xpad_shift(i));
+        dit_tail<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
+          constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
+          wbase[kRows ? q * (T + 2) : xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
+        });
+      } else {
+        dit_tail<R, 1, 0, 16>(zr, zi, [](auto, auto) {});
+      }
+    };
+    if constexpr (i == 0) {
+      dit_head<R, 1, 0, 16>(zrA, ziA);
+      tail(zrA, ziA, xbA);
+      __builtin_amdgcn_sched_barrier(0);
+      dit_head<R, 1, 0, 16>(zrB, ziB);
+      tail(zrB, ziB, xbB);
+      after_first_write();
+      __builtin_amdgcn_sched_barrier(0);
+      frame_sync<T>();                         // both streams' writes are in LDS
+    } else {
+      // the reads of exchange i - 1, both streams, issued back to back
+      v2f32 va[16], vb[16];
+      if constexpr (i == 1) {
+        const int roff = (int)(t & 15) * (T + 2) + (int)(t >> 4);
+        lds_issue16_strided<T / 16>(xbA + roff, va);
+        lds_issue16_strided<T / 16>(xbB + roff, vb);
+      } else {
+        constexpr int STRIDE = xpad_offset(i - 1, T);
+        static_assert(15 * STRIDE * 8 < 65536 && xpad_offset(i - 1, 15 * T) == 15 * STRIDE, "one stride");
+        lds_issue16_strided<STRIDE>(xbA + t + (t >> xpad_shift(i - 1)), va);
+        lds_issue16_strided<STRIDE>(xbB + t + (t >> xpad_shift(i - 1)), vb);
+      }
+      lds_wait16<15>(va);                      // (lgkmcnt has four bits) at most 15 of the 32 outstanding: A's sixteen have landed
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        zrA[m] = va[m].x;
+        ziA[m] = va[m].y;
+      }
+      twiddle(zrA, ziA);
+      dit_head<R, 1, 0, 16>(zrA, ziA);
+      lds_wait16<0>(vb);
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        zrB[m] = vb[m].x;
+        ziB[m] = vb[m].y;
+      }
+      frame_sync<T>();                         // both buffers read: free for the writes that follow
+      tail(zrA, ziA, xbA);
+      __builtin_amdgcn_sched_barrier(0);
+      twiddle(zrB, ziB);
+      dit_head<R, 1, 0, 16>(zrB, ziB);
+      tail(zrB, ziB, xbB);
+      if constexpr (i < NPASS - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        frame_sync<T>();                       // both streams' writes are in LDS
+      }
+    }
+  });
+}
+
+// One stream, the buffer-release barrier moved in front of the last butterfly stage (the single-stream counterpart of
+// stockham16_passes2s: the reads cannot hide under anything, but every wavefront reaches the barrier with its arithmetic
+// done).  Same operations in the same order as stockham16_passes.  Radix-16 passes only.
+template <int LOGM, int NT, class Tw1, class Hook>
+__device__ __forceinline__ void stockham16_passes1s(float (&zr)[16], float (&zi)[16], v2f32 *xb, unsigned t, const Tw1 &tw1row,
+                                                    const float (&twr)[NT], const float (&twi)[NT], Hook &&after_first_write) {
+  using C = Plan16<LOGM>;
+  constexpr int T = C::T, NPASS = C::NPASS, TW1 = 15;
+  static_assert(GLFER16_BARRIER_AFTER_READS != 0 && GLFER16_X0_ROWS != 0 && T >= 32 && T % 32 == 0 && !(GLFER_ABL & 7), "the product configuration");
+  static_for<0, NPASS>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int R = C::radix(i), Ls = C::ls(i);
+    static_assert(R == 16, "radix-16 passes");
+    auto tail = [&] {
+      if constexpr (i < NPASS - 1) {
+        const int k = (int)t & (Ls - 1);
+        const int a0 = ((int)t - k) * R + k;
+        constexpr bool kRows = i == 0;
+        v2f32 *wbase = kRows ? xb + t : xb + a0 + (a0 >> xpad_shift(i));
+        dit_tail<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
+          constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
+          wbase[kRows ? q * (T + 2) : xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
+        });
+      } else {
+        dit_tail<R, 1, 0, 16>(zr, zi, [](auto, auto) {});
+      }
+    };
+    if constexpr (i == 0) {
+      dit_head<R, 1, 0, 16>(zr, zi);
+      tail();
+      after_first_write();
+      __builtin_amdgcn_sched_barrier(0);
+      frame_sync<T>();                         // the writes are in LDS
+    } else {
+      v2f32 v[16];
+      if constexpr (i == 1) {
+        lds_read16_strided<T / 16>(xb + (t & 15) * (T + 2) + (t >> 4), v);
+      } else {
+        constexpr int STRIDE = xpad_offset(i - 1, T);
+        static_assert(15 * STRIDE * 8 < 65536 && xpad_offset(i - 1, 15 * T) == 15 * STRIDE, "one stride");
+        lds_read16_strided<STRIDE>(xb + t + (t >> xpad_shift(i - 1)), v);
+      }
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        zr[m] = v[m].x;
+        zi[m] = v[m].y;
+      }
+      if constexpr (i == 1) {
+        static_for<1, 16>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const v2f32 w = tw1row[q];
+          const float a = zr[q], c = zi[q];
+          zr[q] = __builtin_fmaf(a, w.x, -c * w.y);
+          zi[q] = __builtin_fmaf(a, w.y, c * w.x);
+        });
+      } else {
+        static_for<1, R>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          constexpr int e = C::tw_offset(i) - TW1 + (q - 1);
+          const float a = zr[q], c = zi[q];
+          zr[q] = __builtin_fmaf(a, twr[e], -c * twi[e]);
+          zi[q] = __builtin_fmaf(a, twi[e], c * twr[e]);
+        });
+      }
+      dit_head<R, 1, 0, 16>(zr, zi);
+      frame_sync<T>();                         // the buffer is read: free for the writes that follow (and for the caller after the last pass)
+      tail();
+      if constexpr (i < NPASS - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        frame_sync<T>();                       // the writes are in LDS
+      }
     }
   });
 }
