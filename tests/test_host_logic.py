@@ -28,7 +28,8 @@ def test_compat_library_exports_reference_entry_points():
     L = ctypes.CDLL(path)
     for sym in ("fft_init", "fft_do", "fft_psd", "fft_close", "mtm_init", "mtm_do", "mtm_close",
                 "hparma_init", "hparma_do", "hparma_close", "compute_floor", "init_avg", "alloc_avg", "delete_avg", "update_avg_plain",
-                "update_avg_sumextreme", "update_avg_sumavg", "lmp_init", "lmp_do", "lmp_close", "prepare_audio"):
+                "update_avg_sumextreme", "update_avg_sumavg", "lmp_init", "lmp_do", "lmp_close", "prepare_audio",
+                "open_wav_file", "wav_read", "close_wav_file", "glfer_compat_readahead", "glfer_compat_readahead_served"):   # wav_fmt.h:24-26 (round 3)
         assert hasattr(L, sym), sym
 
 
@@ -150,6 +151,85 @@ def test_wav_header_parse_fixed_width(lib, tmp_path):
     q.write_bytes(bytes(bad) + b"\0" * 64)
     with pytest.raises(lib.GlferHipError, match="bad argument"):
         lib.wav_probe(str(q))
+
+
+def _riff(chunks):
+    body = b"WAVE" + b"".join(cid + len(data).to_bytes(4, "little") + data + (b"\0" if len(data) & 1 else b"") for cid, data in chunks)
+    return b"RIFF" + len(body).to_bytes(4, "little") + body
+
+
+def test_wav_chunk_walk(lib, tmp_path):
+    """glfer_hip_wav_probe walks the RIFF chunks (round 3): LIST / fact chunks before and after `data`, an
+    18-byte fmt chunk, a data size field of 0 (a recording that was cut off), trailing bytes that are not a chunk
+    (the reference reads them as samples, wav_fmt.c:102) -- host code, no GPU."""
+    import struct
+    pcm = (np.arange(5000) % 2000 - 1000).astype(np.int16)
+    fmt = struct.pack("<HHIIHH", 1, 1, 8000, 16000, 2, 16)
+    plain = _riff([(b"fmt ", fmt), (b"data", pcm.tobytes())])
+    (tmp_path / "plain.wav").write_bytes(plain)
+    i = lib.wav_probe(str(tmp_path / "plain.wav"))
+    assert (i.data_offset, i.nsamples, i.sample_rate, i.bits_per_sample) == (44, 5000, 8000, 16)
+    listed = _riff([(b"fmt ", fmt + b"\0\0"), (b"LIST", b"INFOISFT" + (13).to_bytes(4, "little") + b"some encoder\0"),
+                    (b"fact", (5000).to_bytes(4, "little")), (b"data", pcm.tobytes()),
+                    (b"LIST", b"INFOICMT" + (6).to_bytes(4, "little") + b"after\0")])
+    (tmp_path / "listed.wav").write_bytes(listed)
+    i = lib.wav_probe(str(tmp_path / "listed.wav"))
+    assert i.nsamples == 5000 and i.data_offset == listed.index(b"data") + 8 and i.data_offset > 44
+    assert listed[i.data_offset:i.data_offset + 10000] == pcm.tobytes()
+    cut = bytearray(plain)
+    cut[40:44] = (0).to_bytes(4, "little")
+    (tmp_path / "cut.wav").write_bytes(bytes(cut))
+    assert lib.wav_probe(str(tmp_path / "cut.wav")).nsamples == 5000
+    (tmp_path / "stray.wav").write_bytes(plain + b"\x7f\x01\x02")          # not a chunk: samples, as the reference reads them
+    assert lib.wav_probe(str(tmp_path / "stray.wav")).data_bytes == 10003
+    (tmp_path / "nowave.wav").write_bytes(b"RIFF" + plain[4:8] + b"XXXX" + plain[12:])   # no WAVE tag: the fixed 44-byte layout
+    j = lib.wav_probe(str(tmp_path / "nowave.wav"))
+    assert (j.data_offset, j.nsamples) == (44, 5000)
+
+
+@pytest.mark.parametrize("bits", [16, 8])
+def test_exported_reader_follows_the_reference_reader(oracle, tmp_path, bits):
+    """open_wav_file / wav_read / close_wav_file as libglfer_compat.so exports them (round 3) against the oracle's
+    restatement of wav_fmt.c:45-141 -- itself bit-identical to the reference's own object (test_oracle_extras.py):
+    every block handed out, the short last block over the stale buffer, the estimator's mean removal in the
+    reader's buffer between reads.  Host code: no GPU is touched by the reader."""
+    import ctypes as C
+    import wave
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    compat = C.CDLL(os.path.join(root, "glfer_amd", "lib", "libglfer_compat.so"))
+    compat.open_wav_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    compat.wav_read.argtypes = [C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
+    rng = np.random.default_rng(3)
+    hop = 700
+    n = hop * 9 + 333
+    pcm = (rng.integers(-20000, 20000, n).astype(np.int16) if bits == 16 else rng.integers(0, 256, n).astype(np.uint8))
+    path = tmp_path / "r.wav"
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(bits // 8)
+        w.setframerate(11025)
+        w.writeframes(pcm.tobytes())
+
+    def mutate(block):                       # what prepare_audio does to the reader's buffer (fft.c:93-95)
+        block -= np.float32(block.mean())
+
+    want = oracle.wav_blocks(pcm, bits, hop, mutate=mutate)
+    speed = C.c_int(0)
+    compat.open_wav_file(os.fsencode(str(path)), hop, C.byref(speed))
+    assert speed.value == 11025
+    got = []
+    buf, nblk = C.POINTER(C.c_float)(), C.c_int(0)
+    while True:
+        compat.wav_read(C.byref(buf), C.byref(nblk))
+        if nblk.value == 0:
+            break
+        blk = np.ctypeslib.as_array(buf, shape=(hop,))
+        got.append(blk.copy())
+        mutate(blk)
+    compat.close_wav_file()
+    assert len(got) == len(want) == 10
+    for a, b in zip(got, want):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 def test_palettes_match_reference_tables(lib, oracle):
