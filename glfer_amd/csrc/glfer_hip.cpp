@@ -336,7 +336,7 @@ static size_t tap_slot(int n, int pair, int i, int which) {
 
 extern "C" {
 
-const char *glfer_hip_version(void) { return "glfer_hip 0.7 (gfx950; 16 points/lane Stockham radix-16 with LDS exchange: packed pairs, real-input and wavefront-private forms, shared odd taper, register reuse across overlapped frames, mean removal inside the kernels; N = 8..65536; periodogram, multitaper + F-test, HP-ARMA, LMP; wavefront floor, fused average, display map with the average taken inside it; two-stream ingest ring, multi-GPU host entry, kept scratch blocks)"; }
+const char *glfer_hip_version(void) { return "glfer_hip 0.7 (gfx950; 16 points/lane Stockham radix-16 with LDS exchange: packed pairs, real-input and wavefront-private forms, shared odd taper, register reuse across overlapped frames, mean removal inside the kernels; N = 8..1048576; periodogram, multitaper + F-test, HP-ARMA, LMP; wavefront floor, fused average, display map with the average taken inside it; two-stream ingest ring, multi-GPU host entry, kept scratch blocks)"; }
 
 int glfer_hip_palette(int palette, unsigned char colortab[768]) {
   if (!colortab) return GLFER_E_ARG;
@@ -616,9 +616,9 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   *out = nullptr;
   const int n = cfg->n;
   // any power of two the user can type (g_options.c:386-387): 8 .. 128 through spectro_small.hip,
-  // 256 .. 16384 through the 16-points-per-lane kernels, 32768 through spectro16w.hip alone, 65536
+  // 256 .. 16384 through the 16-points-per-lane kernels, 32768 through spectro16w.hip alone, 65536 .. 1048576
   // through spectro_big.hip (sub-transforms and combine as two kernels around a scratch in HBM)
-  if (!is_pow2(n) || n < 8 || n > 65536) return GLFER_E_ARG;
+  if (!is_pow2(n) || n < 8 || n > (1 << 20)) return GLFER_E_ARG;
   if (cfg->mode == GLFER_MODE_HPARMA && (n < 256 || n > 16384)) return GLFER_E_ARG;
   const bool small = n < 256, huge = n > 16384;
   if (!(cfg->overlap >= 0.0f) || !(cfg->overlap < 1.0f)) return GLFER_E_ARG;   // g_options.c:1030
@@ -1016,6 +1016,7 @@ static hipError_t launch_wave_private(const SpectroParams &sp, int n, hipStream_
     case 32768: return (sp.spec || form_override() == 'w') ? glfer_launch_spectro16w_n15(&sp, st) : glfer_launch_spectro_big(&sp, n, st);
     case 65536: return glfer_launch_spectro_big(&sp, n, st);
   }
+  if (n >= 131072 && n <= (1 << 20)) return glfer_launch_spectro_big(&sp, n, st);   // two-level combine (round 3)
   return hipErrorInvalidValue;
 }
 

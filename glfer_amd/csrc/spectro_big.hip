@@ -215,6 +215,98 @@ __global__ __launch_bounds__(64) void combine_kernel(SpectroParams p, int ntap, 
   }
 }
 
+// ---- N >= 131072 (W = N/2048 >= 64 sub-transforms per frame and taper): the W-point transforms over w no longer fit
+// a lane's registers, so the combine is cut once more, decimation in time, W = 32 W1:
+//     Z[k1 + 1024 (k2a + 32 k2b)] = sum_{w1 < W1} W_W1^(w1 k2b) * { W_W^(w1 k2a) * sum_{w2 < 32} c[W1 w2 + w1][k1] W_32^(w2 k2a) }
+// with c[w][k1] = W_M^(w k1) A_w[k1] what subfft_kernel leaves in the scratch.
+//   combine1_kernel : one lane per (frame, taper, w1, k1): the radix-32 transform over w2 in registers, times
+//                     W_W^(w1 k2a), out to a second scratch D[frame][taper][w1][k2a][k1]
+//   combine2_kernel : one lane per (frame, k2a, bin pair k1 / 1024 - k1): the radix-W1 transforms over w1 of the lane's
+//                     column and of its mirror partner's, the real-input split, |X|^2 summed over the tapers, rows out
+// Very-slow-CW sizes (a 131072-point block is 16 s of audio at 8 kHz): a correct path, not a tuned one.
+__global__ __launch_bounds__(64) void combine1_kernel(int W, int W1, const v2f32 *__restrict__ S, v2f32 *__restrict__ D) {
+  const int k1 = blockIdx.x * 64 + threadIdx.x;                  // 0 .. 1023
+  const int w1 = blockIdx.y;
+  const size_t ft = blockIdx.z;                                  // frame * ntap + taper
+  float ar[32], ai[32];
+#pragma unroll
+  for (int w2 = 0; w2 < 32; w2++) {
+    const v2f32 a = S[(ft * W + (size_t)(W1 * w2 + w1)) * 1024 + k1];
+    ar[w2] = a.x;
+    ai[w2] = a.y;
+  }
+  dit<32, 1, 0, 32>(ar, ai);                                     // the sum over w2 for k2a sits at index brev(k2a, 32)
+  v2f32 *o = D + ((ft * W1 + w1) * 32) * 1024 + k1;
+  static_for<0, 32>([&](auto kc) {
+    constexpr int k2a = decltype(kc)::value;
+    constexpr int r = brev(k2a, 32);
+    float sn, cs;
+    sincospif(-2.0f * (float)(w1 * k2a) / (float)W, &sn, &cs);   // W_W^(w1 k2a); w1 k2a < W: no reduction needed
+    o[(size_t)k2a * 1024] = v2f32{__builtin_fmaf(ar[r], cs, -ai[r] * sn), __builtin_fmaf(ar[r], sn, ai[r] * cs)};
+  });
+}
+
+template <int W1>
+__global__ __launch_bounds__(64) void combine2_kernel(SpectroParams p, int ntap, long long f0, int nf,
+                                                      const v2f32 *__restrict__ D) {
+  constexpr int W = 32 * W1;
+  const long long M = 1024LL * W;
+  const int k1 = blockIdx.x * 64 + threadIdx.x;
+  const int k2a = blockIdx.y;
+  const long long fr = blockIdx.z;
+  if (fr >= nf || k1 > 512) return;
+  // the mirror partner of k = k1 + 1024 k2 is M - k = (1024 - k1) + 1024 (W - 1 - k2): column (31 - k2a) of item
+  // 1024 - k1, index W1 - 1 - k2b; for k1 = 0 it is 1024 (W - k2): column (32 - k2a) mod 32 of item 0, index
+  // W1 - 1 - k2b (k2a > 0) or (W1 - k2b) mod W1 (k2a = 0)
+  const int k1m = (1024 - k1) & 1023;
+  const int k2am = k1 == 0 ? ((32 - k2a) & 31) : 31 - k2a;
+  const bool selfcol = k1 == 0 && k2a == 0;
+  float acc[2 * W1];
+#pragma unroll
+  for (int i = 0; i < 2 * W1; i++) acc[i] = 0.0f;
+  float c0, s0;                                                  // (cos, sin)(2 pi (k1 + 1024 k2a) / N), N = 2M
+  {
+    float sn, cs;
+    sincospif((float)(k1 + 1024 * k2a) / (float)M, &sn, &cs);
+    c0 = cs;
+    s0 = sn;
+  }
+  for (int j = 0; j < ntap; j++) {
+    const v2f32 *Dj = D + (((size_t)fr * ntap + j) * W1) * 32 * 1024;
+    float ar[W1], ai[W1], br[W1], bi[W1];
+#pragma unroll
+    for (int w1 = 0; w1 < W1; w1++) {
+      const v2f32 a = Dj[((size_t)w1 * 32 + k2a) * 1024 + k1], b = Dj[((size_t)w1 * 32 + k2am) * 1024 + k1m];
+      ar[w1] = a.x; ai[w1] = a.y; br[w1] = b.x; bi[w1] = b.y;
+    }
+    dit<W1, 1, 0, W1>(ar, ai);                                   // Z[k1 + 1024 (k2a + 32 k2b)] at index brev(k2b, W1)
+    dit<W1, 1, 0, W1>(br, bi);                                   // the partner column, likewise
+    static_for<0, W1>([&](auto kc) {
+      constexpr int k2b = decltype(kc)::value;
+      constexpr int ia = brev(k2b, W1), ib = brev(W1 - 1 - k2b, W1), ic = brev((W1 - k2b) % W1, W1);
+      const float qr = selfcol ? ar[ic] : br[ib], qi = selfcol ? ai[ic] : bi[ib];
+      const float er = ar[ia] + qr, ei = ai[ia] - qi, orr = ar[ia] - qr, oi = ai[ia] + qi;
+      constexpr cplx64 uu = unit_root(k2b, 2 * W1);              // (cos, sin)(2 pi 1024 * 32 k2b / N)
+      constexpr float cm = (float)uu.c, sm = (float)uu.s;
+      const float c = __builtin_fmaf(c0, cm, -s0 * sm), s = __builtin_fmaf(s0, cm, c0 * sm);
+      const float pr = __builtin_fmaf(c, oi, -s * orr), pi = -__builtin_fmaf(c, orr, s * oi);
+      const float x1r = er + pr, x1i = ei + pi, x2r = er - pr, x2i = ei - pi;
+      acc[2 * k2b] = __builtin_fmaf(x1r, x1r, __builtin_fmaf(x1i, x1i, acc[2 * k2b]));
+      acc[2 * k2b + 1] = __builtin_fmaf(x2r, x2r, __builtin_fmaf(x2i, x2i, acc[2 * k2b + 1]));
+    });
+  }
+  float *o = p.psd + (size_t)(f0 + fr) * (size_t)(M + 1);
+#pragma unroll
+  for (int k2b = 0; k2b < W1; k2b++) {
+    const long long k = k1 + 1024LL * (k2a + 32 * k2b);
+    o[k] = acc[2 * k2b];
+    // the mirrored bin M - k: for 0 < k1 < 512 nobody else computes it.  For k1 = 0 and k1 = 512 it is another lane's
+    // bin k (another k2a), computed there in another operation order -- one writer per bin, or a row's last bits would
+    // depend on which lane stores last; only bin M (the mirror of bin 0) has no lane of its own.
+    if ((k1 > 0 && k1 < 512) || k == 0) o[M - k] = acc[2 * k2b + 1];
+  }
+}
+
 }  // namespace glfer
 
 using namespace glfer;
@@ -226,17 +318,27 @@ void scratch_free(void *p, hipStream_t st);
 
 // frames [p->frame0 .. +nframes) in groups that keep the scratch under ~512 MiB; p->psd is row 0 of the launch
 extern "C" hipError_t glfer_launch_spectro_big(const SpectroParams *p, int n, hipStream_t st) {
-  if ((n != 65536 && n != 32768) || !p->wtaps || !p->wtw || !p->bigtw || p->spec) return hipErrorInvalidValue;
+  if (n < 32768 || n > (1 << 20) || (n & (n - 1)) || !p->wtaps || !p->wtw || !p->bigtw || p->spec) return hipErrorInvalidValue;
   if (p->nframes <= 0) return hipSuccess;
   const int W = n / 2048;
+  const bool two_level = W > 32;                                 // N >= 131072: combine1 + combine2 around a second scratch
+  const int W1 = two_level ? W / 32 : 1;
   const int ntap = p->wtapers > 0 ? p->wtapers : 1;
   const size_t per_frame = (size_t)ntap * W * 1024 * sizeof(v2f32);
   long long group = (long long)(((size_t)512 << 20) / per_frame);
   if (group < 1) group = 1;
   if (group > p->nframes) group = p->nframes;
-  v2f32 *scratch = nullptr;
+  if (two_level && group > 65535 / ntap) group = 65535 / ntap;   // (grid.z of combine1)
+  v2f32 *scratch = nullptr, *scratch2 = nullptr;
   hipError_t e = glfer::scratch_malloc((void **)&scratch, (size_t)group * per_frame, st);
   if (e != hipSuccess) return e;
+  if (two_level) {
+    e = glfer::scratch_malloc((void **)&scratch2, (size_t)group * per_frame, st);
+    if (e != hipSuccess) {
+      glfer::scratch_free(scratch, st);
+      return e;
+    }
+  }
   for (long long f0 = 0; f0 < p->nframes && e == hipSuccess; f0 += group) {
     const int nf = (int)((p->nframes - f0 < group) ? p->nframes - f0 : group);
     const long long blocks = ((long long)nf * ntap * W + 3) / 4;
@@ -248,12 +350,27 @@ extern "C" hipError_t glfer_launch_spectro_big(const SpectroParams *p, int n, hi
       default: e = hipErrorInvalidValue;
     }
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) {
+    if (e == hipSuccess && two_level) {
+      hipLaunchKernelGGL(combine1_kernel, dim3(16, (unsigned)W1, (unsigned)(nf * ntap)), dim3(64), 0, st, W, W1, scratch, scratch2);
+      e = hipGetLastError();
+      if (e == hipSuccess) {
+        const dim3 g2(9, 32, (unsigned)nf);
+        switch (W1) {
+          case 2: hipLaunchKernelGGL(combine2_kernel<2>, g2, dim3(64), 0, st, *p, ntap, f0, nf, scratch2); break;
+          case 4: hipLaunchKernelGGL(combine2_kernel<4>, g2, dim3(64), 0, st, *p, ntap, f0, nf, scratch2); break;
+          case 8: hipLaunchKernelGGL(combine2_kernel<8>, g2, dim3(64), 0, st, *p, ntap, f0, nf, scratch2); break;
+          case 16: hipLaunchKernelGGL(combine2_kernel<16>, g2, dim3(64), 0, st, *p, ntap, f0, nf, scratch2); break;
+          default: e = hipErrorInvalidValue;
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+      }
+    } else if (e == hipSuccess) {
       if (W == 32) hipLaunchKernelGGL(combine_kernel<32>, dim3(9, (unsigned)nf), dim3(64), 0, st, *p, ntap, f0, nf, scratch);
       else hipLaunchKernelGGL(combine_kernel<16>, dim3(9, (unsigned)nf), dim3(64), 0, st, *p, ntap, f0, nf, scratch);
       e = hipGetLastError();
     }
   }
   glfer::scratch_free(scratch, st);
+  if (scratch2) glfer::scratch_free(scratch2, st);
   return e;
 }
