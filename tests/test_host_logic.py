@@ -94,7 +94,7 @@ def test_dpss_matches_reference_algorithm(lib, oracle, n, kmax, nw):
 
 def test_argument_errors(lib):
     api = lib.api
-    for bad in (dict(n=1000), dict(n=4), dict(n=131072), dict(n=1 << 20), dict(overlap=1.0), dict(overlap=-0.1), dict(window_type=9)):
+    for bad in (dict(n=1000), dict(n=4), dict(n=1 << 21), dict(n=1 << 24), dict(overlap=1.0), dict(overlap=-0.1), dict(window_type=9)):
         kw = dict(n=1024, overlap=0.0, window_type=0)
         kw.update(bad)
         with pytest.raises(api.GlferHipError, match="bad argument"):
