@@ -61,14 +61,17 @@ __device__ __forceinline__ float cvt_sample(const void *ubase, unsigned elem_off
 
 // Range-checked buffer load of one sample (raw buffer: out-of-range offsets read 0): one shared
 // VGPR byte offset + an SGPR/immediate offset, so gathering a frame costs no address VALU.
+#ifndef GLFER_X_LOAD_AUX
+#define GLFER_X_LOAD_AUX 0        /* cache policy of the sample loads (A/B builds: 2 = non-temporal) */
+#endif
 template <int FMT>
 __device__ __forceinline__ float buf_sample(__amdgpu_buffer_rsrc_t rsrc, unsigned voff_bytes, unsigned soff_bytes) {
   if constexpr (FMT == GLFER_FMT_F32) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, soff_bytes, 0));
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, soff_bytes, GLFER_X_LOAD_AUX));
   } else if constexpr (FMT == GLFER_FMT_S16) {
-    return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff_bytes, soff_bytes, 0) / 32768.0f;
+    return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff_bytes, soff_bytes, GLFER_X_LOAD_AUX) / 32768.0f;
   } else {
-    return ((float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsrc, voff_bytes, soff_bytes, 0) - 128.0f) / 128.0f;
+    return ((float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsrc, voff_bytes, soff_bytes, GLFER_X_LOAD_AUX) - 128.0f) / 128.0f;
   }
 }
 
