@@ -44,6 +44,11 @@
 #ifndef GLFER16H_PREFETCH_TOP
 #define GLFER16H_PREFETCH_TOP 0    /* 1: next frame's samples requested at the top of the iteration, not after exchange 0's writes */
 #endif
+#ifndef GLFER16H_TW1_REGS
+#define GLFER16H_TW1_REGS (GLFER_LOGN_OR(12) != 13)   /* the lane's 15 pass-1 twiddles in registers instead of 15 LDS reads per transform: the compiler still
+                                     fits three wavefronts per SIMD (168 VGPRs, no spill at N = 4096); N = 512 +3.5 %, 1024 +-0, 2048 +1 %, 4096 +0.4...2 % (C2 +2.5 %),
+                                     16384 +2...4 %; N = 8192 (window in registers there) spills and loses 7 %: off -- profiles/r03_h_tw1_regs.txt */
+#endif
 #ifndef GLFER16H_PREFETCH2
 #define GLFER16H_PREFETCH2 0        /* 1: register-reuse forms (SHIFT 4 / 8, no mean removal): a frame's new pairs are requested TWO frames ahead, into landing registers */
 #endif
@@ -180,6 +185,11 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   }
   __syncthreads();
   const v2f32 *tw1row = tw1 + (t & 15) * 17;
+  v2f32 tw1reg[16];
+  if constexpr (GLFER16H_TW1_REGS != 0) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) tw1reg[q] = tw1row[q];
+  }
 
   v2f32 px[16];
   // The launcher hands this kernel only frames that lie wholly inside the stream
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       if (has_next && last) prefetch_next(rel_of(it + 1), rotc);   // px is free as soon as xs is formed
     }
 
-    stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1row, twr, twi, [&] {
+    auto pass_hook = [&] {
       if constexpr (GLFER_H_ABL & 2) {                 // timing ablation: no sample loads after the first frame
 #pragma unroll
         for (int m = 0; m < 16; m++) px[m] = px[m] * 0.999f;
@@ -444,7 +454,9 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
         } else
         if (has_next && last) prefetch_next(rel_of(it + 1), rotc);   // the frame's last use of px is behind us
       }
-    });
+    };
+    if constexpr (GLFER16H_TW1_REGS != 0) stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1reg, twr, twi, pass_hook);
+    else stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1row, twr, twi, pass_hook);
 
     // ---- mirror step: Z[k], k >= M/2, through LDS (entry u = k - M/2)
     frame_sync<T>();

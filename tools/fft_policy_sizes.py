@@ -8,7 +8,7 @@ import glfer_amd.api as A
 if os.environ.get("GLFER_LIB_PATH"):
     A.LIB_PATH = os.environ["GLFER_LIB_PATH"]
 tag = os.path.basename(os.path.dirname(os.environ.get("GLFER_LIB_PATH", "x/product/lib")))
-for n in (4096, 8192, 16384):
+for n in [int(v) for v in os.environ.get("GLFER_SIZES", "4096,8192,16384").split(",")]:
     for overlap in (0.0, 0.5, 0.75):
         hop = int(n * (1 - overlap))
         frames = (1 << 29) // hop
