@@ -38,6 +38,10 @@
 #endif
 #endif
 
+#ifndef GLFER16_TW1_REGS
+#define GLFER16_TW1_REGS 1
+#endif
+
 namespace glfer {
 
 // One kernel, persistent blocks.  The work of a block is a flat sequence of ROUNDS
@@ -101,7 +105,11 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
     }
   }
   __syncthreads();
-  const v2f32 *tw1row = tw1 + (t & 15) * 17;
+  // the lane's pass-1 twiddles: a row of the LDS table, or 32 registers where the form has them to spare (two wavefronts
+  // per SIMD: N = 1024 / 2048, and N = 256 outside the generic-window form) -- profiles/r03_tw1_regs_other_kernels.txt
+  constexpr bool TW1R = (GLFER16_TW1_REGS) != 0 && (LOGN == 10 || LOGN == 11 || (LOGN == 8 && !GEN));
+  Tw1Source<TW1R> tw1row;
+  tw1row.init(tw1 + (t & 15) * 17);
 
   const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(p.taps), 0, p.npairs * 2 * N * 4, 0x00020000);

@@ -64,6 +64,10 @@
 #define W_STAMP(T, id)
 #endif
 
+#ifndef GLFER16W_TW1_REGS
+#define GLFER16W_TW1_REGS 1
+#endif
+
 namespace glfer {
 
 template <int LOGN>
@@ -174,7 +178,11 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
     load_window(0);
   }
   __syncthreads();
-  const v2f32 *tw1row = tw1 + (t & 15) * 17;
+  // the lane's pass-1 twiddles: a row of the LDS table, or 32 registers in the two-wavefronts-per-SIMD forms that hold them
+  // without spilling (profiles/r03_tw1_regs_other_kernels.txt: +3.9 % on N = 16384, 9 tapers)
+  constexpr bool TW1R = (GLFER16W_TW1_REGS) != 0 && WPS == 2 && LOGN <= 14 && !(LOGN >= 13 && KM != 0) && !(LOGN == 14 && HIST != 0);
+  Tw1Source<TW1R> tw1row;
+  tw1row.init(tw1 + (t & 15) * 17);
 
   // ---- samples: z index n = W*(t + 64 m) + w, the pair (y[2n], y[2n+1]) with one load.  The
   // launcher hands this kernel only frames that lie wholly inside the stream.

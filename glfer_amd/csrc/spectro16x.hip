@@ -26,6 +26,10 @@
 #define GLFER16X_WAVES_PER_SIMD 3
 #endif
 
+#ifndef GLFER16X_TW1_REGS
+#define GLFER16X_TW1_REGS 0
+#endif
+
 namespace glfer {
 
 template <int LOGN>
@@ -80,7 +84,8 @@ __global__ __launch_bounds__(LaunchX<LOGN>::BLOCK, WPS) void spectro16x_kernel(S
     if constexpr (NTWR == 0) twr[0] = twi[0] = 0.0f;
   }
   __syncthreads();
-  const v2f32 *tw1row = tw1 + (t & 15) * 17;
+  Tw1Source<(GLFER16X_TW1_REGS) != 0> tw1row;                   // the lane's pass-1 twiddles: a row of the LDS table, or registers
+  tw1row.init(tw1 + (t & 15) * 17);
 
   const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(p.taps), 0, p.npairs * 2 * N * 4, 0x00020000);

@@ -18,6 +18,10 @@
 #include <stdint.h>
 #include "odd_taper.hpp"
 
+#ifndef GLFER16XL_TW1_REGS
+#define GLFER16XL_TW1_REGS 1
+#endif
+
 namespace glfer {
 hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);   // plan.h / glfer_hip.cpp: once per device, kernel and size class
 }
@@ -81,7 +85,11 @@ __global__ __launch_bounds__(256, 2) void spectro16xl_kernel(SpectroParams p) {
     if constexpr (NTWR == 0) twr[0] = twi[0] = 0.0f;
   }
   __syncthreads();
-  const v2f32 *tw1row = tw1 + (t & 15) * 17;
+  // the lane's pass-1 twiddles: a row of the LDS table, or 32 registers (N >= 1024, where the kernel is at two wavefronts
+  // per SIMD anyway; below, the registers would cost the third wavefront) -- profiles/r03_tw1_regs_other_kernels.txt
+  constexpr bool TW1R = (GLFER16XL_TW1_REGS) != 0 && LOGN >= 10;
+  Tw1Source<TW1R> tw1row;
+  tw1row.init(tw1 + (t & 15) * 17);
   const long long stride = (long long)gridDim.x * (2 * FPB);
 
   auto load_x = [&](float (&dst)[16], long long fblk) {

@@ -172,6 +172,26 @@ __device__ __forceinline__ void lds_wait16(v2f32 (&v)[16]) {
                : "memory");
 }
 
+// The lane's pass-1 twiddles as the passes take them (tw1[q], q = 1..15, q a compile-time constant): a row of the
+// shared LDS table, or -- REGS -- the lane's own 30 registers (15 fewer ds_read_b64 per transform; worth 1-3 % where
+// the kernel's occupancy survives the registers: profiles/r03_y_tw1_regs.txt, r03_h_tw1_regs.txt).
+template <bool REGS>
+struct Tw1Source {
+  v2f32 r[REGS ? 16 : 1];
+  const v2f32 *row;
+  __device__ __forceinline__ void init(const v2f32 *tw1row) {
+    row = tw1row;
+    if constexpr (REGS) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) r[q] = tw1row[q];
+    }
+  }
+  __device__ __forceinline__ v2f32 operator[](int q) const {
+    if constexpr (REGS) return r[q];
+    else return row[q];
+  }
+};
+
 // The Stockham passes of one complex 2^LOGM-point transform held 16 points per lane
 // (lane t of T = 2^LOGM/16: points t + T*m on entry; on exit register b + B*brev(q',R) holds
 // bin t + T*(b + B*q'), R = last radix, B = 16/R).  xb: this frame's exchange buffer
