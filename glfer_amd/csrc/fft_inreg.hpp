@@ -115,6 +115,56 @@ __device__ __forceinline__ void dit(float (&re)[LEN], float (&im)[LEN]) {
   }
 }
 
+// ---- the inter-pass twiddles folded into the first butterfly stage ----
+// A Stockham pass multiplies its inputs by twiddles T_m and then runs dit<R>.  The first stage's butterflies have w = 1
+// (pairs m, m + 8S', four operations each) on inputs that cost four operations each to twiddle: 12 per pair.  Folded,
+//     a' = T_a a (4; none when T_a = 1)      X = a' + T_b b (4 fma)      X' = 2a' - X (2 fma)
+// the pair costs 10 (6 with T_a = 1): 16 operations fewer per lane and twiddled pass, and one rounding fewer on X.
+// tw(integral_constant<int, m>) returns register m's twiddle as a v2f32, or NoTwiddle.
+struct NoTwiddle {};
+
+template <int R, int S, int OFF, int LEN, class TW>
+__device__ __forceinline__ void dit_tw(float (&re)[LEN], float (&im)[LEN], const TW &tw) {
+  if constexpr (R == 2) {
+    constexpr int PA = OFF, PB = OFF + S;
+    const auto wa = tw(std::integral_constant<int, PA>{});
+    const auto wb = tw(std::integral_constant<int, PB>{});
+    float ar = re[PA], ai = im[PA];
+    if constexpr (!std::is_same_v<std::decay_t<decltype(wa)>, NoTwiddle>) {
+      const float r0 = ar, i0 = ai;
+      ar = __builtin_fmaf(r0, wa.x, -i0 * wa.y);
+      ai = __builtin_fmaf(r0, wa.y, i0 * wa.x);
+    }
+    const float br = re[PB], bi = im[PB];
+    if constexpr (!std::is_same_v<std::decay_t<decltype(wb)>, NoTwiddle>) {
+      const float xr = __builtin_fmaf(br, wb.x, __builtin_fmaf(-bi, wb.y, ar));
+      const float xi = __builtin_fmaf(br, wb.y, __builtin_fmaf(bi, wb.x, ai));
+      re[PA] = xr; im[PA] = xi;
+      re[PB] = __builtin_fmaf(2.0f, ar, -xr);
+      im[PB] = __builtin_fmaf(2.0f, ai, -xi);
+    } else {
+      re[PA] = ar + br; im[PA] = ai + bi;
+      re[PB] = ar - br; im[PB] = ai - bi;
+    }
+  } else if constexpr (R > 2) {
+    dit_tw<R / 2, 2 * S, OFF, LEN>(re, im, tw);
+    dit_tw<R / 2, 2 * S, OFF + S, LEN>(re, im, tw);
+    static_for<0, R / 2>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int pa = OFF + 2 * S * brev(k, R / 2);
+      bfly<R, k, pa, pa + S, LEN>(re, im);
+      if constexpr (GLFER_BFLY_GROUP > 0 && (k % GLFER_BFLY_GROUP) == GLFER_BFLY_GROUP - 1)
+        __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+}
+template <int R, int S, int OFF, int LEN, class TW>
+__device__ __forceinline__ void dit_head_tw(float (&re)[LEN], float (&im)[LEN], const TW &tw) {
+  static_assert(R >= 4, "radix");
+  dit_tw<R / 2, 2 * S, OFF, LEN>(re, im, tw);
+  dit_tw<R / 2, 2 * S, OFF + S, LEN>(re, im, tw);
+}
+
 // dit<R,...> whose LAST stage hands every finished output to emit(k, reg) -- X[k] sits in register
 // reg -- as soon as its butterfly is done (two outputs per butterfly: k and k + R/2), so that the
 // consumer (an LDS store) is issued between butterflies instead of in one burst after the transform.

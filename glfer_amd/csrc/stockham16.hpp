@@ -14,6 +14,10 @@
 #endif
 // 1: the barrier that frees the exchange buffer sits right after an exchange's reads; 0: in front
 // of the next exchange's writes
+// inter-pass twiddles folded into the first butterfly stage (fft_inreg.hpp: dit_tw)
+#ifndef GLFER16_FOLD_TW
+#define GLFER16_FOLD_TW 1
+#endif
 #ifndef GLFER16_BARRIER_AFTER_READS
 #define GLFER16_BARRIER_AFTER_READS 1
 #endif
@@ -192,6 +196,26 @@ struct Tw1Source {
   }
 };
 
+// pass I's input twiddles by register index, for dit_tw: none in pass 0 and on a sub-transform's element 0
+template <class C, int I, int NT, class Tw1>
+struct PassTwiddles {
+  const Tw1 &tw1row;
+  const float (&twr)[NT];
+  const float (&twi)[NT];
+  template <int M>
+  __device__ __forceinline__ auto operator()(std::integral_constant<int, M>) const {
+    constexpr int R = C::radix(I), B = 16 / R, b = M % B, q = M / B;
+    if constexpr (I == 0 || q == 0) {
+      return NoTwiddle{};
+    } else if constexpr (I == 1) {
+      return tw1row[M];
+    } else {
+      constexpr int e = C::tw_offset(I) - 15 + b * (R - 1) + (q - 1);
+      return v2f32{twr[e], twi[e]};
+    }
+  }
+};
+
 // The Stockham passes of one complex 2^LOGM-point transform held 16 points per lane
 // (lane t of T = 2^LOGM/16: points t + T*m on entry; on exit register b + B*brev(q',R) holds
 // bin t + T*(b + B*q'), R = last radix, B = 16/R).  xb: this frame's exchange buffer
@@ -207,7 +231,10 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
   static_for<0, NPASS>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     constexpr int R = C::radix(i), Ls = C::ls(i), B = 16 / R;
-    if constexpr (i == 1) {
+    constexpr bool kFold = GLFER16_FOLD_TW != 0 && i > 0;
+    const PassTwiddles<C, i, NT, Tw1> twf{tw1row, twr, twi};
+    if constexpr (kFold) {
+    } else if constexpr (i == 1) {
       static_for<1, 16>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const v2f32 w = tw1row[q];
@@ -236,14 +263,17 @@ __device__ __forceinline__ void stockham16_passes(float (&zr)[16], float (&zi)[1
       const int a0 = ((int)t - k) * R + k;
       constexpr bool kRows = GLFER16_X0_ROWS != 0 && i == 0 && T >= 32;
       v2f32 *wbase = kRows ? xb + t : xb + a0 + (a0 >> xpad_shift(i));
-      dit_emit<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
+      if constexpr (kFold) dit_head_tw<R, 1, 0, 16>(zr, zi, twf);
+      else dit_head<R, 1, 0, 16>(zr, zi);
+      dit_tail<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
         constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
         if constexpr (!(GLFER_ABL & 2)) wbase[kRows ? q * (T + 2) : xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
       });
     } else {
       static_for<0, B>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
-        dit<R, B, b, 16>(zr, zi);
+        if constexpr (kFold) dit_tw<R, B, b, 16>(zr, zi, twf);
+        else dit<R, B, b, 16>(zr, zi);
       });
     }
     GLFER_STAMP(4 * i + 1);                // pass i butterflies done
@@ -329,8 +359,11 @@ __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA
   static_for<0, NPASS>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     constexpr int R = C::radix(i), Ls = C::ls(i), B = 16 / R;
+    constexpr bool kFold = GLFER16_FOLD_TW != 0 && i > 0;
+    const PassTwiddles<C, i, NT, Tw1> twf{tw1row, twr, twi};
     auto compute = [&](float (&zr)[16], float (&zi)[16], v2f32 *xb) {
-      if constexpr (i == 1) {
+      if constexpr (kFold) {
+      } else if constexpr (i == 1) {
         static_for<1, 16>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
           const v2f32 w = tw1row[q];
@@ -357,14 +390,17 @@ __device__ __forceinline__ void stockham16_passes2(float (&zrA)[16], float (&ziA
         const int a0 = ((int)t - k) * R + k;
         constexpr bool kRows = GLFER16_X0_ROWS != 0 && i == 0 && T >= 32;
         v2f32 *wbase = kRows ? xb + t : xb + a0 + (a0 >> xpad_shift(i));
-        dit_emit<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
+        if constexpr (kFold) dit_head_tw<R, 1, 0, 16>(zr, zi, twf);
+        else dit_head<R, 1, 0, 16>(zr, zi);
+        dit_tail<R, 1, 0, 16>(zr, zi, [&](auto qc, auto rc) {
           constexpr int q = decltype(qc)::value, reg = decltype(rc)::value;
           if constexpr (!(GLFER_ABL & 2)) wbase[kRows ? q * (T + 2) : xpad_offset(i, q * Ls)] = v2f32{zr[reg], zi[reg]};
         });
       } else {
         static_for<0, B>([&](auto bc) {
           constexpr int b = decltype(bc)::value;
-          dit<R, B, b, 16>(zr, zi);
+          if constexpr (kFold) dit_tw<R, B, b, 16>(zr, zi, twf);
+          else dit<R, B, b, 16>(zr, zi);
         });
       }
     };
@@ -444,8 +480,12 @@ __device__ __forceinline__ void stockham16_passes2s(float (&zrA)[16], float (&zi
     constexpr int i = decltype(ic)::value;
     constexpr int R = C::radix(i), Ls = C::ls(i);
     static_assert(R == 16, "radix-16 passes");
+    constexpr bool kFold = GLFER16_FOLD_TW != 0 && i > 0;
+    const PassTwiddles<C, i, NT, Tw1> twf{tw1row, twr, twi};
     auto twiddle = [&](float (&zr)[16], float (&zi)[16]) {
-      if constexpr (i == 1) {
+      if constexpr (kFold) {
+        dit_head_tw<R, 1, 0, 16>(zr, zi, twf);
+      } else if constexpr (i == 1) {
         static_for<1, 16>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
           const v2f32 w = tw1row[q];
@@ -462,6 +502,7 @@ __device__ __forceinline__ void stockham16_passes2s(float (&zrA)[16], float (&zi
           zi[q] = __builtin_fmaf(a, twi[e], c * twr[e]);
         });
       }
+      if constexpr (!kFold) dit_head<R, 1, 0, 16>(zr, zi);
     };
     // the last stage: with the exchange writes (a pass that an exchange follows) or plain
     auto tail = [&](float (&zr)[16], float (&zi)[16], v2f32 *xb) {
@@ -506,8 +547,7 @@ __device__ __forceinline__ void stockham16_passes2s(float (&zrA)[16], float (&zi
         zrA[m] = va[m].x;
         ziA[m] = va[m].y;
       }
-      twiddle(zrA, ziA);
-      dit_head<R, 1, 0, 16>(zrA, ziA);
+      twiddle(zrA, ziA);                       // and every butterfly stage but the last
       lds_wait16<0>(vb);
 #pragma unroll
       for (int m = 0; m < 16; m++) {
@@ -518,7 +558,6 @@ __device__ __forceinline__ void stockham16_passes2s(float (&zrA)[16], float (&zi
       tail(zrA, ziA, xbA);
       __builtin_amdgcn_sched_barrier(0);
       twiddle(zrB, ziB);
-      dit_head<R, 1, 0, 16>(zrB, ziB);
       tail(zrB, ziB, xbB);
       if constexpr (i < NPASS - 1) {
         __builtin_amdgcn_sched_barrier(0);
@@ -575,24 +614,29 @@ __device__ __forceinline__ void stockham16_passes1s(float (&zr)[16], float (&zi)
         zr[m] = v[m].x;
         zi[m] = v[m].y;
       }
-      if constexpr (i == 1) {
-        static_for<1, 16>([&](auto qc) {
-          constexpr int q = decltype(qc)::value;
-          const v2f32 w = tw1row[q];
-          const float a = zr[q], c = zi[q];
-          zr[q] = __builtin_fmaf(a, w.x, -c * w.y);
-          zi[q] = __builtin_fmaf(a, w.y, c * w.x);
-        });
+      if constexpr (GLFER16_FOLD_TW != 0) {
+        const PassTwiddles<C, i, NT, Tw1> twf{tw1row, twr, twi};
+        dit_head_tw<R, 1, 0, 16>(zr, zi, twf);
       } else {
-        static_for<1, R>([&](auto qc) {
-          constexpr int q = decltype(qc)::value;
-          constexpr int e = C::tw_offset(i) - TW1 + (q - 1);
-          const float a = zr[q], c = zi[q];
-          zr[q] = __builtin_fmaf(a, twr[e], -c * twi[e]);
-          zi[q] = __builtin_fmaf(a, twi[e], c * twr[e]);
-        });
+        if constexpr (i == 1) {
+          static_for<1, 16>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const v2f32 w = tw1row[q];
+            const float a = zr[q], c = zi[q];
+            zr[q] = __builtin_fmaf(a, w.x, -c * w.y);
+            zi[q] = __builtin_fmaf(a, w.y, c * w.x);
+          });
+        } else {
+          static_for<1, R>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int e = C::tw_offset(i) - TW1 + (q - 1);
+            const float a = zr[q], c = zi[q];
+            zr[q] = __builtin_fmaf(a, twr[e], -c * twi[e]);
+            zi[q] = __builtin_fmaf(a, twi[e], c * twr[e]);
+          });
+        }
+        dit_head<R, 1, 0, 16>(zr, zi);
       }
-      dit_head<R, 1, 0, 16>(zr, zi);
       frame_sync<T>();                         // the buffer is read: free for the writes that follow (and for the caller after the last pass)
       tail();
       if constexpr (i < NPASS - 1) {
