@@ -185,8 +185,11 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   }
   __syncthreads();
   const v2f32 *tw1row = tw1 + (t & 15) * 17;
+  // (integer samples at 75 % overlap: the registers push the three-wavefront form over its 168 and the 2-4 spilled dwords cost
+  // 4-6 %: the LDS row there -- profiles/r03_h_tw1_regs.txt)
+  constexpr bool TW1R = GLFER16H_TW1_REGS != 0 && !(FMT != GLFER_FMT_F32 && SHIFT == 4);
   v2f32 tw1reg[16];
-  if constexpr (GLFER16H_TW1_REGS != 0) {
+  if constexpr (TW1R) {
 #pragma unroll
     for (int q = 0; q < 16; q++) tw1reg[q] = tw1row[q];
   }
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
         if (has_next && last) prefetch_next(rel_of(it + 1), rotc);   // the frame's last use of px is behind us
       }
     };
-    if constexpr (GLFER16H_TW1_REGS != 0) stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1reg, twr, twi, pass_hook);
+    if constexpr (TW1R) stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1reg, twr, twi, pass_hook);
     else stockham16_passes<LOGN - 1, NT>(zr, zi, xb, t, tw1row, twr, twi, pass_hook);
 
     // ---- mirror step: Z[k], k >= M/2, through LDS (entry u = k - M/2)

@@ -1,4 +1,4 @@
-"""Periodogram throughput by block size and overlap (f32, Hanning) for store-policy A/B runs:
+"""Periodogram throughput by block size and overlap (f32, or GLFER_FMT=s16|u8; Hanning) for A/B runs:
 GLFER_LIB_PATH=<other libglfer_hip.so> python3 tools/fft_policy_sizes.py"""
 import os, sys, time
 sys.path.insert(0, '.')
@@ -12,8 +12,10 @@ for n in [int(v) for v in os.environ.get("GLFER_SIZES", "4096,8192,16384").split
     for overlap in (0.0, 0.5, 0.75):
         hop = int(n * (1 - overlap))
         frames = (1 << 29) // hop
-        sp = G.Spectrogram(G.FftParams(n=n, overlap=overlap, window_type=0))
+        sp = G.Spectrogram(G.FftParams(n=n, overlap=overlap, window_type=0, sample_format={'s16': A.SAMPLES_S16, 'u8': A.SAMPLES_U8}.get(os.environ.get('GLFER_FMT'), A.SAMPLES_F32)))
         x = torch.randn(frames * sp.hop + (n - sp.hop), device='cuda') * 0.2
+        if os.environ.get("GLFER_FMT") == "s16": x = (x * 32768.0).clamp(-32768, 32767).to(torch.int16)
+        if os.environ.get("GLFER_FMT") == "u8": x = (x * 128.0 + 128.0).clamp(0, 255).to(torch.uint8)
         out = torch.empty((sp.num_frames(x.numel()), sp.bins), device='cuda')
         best = 1e9
         for rep in range(3):
