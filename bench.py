@@ -276,14 +276,16 @@ def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local,
         b.record()
     barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    each = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms = sum(each) / steps
     tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     res = {"workload": workload, "name": name, "n": n, "overlap": overlap, "hop": hop, "bins": bins, "frames": frames,
            "ntapers": sp.ntapers, "dt": dt, "kernel_ms": kernel_ms, "fps": frames * world * steps / dt,
-           "ms_per_step": dt / steps * 1e3, "b_alg": 4 * hop + 4 * bins}
+           "ms_per_step": dt / steps * 1e3, "b_alg": 4 * hop + 4 * bins,
+           "kernel_ms_first": each[0], "kernel_ms_min": min(each), "kernel_ms_max": max(each)}
     res["achieved_gbs"] = frames * res["b_alg"] / (kernel_ms * 1e-3) / 1e9
     del shard, psd
     sp.close()
@@ -363,7 +365,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's default)")
     ap.add_argument("--workload", default="mtm", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -428,6 +430,7 @@ def main():
                          "algorithmic_bytes_per_launch": frames * b_alg,
                          "kernel": kernel,
                          "kernel_ms": kernel_ms,
+                         "kernel_ms_first_min_max": [res["kernel_ms_first"], res["kernel_ms_min"], res["kernel_ms_max"]],
                          "algorithmic_bytes_per_frame": b_alg,
                          "note": ROOFLINE_NOTES.get(args.workload, "")},
             "hbm_gbs_aggregate": res["fps"] * b_alg / 1e9,
