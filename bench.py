@@ -61,12 +61,15 @@ KERNELS = {"fft1k": ("spectro16h_kernel<10, ..., SHIFT 8> (register reuse across
 ROOFLINE_NOTES = {
     "mtm": "not HBM-bound (traffic 1.00x algorithmic): FP32 VALU at two wavefronts per SIMD (248 VGPRs, 2 x 35 KB LDS). "
            "Counters (profiles/r03_stall_picture.txt): a wavefront executes VALU 51 % / LDS 10 % of its time and waits 34.5 %; "
-           "VALU pipe 48 %, LDS array 33 % busy. Measured ceiling of this instruction stream with the exchange removed "
+           "VALU pipe 47-48 %, LDS array 33 % busy. Measured ceiling of this instruction stream with the exchange removed "
            "(tools/xbench GLFER_ABL, profiles/r01_xbench_exchange_ablation.txt): 98 M frames/s = 0.30 of the HBM roofline",
     "mtm75": "FP32-VALU-bound at two wavefronts per SIMD, as the headline (profiles/r03_stall_picture.txt): see valu.frac",
     "mtm16k": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac",
-    "fft": "HBM-bound: the copy ceiling on this chip is 0.79 of the 8 TB/s spec (MI355X_MICROARCH.md: 6.29 TB/s measured)",
-    "fft1k": "HBM-bound: the copy ceiling on this chip is 0.79 of the 8 TB/s spec (MI355X_MICROARCH.md: 6.29 TB/s measured)",
+    "fft": "HBM-bound. Measured ceiling (tools/mixbench, profiles/r03_streaming_ceilings.txt): a kernel that only streams this "
+           "frame's 4 KB in : 8 KB out reaches 0.65-0.66 of the 8 TB/s spec with aligned 16-byte stores and 0.58-0.61 with this "
+           "interface's dense rows of 2049 floats (4-byte stores, 256-byte instructions off the 128-byte lines); read-only 0.79",
+    "fft1k": "HBM-bound. Measured ceiling (tools/mixbench, profiles/r03_streaming_ceilings.txt): a kernel that only streams this "
+             "frame's 2 KB in : 2 KB out reaches 0.63-0.64 of the 8 TB/s spec (read-only 0.79, write-only 0.71, copy 0.69)",
     "hparma": "not HBM-bound (24.6 KB per frame of algorithmic traffic): compute/latency-bound, see valu (FP64)",
 }
 
