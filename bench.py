@@ -62,7 +62,10 @@ ROOFLINE_NOTES = {
     "mtm": "not HBM-bound (traffic 1.00x algorithmic): FP32 VALU at two wavefronts per SIMD (248 VGPRs, 2 x 35 KB LDS). "
            "Counters (profiles/r03_stall_picture.txt): a wavefront executes VALU 51 % / LDS 10 % of its time and waits 34.5 %; "
            "VALU pipe 47-48 %, LDS array 33 % busy. Measured ceiling of this instruction stream with the exchange removed "
-           "(tools/xbench GLFER_ABL, profiles/r01_xbench_exchange_ablation.txt): 98 M frames/s = 0.30 of the HBM roofline",
+           "(tools/xbench GLFER_ABL, profiles/r01_xbench_exchange_ablation.txt): 98 M frames/s = 0.30 of the HBM roofline; with the "
+           "sample stream served from L2 instead of HBM (same instructions): 93-95 M -- on this chip an L2-hit load (the taper "
+           "tables) waits behind other wavefronts' HBM misses (tools/tcpbench), and no placement of the loads gets that back "
+           "(profiles/r03_y_sample_misses.txt)",
     "mtm75": "FP32-VALU-bound at two wavefronts per SIMD, as the headline (profiles/r03_stall_picture.txt): see valu.frac",
     "mtm16k": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac",
     "fft": "HBM-bound. Measured ceiling (tools/mixbench, profiles/r03_streaming_ceilings.txt): a kernel that only streams this "
