@@ -11,7 +11,7 @@ for W in $WL; do
   if [ $W = mtm ]; then D=$R/gpurun_out/prof; else D=$R/gpurun_out/prof_$W; fi
   rm -rf $D; mkdir -p $D
   cd $R
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --workload $W > $D/stats.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --workload $W > $D/stats.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --workload $W > $D/fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --workload $W > $D/write.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $D/sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --workload $W > $D/sq.log 2>&1
