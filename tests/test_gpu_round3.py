@@ -622,3 +622,63 @@ def test_block_sizes_above_65536(lib, oracle, torch_cuda, n):
     torch.cuda.synchronize()
     with pytest.raises(lib.GlferHipError):
         lib.Spectrogram(lib.FftParams(n=2 * (1 << 20), window_type=0, overlap=0.0))
+
+
+# ---- randomised: the block sizes and the mean-removal mode the round-1/2 fuzz does not reach ---------------
+def _big_cases():
+    import os
+    rng = np.random.default_rng(int(os.environ.get("GLFER_FUZZ_SEED", "20260")) + 31)
+    out = []
+    for i in range(int(os.environ.get("GLFER_FUZZ_BIG_CASES", "28"))):
+        n = int(rng.choice([2048, 4096, 8192, 8192, 16384, 16384]))   # (above 16384 the REFERENCE's recurrence FFT is itself > 1e-5 from exact: test_block_sizes_above_65536, test_gpu_round2.py)
+        overlap = float(rng.choice([0.0, 0.0, 0.5, 0.75, 0.9]))
+        mode = "mtm" if rng.random() < 0.55 else "fft"
+        kmax = int(rng.integers(1, 9))
+        nw = float(rng.choice([2.5, 4.0, 4.5]))
+        fmt = str(rng.choice(["f32", "f32", "s16", "u8"]))
+        sub_mean = int(rng.choice([0, 1, 2, 2]))
+        history_mode = int(rng.random() < 0.2)
+        frames = int(rng.integers(2, 14))
+        out.append((i, mode, n, overlap, kmax, nw, fmt, sub_mean, history_mode, frames))
+    return out
+
+
+@pytest.mark.parametrize("case", _big_cases(), ids=lambda c: "%d-%s-n%d-o%.2f-k%d-%s-m%d-h%d-f%d" % (c[0], c[1], c[2], c[3], c[4], c[6], c[7], c[8], c[9]))
+def test_random_big_blocks_and_exact_means(lib, oracle, torch_cuda, case):
+    """Seeded random configurations over N = 2048 ... 16384, every sample format, mean removal off / in-kernel sums /
+    the reference's summation order (GLFER_SUBMEAN_EXACT), history zeroed every frame or not: rows within 1e-5 of
+    the oracle's per frame (the in-kernel sums on a stream with a small DC level: the same bound), a sub-range of
+    the frames the same to rounding."""
+    torch = torch_cuda
+    i, mode, n, overlap, kmax, nw, fmt, sub_mean, history_mode, frames = case
+    h = oracle.hop(n, overlap)
+    x = synth(frames * h + (i % 5), seed=300 + i) + np.float32(0.01 * (i % 3))
+    if fmt == "s16":
+        raw = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16)
+        xf, sf = oracle.pcm_s16_to_float(raw), lib.SAMPLES_S16
+    elif fmt == "u8":
+        raw = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8)
+        xf, sf = oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
+    else:
+        raw, xf, sf = x, x, lib.SAMPLES_F32
+    ref_mean = 1 if sub_mean else 0
+    if mode == "mtm":
+        want = oracle.spectrogram_mtm(xf.copy(), n, overlap, nw, kmax, sub_mean=ref_mean, history_mode=history_mode)
+        params = lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=sub_mean, history_mode=history_mode, sample_format=sf)
+    else:
+        window = lib.WINDOWS["hanning"] if i % 2 else lib.WINDOWS["kaiser"]
+        owin = oracle.WINDOWS["hanning"] if i % 2 else oracle.WINDOWS["kaiser"]
+        want = oracle.spectrogram_fft(xf.copy(), n, overlap, owin, 0.0, 0, ref_mean, history_mode)
+        params = lib.FftParams(n=n, window_type=window, overlap=overlap, sub_mean=sub_mean, history_mode=history_mode, sample_format=sf)
+    sp = lib.Spectrogram(params)
+    d = torch.from_numpy(raw).cuda()
+    got = sp.run(d).cpu().numpy()
+    assert got.shape == want.shape == (frames, n // 2 + 1)
+    for f in range(frames):
+        assert max(rel_err(got[f], want[f])) <= TOL, (case, f, rel_err(got[f], want[f]))
+    if frames >= 3:
+        first = 1 + i % (frames - 2)
+        count = 1 + (i * 5) % (frames - first)
+        part = sp.run(d, first_frame=first, nframes=count).cpu().numpy()
+        for f in range(count):
+            assert max(rel_err(part[f], want[first + f])) <= TOL, (case, first, count, f)
