@@ -273,9 +273,22 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
       });
     }
   };
+  // MT: an integer frame is converted ONCE, in place, when its first taper starts (phase_S) -- the same floats as converting
+  // at every use, a twentieth of C4's arithmetic less for 16-bit and 8-bit streams
+  constexpr bool kConvertOnce = MT != 0 && FMT != GLFER_FMT_F32 && GEN == 0;
+  auto raw_pair = [&](auto mc) -> v2f32 {
+    constexpr int m = decltype(mc)::value;
+    if constexpr (FMT == GLFER_FMT_S16) {
+      const int raw = (int)__float_as_uint(px[m].x);
+      return v2f32{(float)(short)(raw & 0xffff), (float)(raw >> 16)};
+    } else {
+      const unsigned raw = __float_as_uint(px[m].x);
+      return v2f32{(float)(raw & 0xffu) - 128.0f, (float)((raw >> 8) & 0xffu) - 128.0f};
+    }
+  };
   auto sample_pair = [&](auto mc) -> v2f32 {
     constexpr int m = decltype(mc)::value;
-    if constexpr (FMT == GLFER_FMT_F32 || GEN != 0) {
+    if constexpr (FMT == GLFER_FMT_F32 || GEN != 0 || kConvertOnce) {
       return px[m];
     } else if constexpr (FMT == GLFER_FMT_S16) {
       const int raw = (int)__float_as_uint(px[m].x);
@@ -357,6 +370,9 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
     const bool last = sj == ntap - 1;
     const long long nf = sf + FPB;
     const bool has_next = nf < fend;
+    if constexpr (kConvertOnce) {
+      if (sj == 0) static_for<0, 16>([&](auto mc) { px[decltype(mc)::value] = raw_pair(mc); });
+    }
     if constexpr (KM != 0) {
       if (sj == 0) {                                       // a new frame in px: its hops' means, once (every wavefront of the workgroup is here)
         float part[NH];
