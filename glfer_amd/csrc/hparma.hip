@@ -47,6 +47,53 @@ __device__ __forceinline__ double wave_sum(double v) {
   return tot;
 }
 
+// The three sums of a rotation at once (round 3).  Three separate wave_sum()s are 24 double-precision additions (4 clocks each)
+// and 48 cross-lane moves; here the lanes SHARE the work: after the first exchange (lane ^ 1) the even lanes carry a and b, the
+// odd lanes c; after the second (lane ^ 2) lane q of every quad carries one value -- q = 0: a, 1: c, 2: b, 3: nothing -- and from
+// there one tree (row_ror 4 and 8, then the rows by v_permlane16_swap / v_permlane32_swap) sums all three: 7 additions.  Lanes 0, 1
+// and 2 hand every lane the three totals (v_readlane: the same bits everywhere).  The order of the additions is fixed (a tree over the lanes, as before).
+__device__ __forceinline__ void wave_sum3(double &a, double &b, double &c, bool odd, bool bit1) {
+  auto dpp = [](double x, auto ctrl) -> double {
+    constexpr int C = decltype(ctrl)::value;
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, C, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), C, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  };
+  // lane ^ 1: even lanes keep (a, b) and send c; odd lanes keep c and send (a, b)
+  const double k1 = odd ? c : a, k2 = odd ? 0.0 : b, s1 = odd ? a : c, s2 = odd ? b : 0.0;
+  const double u1 = k1 + dpp(s1, std::integral_constant<int, 0xB1>{});      // even: a over the pair; odd: c over the pair
+  const double u2 = k2 + dpp(s2, std::integral_constant<int, 0xB1>{});      // even: b over the pair; odd: 0
+  // lane ^ 2: the lower pair of a quad keeps its first value and sends the second, the upper pair the other way round
+  const double k = bit1 ? u2 : u1, s = bit1 ? u1 : u2;
+  double v = k + dpp(s, std::integral_constant<int, 0x4E>{});               // quad lane 0: a, 1: c, 2: b, 3: 0 -- over the quad
+  v += dpp(v, std::integral_constant<int, 0x124>{});                        // row_ror:4
+  v += dpp(v, std::integral_constant<int, 0x128>{});                        // row_ror:8: over the 16-lane row, per quad lane
+  {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+    v = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]) + __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+  }
+  {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+    v = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]) + __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+  }
+  // every lane must see the SAME bits (the skip / swap decisions are taken per lane): the lanes of a class added their row's four
+  // quads in rotated orders, so the totals are read from lanes 0, 1, 2 rather than from each quad's own
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  auto from = [&](int l) -> double {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  };
+  a = from(0);
+  c = from(1);
+  b = from(2);
+}
+
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -119,6 +166,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
     const int sweepmax = ncol > 12 ? ncol : 12;
     int count = 1, sweep = 0;
     const bool fast = t <= 128 && ncol <= 64;
+    const bool odd = (lane & 1) != 0, bit1 = (lane & 2) != 0;
     while (count > 0 && sweep <= sweepmax) {
       count = ncol * (ncol - 1) / 2;
       if (fast) {
@@ -145,9 +193,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
               const double a = aj1, b = ak1;
               pp += a * b; qq += a * a; rr += b * b;
             }
-            pp = wave_sum(pp);
-            qq = wave_sum(qq);
-            rr = wave_sum(rr);
+            wave_sum3(pp, qq, rr, odd, bit1);
             bool rotate = true;
             if (qq * rr < 2.22e-16) { count--; rotate = false; }                       // util.c:316-320
             else if (pp * pp / (qq * rr) < 1.0e-12) { count--; rotate = false; }       // util.c:321-325
@@ -200,9 +246,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
             qq += aj * aj;
             rr += ak * ak;
           }
-          pp = wave_sum(pp);
-          qq = wave_sum(qq);
-          rr = wave_sum(rr);
+          wave_sum3(pp, qq, rr, odd, bit1);
           if (qq * rr < 2.22e-16) { count--; continue; }            // util.c:316-320
           if (pp * pp / (qq * rr) < 1.0e-12) { count--; continue; } // util.c:321-325
           double cs, sn;

@@ -682,3 +682,28 @@ def test_random_big_blocks_and_exact_means(lib, oracle, torch_cuda, case):
         part = sp.run(d, first_frame=first, nframes=count).cpu().numpy()
         for f in range(count):
             assert max(rel_err(part[f], want[first + f])) <= TOL, (case, first, count, f)
+
+
+# ---- HP-ARMA: the three sums of a rotation share one reduction tree (round 3) --------------------------------
+@pytest.mark.parametrize("n,overlap,t,p_e,sub_mean", [(1024, 0.5, 96, 16, 1), (4096, 0.75, 96, 16, 0), (4096, 0.0, 128, 32, 0), (512, 0.0, 40, 7, 1)])
+def test_hparma_over_many_streams(lib, oracle, torch_cuda, n, overlap, t, p_e, sub_mean):
+    """hparma.hip's wave_sum3: every lane must take a rotation's skip / swap decisions on the SAME bits -- a first form that let
+    each quad use its own (differently associated) totals was wrong in one frame in six at t = 96 and right at t = 128 and 64.
+    Eight streams per shape, |A(f)|^2/N peak-normalised within 1e-4 of the oracle (the bound of test_hparma_parity; the device
+    sits at 2e-6 median / 2e-5 worst, where the oracle itself moves when its input moves by one float ulp:
+    tools/hparma_err_spread.py)."""
+    h = oracle.hop(n, overlap)
+    frames = 8
+    worst = 0.0
+    for seed in range(8):
+        x = synth(frames * h, seed=5000 + 100 * seed + t)
+        ref = oracle.hparma_frames(x, n, overlap, t, p_e, sub_mean=sub_mean)
+        sp = lib.Spectrogram(lib.HparmaParams(n=n, overlap=overlap, t=t, p_e=p_e, sub_mean=sub_mean))
+        got = sp.run(torch_cuda.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all()
+        for f in range(frames):
+            want = ref[f][0].astype(np.float64)
+            e = max(rel_err(1.0 / got[f, :n // 2], 1.0 / want[:n // 2]))
+            worst = max(worst, e)
+            assert e < 1e-4, (seed, f, e)
+    print("HP-ARMA N=%d t=%d p_e=%d: worst %.1e over 64 frames" % (n, t, p_e, worst))
