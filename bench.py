@@ -331,7 +331,10 @@ def hparma_view(res):
     tf = frames * flops / (kernel_ms * 1e-3) / 1e12
     return {"model": "counted FP64 flops of hparma_do, lower bound (12 Jacobi sweeps)", "flops_per_frame_f64": flops,
             "achieved_TFLOPs": tf, "peak_TFLOPs": 78.6, "frac": tf / 78.6,
-            "note": "latency-bound: one wavefront per frame walks the Jacobi rotations in the reference's order"}
+            "note": "bound by the vector instructions a Jacobi rotation issues (most of them double precision at 4 clocks each), not by latency "
+                    "(12 frames in flight per CU instead of 7: no change); one wavefront per frame walks the rotations in the reference's "
+                    "order.  Round 3: the rotation's three 64-lane sums share one reduction tree and its ratio test needs no division "
+                    "(0.42 -> 0.52 M frames/s, profiles/r03_hparma_shared_sums.txt)"}
 
 
 def parity_vs_oracle(torch, G, workload, local, frames=64):

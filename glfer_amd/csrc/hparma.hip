@@ -184,19 +184,17 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
               an1 = v1 ? A[(k + 1) * t + i1] : 0.0f;
               qn = vq ? Q[(k + 1) * ncol + lane] : 0.0f;
             }
-            double pp = 0.0, qq = 0.0, rr = 0.0;
+            double pp, qq, rr;                                       // the lane's two rows (0 + x is x: no addition for the first)
             {
-              const double a = aj0, b = ak0;
-              pp += a * b; qq += a * a; rr += b * b;
-            }
-            {
-              const double a = aj1, b = ak1;
-              pp += a * b; qq += a * a; rr += b * b;
+              const double a = aj0, b = ak0, a1 = aj1, b1 = ak1;
+              pp = a * b + a1 * b1;
+              qq = a * a + a1 * a1;
+              rr = b * b + b1 * b1;
             }
             wave_sum3(pp, qq, rr, odd, bit1);
             bool rotate = true;
             if (qq * rr < 2.22e-16) { count--; rotate = false; }                       // util.c:316-320
-            else if (pp * pp / (qq * rr) < 1.0e-12) { count--; rotate = false; }       // util.c:321-325
+            else if (pp * pp < 1.0e-12 * (qq * rr)) { count--; rotate = false; }       // util.c:321-325: p*p/(q*r) < 1e-12, without the division (qq * rr > 0 here)
             if (rotate) {
               double cs, sn;
               if (qq < rr) {                                          // util.c:327-335
@@ -248,7 +246,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
           }
           wave_sum3(pp, qq, rr, odd, bit1);
           if (qq * rr < 2.22e-16) { count--; continue; }            // util.c:316-320
-          if (pp * pp / (qq * rr) < 1.0e-12) { count--; continue; } // util.c:321-325
+          if (pp * pp < 1.0e-12 * (qq * rr)) { count--; continue; } // util.c:321-325 (see the fast path)
           double cs, sn;
           if (qq < rr) {                                            // util.c:327-335
             cs = 0.0;
