@@ -24,6 +24,7 @@ WINDOWS = {"hanning": 0, "blackman": 1, "gaussian": 2, "welch": 3,
            "bartlett": 4, "rectangular": 5, "hamming": 6, "kaiser": 7}
 SAMPLES_F32, SAMPLES_S16, SAMPLES_U8 = 0, 1, 2
 HISTORY_ZERO_FIRST, HISTORY_ZERO_ALWAYS = 0, 1
+SUBMEAN_OFF, SUBMEAN_EXACT, SUBMEAN_FAST = 0, 1, 2     # cfg.sub_mean: 1 = the reference's rows (fft.c:86-96 in its own summation order)
 AVG_SUMAVG, AVG_PLAIN, AVG_SUMEXTREME = 1, 2, 3
 
 # every symbol include/glfer_hip.h declares

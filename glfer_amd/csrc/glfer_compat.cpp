@@ -32,6 +32,15 @@ int glfer_compat_get_autoscale(void) { return &opt ? opt.autoscale : glfer_compa
 int glfer_compat_get_first_buffer(void) { return &glfer ? glfer.first_buffer : glfer_compat_first_buffer; }
 int glfer_compat_readahead = 1;        // 0: every hop of a file source goes through the per-hop path
 unsigned long glfer_compat_readahead_served = 0;   // hops served from a device-computed batch (a counter for tests and logs)
+
+// fft.c:47-59 -- the window menu of the options dialog (g_options.c:47-48, 579-583) reads these two data
+// symbols from the object this library replaces: same names, same order, same menu paths
+static char wn_hanning[] = "/Hanning", wn_blackman[] = "/Blackman", wn_gaussian[] = "/Gaussian", wn_welch[] = "/Welch",
+            wn_bartlett[] = "/Bartlett", wn_rectangular[] = "/Rectangular", wn_hamming[] = "/Hamming", wn_kaiser[] = "/Kaiser";
+fft_window_t fft_windows[] = {
+  {wn_hanning, HANNING_WINDOW},   {wn_blackman, BLACKMAN_WINDOW},       {wn_gaussian, GAUSSIAN_WINDOW}, {wn_welch, WELCH_WINDOW},
+  {wn_bartlett, BARTLETT_WINDOW}, {wn_rectangular, RECTANGULAR_WINDOW}, {wn_hamming, HAMMING_WINDOW},   {wn_kaiser, KAISER_WINDOW}};
+int num_fft_windows = sizeof(fft_windows) / sizeof(fft_windows[0]);
 }
 
 namespace {
@@ -82,9 +91,12 @@ void engine_open(const void *key, const glfer_hip_config &cfg, bool want_spec, c
   e.psd.assign(cfg.n / 2 + 1, 0.0f);
   // the library's device code is loaded by its first launch (tens of ms for the whole set of kernels):
   // here, at *_init, not under the first hop
+  // (any launch loads the library's one code object; the floor entry takes rows of at most 32769 bins, the
+  // estimators go up to N = 1048576 -- a short row does, and a refused warm-up only moves the load under the first hop)
   hipck(hipMemset(e.d_psd, 0, (size_t)(cfg.n / 2 + 1) * sizeof(float)), "hipMemset");
-  int wrc = glfer_hip_floor_device(e.d_psd, 1, cfg.n / 2 + 1, e.d_frame, nullptr);
-  if (wrc) die("warm-up launch", wrc);
+  const int warm_bins = cfg.n / 2 + 1 < 2049 ? cfg.n / 2 + 1 : 2049;
+  int wrc = glfer_hip_floor_device(e.d_psd, 1, warm_bins, e.d_frame, nullptr);
+  if (wrc) fprintf(stderr, "glfer_compat: warm-up launch: %s (continuing)\n", glfer_hip_strerror(wrc));
   hipck(hipDeviceSynchronize(), "hipDeviceSynchronize");
   g_engines[key] = e;
   reader_prepare();                 // a file is open already: its first window now, not under the first hop
@@ -270,7 +282,25 @@ glfer_hip_config batch_config(glfer_hip_config want, const fft_params_t *fp) {
   return want;
 }
 
+// blocks the open file holds, the trailing partial one included (wav_fmt.c:102-119)
+size_t reader_total_blocks() {
+  const size_t block_bytes = (size_t)g_rd.out_len * (g_rd.info.bits_per_sample / 8);
+  return block_bytes ? (g_rd.info.data_bytes + block_bytes - 1) / block_bytes : 0;
+}
+
+// A host that leaves without close_wav_file -- glfer's /Source/Quit goes straight to gtk_main_quit
+// (g_main.c:115), and every exit(-1) in here -- must not reach the static destructor of g_rd with a joinable
+// fetcher (std::terminate), nor tear HIP down under a fetcher that is still launching: registered when the first
+// fetcher starts, i.e. after the HIP runtime's own handlers, so it runs before them.
+void reader_at_exit() {
+  if (g_rd.fetching && g_rd.fetcher.joinable()) g_rd.fetcher.join();
+  g_rd.fetching = false;
+}
+
 void start_prefetch(size_t next, size_t bins) {
+  if (next >= reader_total_blocks()) return;       // nothing after the window being served
+  static const bool registered = [] { atexit(reader_at_exit); return true; }();
+  (void)registered;
   Window *nx = &g_rd.win[g_rd.cur ^ 1];
   g_rd.fetching = true;
   g_rd.fetcher = std::thread([nx, next, bins] { g_rd.fetch_rc = fetch_window(*nx, next, bins); });
@@ -373,6 +403,7 @@ void reader_sync_state(const float *audio_buf, fft_params_t *fp) {
   if (h != (int)(n * (1.0 - fp->overlap))) { r.state_hops = k + 1; return; }
   const size_t back = (size_t)((n - h + h - 1) / h);                       // hops the history reaches back over
   size_t j0 = k > back ? k - back : 0;
+  const size_t gap_from = r.state_hops;
   if (j0 < r.state_hops) j0 = r.state_hops;
   const int bytes_per = r.info.bits_per_sample / 8;
   const long pos = ftell(r.f);
@@ -386,7 +417,10 @@ void reader_sync_state(const float *audio_buf, fft_params_t *fp) {
     // the flag as it stood when this hop was taken: TRUE at hop 0 and -- without autoscale -- always
     const int first = (j == 0 || !fp->sub_mean) ? 1 : 0;
     if (&glfer) glfer.first_buffer = first; else glfer_compat_first_buffer = first;
-    if (j == j0 && j0 > 0 && first == 0) memset(fp->inbuf_audio, 0, (size_t)n * sizeof(float));   // (older hops: out of reach)
+    // a gap between the state the per-hop path left (hops < state_hops) and the oldest hop the history reaches:
+    // start from an empty history; WITHOUT a gap (the per-hop path ran fewer than `back` hops ago -- the scope
+    // window toggled) inbuf_audio still holds the hops before state_hops and the assembly continues from it
+    if (j == j0 && j0 > gap_from && first == 0) memset(fp->inbuf_audio, 0, (size_t)n * sizeof(float));
     assemble(hop.data(), fp);
     if (j + 1 == k && r.last_samples < (size_t)h)
       memcpy(r.buff + r.last_samples, hop.data() + r.last_samples, ((size_t)h - r.last_samples) * sizeof(float));
@@ -522,6 +556,15 @@ void fft_do(float *audio_buf, fft_params_t *p) {                   // fft.c:190-
   reader_sync_state(audio_buf, p);
   assemble(audio_buf, p);
   hipck(hipMemcpy(e.d_frame, p->inbuf_audio, (size_t)p->n * sizeof(float), hipMemcpyHostToDevice), "H2D frame");
+  if (p->n > 32768) {
+    // the halfcomplex spectrum output stops at N = 32768 (glfer_hip.h); above it fft_do leaves the PSD for
+    // fft_psd and outbuf as it was -- its one reader is fft_psd's phase branch, which no caller of the
+    // reference asks for (source.c:144 passes NULL)
+    int rc = glfer_hip_spectrogram_device(e.plan, e.d_frame, (size_t)p->n, 0, 1, e.d_psd, nullptr);
+    if (rc) die("fft_do", rc);
+    hipck(hipMemcpy(e.psd.data(), e.d_psd, e.psd.size() * sizeof(float), hipMemcpyDeviceToHost), "D2H psd");
+    return;
+  }
   int rc = glfer_hip_spectrum_device(e.plan, e.d_frame, (size_t)p->n, 0, 1, e.d_psd, e.d_spec, nullptr);
   if (rc) die("fft_do", rc);
   hipck(hipMemcpy(p->outbuf, e.d_spec, (size_t)p->n * sizeof(float), hipMemcpyDeviceToHost), "D2H spectrum");

@@ -41,6 +41,8 @@ extern "C" hipError_t glfer_launch_ftest(const float *spec, size_t nframes, int 
 extern "C" hipError_t glfer_launch_submean_tail_ex(const void *raw_last, const float *prev, float *out, int H, int fresh, int exact,
                                                    int fmt, hipStream_t st);
 extern "C" hipError_t glfer_launch_hop_means_seq(const void *in, float *means, int H, long long nhops, int fmt, hipStream_t st);
+extern "C" hipError_t glfer_launch_hop_means_tiled(const void *in, float *means, int H, long long nhops, int fmt, int hpw, unsigned blocks,
+                                                   hipStream_t st);
 extern "C" hipError_t glfer_launch_prepare(const SpectroParams *p, int n, const float *window, float *out,
                                            hipStream_t st);
 
@@ -267,6 +269,10 @@ void scratch_free(void *q, hipStream_t st) {
             b.last = nullptr;
           }
           b.out = false;
+          // the cap bounds what is KEPT, not only what is newly made: a block handed back while the
+          // device holds more than the cap -- a reused block larger than a cap set since, glfer_hip_scratch_limit(0)
+          // -- goes back now (drop_block waits for the event just recorded, then hipFree)
+          if (b.dev >= 0 && b.dev < 64) trim_locked(g_scratch[b.dev], g_scratch_cap);
           if (moved) (void)hipSetDevice(cur);
           return;
         }
@@ -292,6 +298,18 @@ size_t scratch_held(int dev) {
 void scratch_set_cap(size_t bytes) {
   std::lock_guard<std::mutex> lock(g_scratch_mu);
   g_scratch_cap = bytes;
+  // idle blocks above the new cap go back at once, on every device that holds any
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+  for (int dev = 0; dev < 64; dev++) {
+    size_t held = 0;
+    for (BigBlock &b : g_scratch[dev].big)
+      if (b.p) held += b.cap;
+    if (held <= bytes) continue;
+    if (dev != cur && hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); continue; }
+    trim_locked(g_scratch[dev], bytes);
+    if (dev != cur && cur >= 0) (void)hipSetDevice(cur);
+  }
 }
 
 // Dynamic LDS above the default limit has to be allowed per kernel -- and per DEVICE: a process that
@@ -932,6 +950,8 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (p->d_lagmap) (void)hipFree(p->d_lagmap);
   if (p->d_unit) (void)hipFree(p->d_unit);
   glfer::ingest_ring_free(p->ring);
+  for (hipStream_t a : p->aux)
+    if (a) (void)hipStreamDestroy(a);
   delete p;
 }
 
@@ -1179,6 +1199,10 @@ static void fill_params(const glfer_hip_plan *p, SpectroParams &sp) {
   sp.bigtw = p->d_bigtw;
 }
 
+// cfg.sub_mean: any non-zero value but GLFER_SUBMEAN_FAST asks for the reference's rows, i.e. the hop means in
+// the reference's own summation order (1 = GLFER_SUBMEAN_EXACT is what fft_init stores: sub_mean = opt.autoscale)
+static bool reference_means(const glfer_hip_plan *p) { return p->cfg.sub_mean != 0 && p->cfg.sub_mean != GLFER_SUBMEAN_FAST; }
+
 // K0 (fft.c:86-96) for the hops that frames [first, first+nframes) touch: the mean of each hop's
 // NEW samples is removed before the hop enters the frame history, so every sample is corrected by
 // the mean of the hop it arrived in.  ZERO_ALWAYS frames see only their own hop; otherwise a frame
@@ -1209,7 +1233,7 @@ static int submean_scratch(const glfer_hip_plan *p, SpectroParams &sp, size_t fi
   const char *src = (const char *)sp.stream + hop_lo * (size_t)p->hop * esz;
   // GLFER_SUBMEAN_EXACT: the hop means first, accumulated sample after sample as fft.c:88-92 does
   // (submean_seq.hip: one more read of the stream), then the copy with those means
-  const bool exact = p->cfg.sub_mean == GLFER_SUBMEAN_EXACT;
+  const bool exact = reference_means(p);
   float *means = nullptr;
   hipError_t e = hipSuccess;
   if (exact) {
@@ -1245,15 +1269,130 @@ static bool mean_inkernel_ok(const glfer_hip_plan *p, const SpectroParams &sp, c
   if (!route_takes_mean(r, sp, p->n)) return false;
   // GLFER_SUBMEAN_EXACT: the kernels sum a hop in another order than fft.c:88-92, so they are handed the means
   // (SpectroParams::means) -- the forms that take a table: the periodogram, the packed kernel, spectro16y
-  if (p->cfg.sub_mean == GLFER_SUBMEAN_EXACT && !route_takes_table(r, sp, p->n)) return false;
+  if (reference_means(p) && !route_takes_table(r, sp, p->n)) return false;
   return true;
+}
+
+// The hop means in the reference's own order (fft.c:88-92, submean_seq.hip) for hops [hop_lo, hop_lo + nhops) of the raw
+// stream, into means[0 .. nhops): the tiled kernel where the hop and the stream's alignment allow it -- 16 or 4 hops per
+// wavefront, whichever still gives the pass a few thousand wavefronts -- else 64 hops per wavefront.
+static hipError_t launch_reference_means(const glfer_hip_plan *p, const SpectroParams &sp, size_t hop_lo, size_t nhops, float *means,
+                                         unsigned blocks, hipStream_t st) {
+  const size_t esz = sp.fmt == GLFER_FMT_F32 ? 4 : (sp.fmt == GLFER_FMT_S16 ? 2 : 1);
+  const char *src = (const char *)sp.stream + hop_lo * (size_t)p->hop * esz;
+  const int forced = [] { const char *e = getenv("GLFER_MEANS_HPW"); return e && *e ? atoi(e) : 0; }();
+  int hpw = forced;
+  if (!hpw) hpw = nhops >= 262144 ? 64 : (nhops >= 32768 || p->hop % 1024 != 0 ? 16 : 4);
+  if (hpw == 4 && p->hop % 1024 != 0) hpw = 16;
+  if (hpw == 16 && p->hop % 256 != 0) hpw = 64;
+  if ((hpw == 16 || hpw == 4) && (reinterpret_cast<uintptr_t>(src) & (4 * esz - 1)) == 0)
+    return glfer_launch_hop_means_tiled(src, means, p->hop, (long long)nhops, sp.fmt, hpw, blocks, st);
+  return glfer_launch_hop_means_seq(src, means, p->hop, (long long)nhops, sp.fmt, st);
+}
+
+// Frames [b0, b1) of the body (they lie inside the stream and on the kernel's frame groups) with GIVEN hop means
+// (cfg.sub_mean = GLFER_SUBMEAN_EXACT: the reference's rows).  Round 3 took the means of the whole range in one launch and
+// then ran the estimator: the stream came from HBM twice (C1 772 against 1 108, C2 230 against 277, C3 64 against 75 M
+// frames/s).  Round 4: PIECE BY PIECE -- the means of piece c+1 (side stream) run beside the estimator launch of piece c,
+// and a piece is small enough (samples + rows of two pieces under the 256 MiB Infinity Cache) that the estimator's read of
+// it is served on-die: the stream leaves HBM once.  Pieces end on multiples of GLFER_FRAME_ALIGN frames, so every row is
+// the one-launch row bit for bit.  GLFER_EXACT_PIECE_MB (samples per piece; 0 = one piece), GLFER_EXACT_STREAMS (1: means and
+// estimator in turn on the caller's stream; 2: means on a side stream; 3: estimator launches alternate between the
+// caller's stream and a second side stream as well), GLFER_MEANS_BLOCKS (grid of the tiled means kernel beside an
+// estimator launch) are the knobs tools/exact_mean_time.py sweeps.
+static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroParams &bs, size_t b0, size_t b1, hipStream_t st) {
+  const long piece_mb = [] { const char *e = getenv("GLFER_EXACT_PIECE_MB"); return e && *e ? atol(e) : 48L; }();   // (read per call: the sweep sets them between calls)
+  const int nstreams_env = [] { const char *e = getenv("GLFER_EXACT_STREAMS"); return e && *e ? atoi(e) : 2; }();
+  const unsigned means_blocks = [] { const char *e = getenv("GLFER_MEANS_BLOCKS"); return e && *e ? (unsigned)atol(e) : 0u; }();
+  const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop);
+  const size_t hop_lo = b0 - hops_back, nhops = b1 - hop_lo;                  // (b0 >= first_inside >= hops_back)
+  const size_t esz = bs.fmt == GLFER_FMT_F32 ? 4 : (bs.fmt == GLFER_FMT_S16 ? 2 : 1);
+  // frames per piece: a multiple of 64 frames (the frame groups of every form and GLFER_FRAME_ALIGN)
+  size_t piece = b1 - b0;
+  if (piece_mb > 0) {
+    piece = ((size_t)piece_mb << 20) / ((size_t)p->hop * esz);
+    piece = std::max<size_t>(piece / 64 * 64, 64);
+  }
+  const size_t npieces = (b1 - b0 + piece - 1) / piece;
+  int nstreams = npieces > 1 ? nstreams_env : 1;
+  float *means = nullptr;
+  hipError_t e = glfer::scratch_malloc((void **)&means, nhops * sizeof(float), st);
+  if (e != hipSuccess) return hip_fail(e, "scratch (hop means)");
+  SpectroParams q = bs;
+  q.means = means - hop_lo;                                                    // indexed by GLOBAL hop (= frame) index
+  if (nstreams > 1) {                                                          // the side streams, once per plan
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < nstreams - 1 && e == hipSuccess; i++)
+      if (!p->aux[i]) e = hipStreamCreateWithFlags(&p->aux[i], hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      nstreams = 1;
+      e = hipSuccess;
+    }
+  }
+  if (nstreams <= 1) {
+    for (size_t c = 0; c < npieces && e == hipSuccess; c++) {
+      const size_t f0 = b0 + c * piece, f1 = std::min(b1, f0 + piece);
+      const size_t h0 = c == 0 ? hop_lo : f0;
+      e = launch_reference_means(p, bs, h0, f1 - h0, means + (h0 - hop_lo), 0, st);
+      q.frame0 = (long long)f0;
+      q.nframes = (int)(f1 - f0);
+      q.psd = bs.psd + (f0 - b0) * (size_t)p->bins;
+      if (e == hipSuccess) e = launch_by_n(q, p->n, st);
+    }
+    glfer::scratch_free(means, st);
+    return e == hipSuccess ? GLFER_OK : hip_fail(e, "estimator launch (given hop means)");
+  }
+  // means(c) on aux[0]; estimator(c) on the caller's stream (or alternately aux[1]) after means(c); means(c + 2) not before
+  // estimator(c) is done, so that at most two pieces are between their two reads at any time
+  hipStream_t sm = p->aux[0];
+  std::vector<hipEvent_t> ev_m(npieces, nullptr), ev_e(npieces, nullptr);
+  hipEvent_t ev_fork = nullptr;
+  auto make = [&](hipEvent_t *ev) { return hipEventCreateWithFlags(ev, hipEventDisableTiming); };
+  e = make(&ev_fork);
+  if (e == hipSuccess) e = hipEventRecord(ev_fork, st);                        // the stream's samples (and the scratch) are the caller's stream's
+  if (e == hipSuccess) e = hipStreamWaitEvent(sm, ev_fork, 0);
+  if (e == hipSuccess && nstreams > 2) e = hipStreamWaitEvent(p->aux[1], ev_fork, 0);
+  for (size_t c = 0; c < npieces && e == hipSuccess; c++) {
+    const size_t f0 = b0 + c * piece, f1 = std::min(b1, f0 + piece);
+    const size_t h0 = c == 0 ? hop_lo : f0;
+    if (c >= 2) e = hipStreamWaitEvent(sm, ev_e[c - 2], 0);
+    if (e == hipSuccess) e = launch_reference_means(p, bs, h0, f1 - h0, means + (h0 - hop_lo), c == 0 ? 0 : means_blocks, sm);
+    if (e == hipSuccess) e = make(&ev_m[c]);
+    if (e == hipSuccess) e = hipEventRecord(ev_m[c], sm);
+    hipStream_t se = (nstreams > 2 && (c & 1)) ? p->aux[1] : st;
+    if (e == hipSuccess) e = hipStreamWaitEvent(se, ev_m[c], 0);
+    q.frame0 = (long long)f0;
+    q.nframes = (int)(f1 - f0);
+    q.psd = bs.psd + (f0 - b0) * (size_t)p->bins;
+    if (e == hipSuccess) e = launch_by_n(q, p->n, se);
+    if (e == hipSuccess) e = make(&ev_e[c]);
+    if (e == hipSuccess) e = hipEventRecord(ev_e[c], se);
+  }
+  // join: everything the side streams were given completes before the caller's stream goes on (also on an error path)
+  for (size_t c = 0; c < npieces; c++) {
+    if (ev_e[c] && (nstreams > 2 && (c & 1))) (void)hipStreamWaitEvent(st, ev_e[c], 0);
+    if (ev_m[c] && c + 1 == npieces) (void)hipStreamWaitEvent(st, ev_m[c], 0);
+  }
+  if (e != hipSuccess) {                                                       // a launch failed midway: the side stream may hold work that no estimator waited for
+    (void)hipStreamSynchronize(sm);
+    if (nstreams > 2) (void)hipStreamSynchronize(p->aux[1]);
+  }
+  glfer::scratch_free(means, st);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  for (size_t c = 0; c < npieces; c++) {
+    if (ev_m[c]) (void)hipEventDestroy(ev_m[c]);
+    if (ev_e[c]) (void)hipEventDestroy(ev_e[c]);
+  }
+  return e == hipSuccess ? GLFER_OK : hip_fail(e, "estimator launch (given hop means, piecewise)");
 }
 
 // Periodograms of frames [first, first + nframes) with the mean removal (fft.c:86-96) done inside the
 // periodogram kernel: the frames that lie inside the stream read the RAW stream and no corrected
 // copy is written for them; the first ceil(R/H) frames of a stream (zero history: the packed
 // kernel) keep the copy, a few hops long.  sp: fill_params + the raw stream.
-static int launch_mean_inkernel(const glfer_hip_plan *p, const SpectroParams &sp, size_t first, size_t nframes, float *d_psd,
+static int launch_mean_inkernel(glfer_hip_plan *p, const SpectroParams &sp, size_t first, size_t nframes, float *d_psd,
                                 hipStream_t st) {
   const size_t first_inside = (size_t)((p->keep + p->hop - 1) / p->hop);
   // the shared-odd-taper kernels take whole, globally aligned groups of frames (launch_by_n): pairs at N = 4096
@@ -1288,22 +1427,12 @@ static int launch_mean_inkernel(const glfer_hip_plan *p, const SpectroParams &sp
     bs.psd = d_psd + (b0 - first) * (size_t)p->bins;
     bs.spec = nullptr;
     bs.mean_inkernel = 1;
-    float *means = nullptr;
-    hipError_t e = hipSuccess;
-    if (p->cfg.sub_mean == GLFER_SUBMEAN_EXACT) {
-      // the means of the hops the body's frames touch, in the reference's order; the kernel indexes them by
-      // GLOBAL hop (= frame) index
-      const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop);
-      const size_t hop_lo = b0 - hops_back, nhops = b1 - hop_lo;                  // (b0 >= first_inside >= hops_back)
-      const size_t esz = sp.fmt == GLFER_FMT_F32 ? 4 : (sp.fmt == GLFER_FMT_S16 ? 2 : 1);
-      e = glfer::scratch_malloc((void **)&means, nhops * sizeof(float), st);
-      if (e == hipSuccess)
-        e = glfer_launch_hop_means_seq((const char *)sp.stream + hop_lo * (size_t)p->hop * esz, means, p->hop, (long long)nhops, sp.fmt, st);
-      bs.means = means ? means - hop_lo : nullptr;
+    if (!reference_means(p)) {
+      hipError_t e = launch_by_n(bs, p->n, st);
+      if (e != hipSuccess) rc = hip_fail(e, "estimator launch (mean removal in the kernel)");
+    } else {
+      rc = launch_body_with_reference_means(p, bs, b0, b1, st);
     }
-    if (e == hipSuccess) e = launch_by_n(bs, p->n, st);
-    if (means) glfer::scratch_free(means, st);
-    if (e != hipSuccess) rc = hip_fail(e, "estimator launch (mean removal in the kernel)");
   }
   by_copy(std::max(b1, std::min(b0, end)), end);
   return rc;

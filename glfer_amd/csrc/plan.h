@@ -110,6 +110,9 @@ struct glfer_hip_plan {
   float spec_unscale = 1.0f;
   bool nonlin = false;
   glfer::IngestRing *ring = nullptr;   // the host entries' chunk ring, kept between calls (ingest.cpp)
+  // side streams of the piecewise mean pass (glfer_hip.cpp launch_mean_inkernel): [0] runs the hop means of piece c+1
+  // beside piece c's estimator launch, [1] takes every other estimator launch; made on first use
+  hipStream_t aux[2] = {nullptr, nullptr};
 };
 
 // frames [first, first+nframes) of a device-resident stream (virtual base allowed); psd and/or

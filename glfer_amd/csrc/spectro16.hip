@@ -232,10 +232,7 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
         // scale is applied afterwards (post_scale) because the limiter is not linear.
         if (p.a > 0.0f) x = x / (p.a + x * x);
         float y = x * pt[m].x;
-        if (p.limiter) {
-          const float mag = __expf(0.1f * __logf(fabsf(y)));
-          y = (y > 0.0f) ? mag : -mag;
-        }
+        if (p.limiter) y = limiter_value(y);
         zr[m] = y * p.post_scale;
         zi[m] = 0.0f;
       } else {

@@ -113,8 +113,16 @@ struct LaunchH {
 // frame's wavefronts combined through LDS across the iteration's last barrier -- no extra barrier);
 // the older hops' means move down with the frames a slot walks.  Wherever and whenever a hop's
 // mean is formed, it is formed from the same lanes' same registers in the same order: one value.
-template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0, int SHIFT = 0, int MEAN = 0>
+// MTAB = 1 (with MEAN = 1; round 4): the hop means are GIVEN (p.means, the reference's own summation order,
+// submean_seq.hip) -- a form of its own, so that it carries none of the summing code: it fits the three
+// wavefronts per SIMD of the plain periodogram where the summing form needs two, and the next frame's
+// table entry is requested at the top of a frame, not where it is needed.  A sample belongs to ONE hop, so
+// x - mu is formed once, IN PLACE, when a hop's pairs are first used (`absorb`: integer pairs become floats
+// there) -- what fft.c:93-95 does to the caller's buffer -- and the frames that share the pair afterwards
+// read the corrected value: no second copy of the frame in registers.
+template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0, int SHIFT = 0, int MEAN = 0, int MTAB = 0>
 __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(SpectroParams p) {
+  static_assert(MTAB == 0 || (MEAN == 1 && MT == 0), "given means: the periodogram's mean form");
   static_assert(SHIFT == 0 || (MT == 0 && HIST == 0), "register reuse: periodogram, history from the stream");
   static_assert(MEAN == 0 || ((MT == 0 || SHIFT == 0) && HIST == 0 && GLFER16_BARRIER_AFTER_READS != 0),
                 "in-kernel mean removal: the periodogram, or the multitaper form with hop = frame; history from the stream");
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   constexpr float kSampleScale = FMT == GLFER_FMT_F32 ? 1.0f : (FMT == GLFER_FMT_S16 ? 1.0f / 32768.0f : 1.0f / 128.0f);
   __shared__ __attribute__((aligned(16))) v2f32 lds[L::LDS_WORDS + (VAR == 2 ? M : 0)];
   constexpr int WPF = T > 64 ? T / 64 : 1;               // wavefronts per frame
-  __shared__ float mred[MEAN ? FPB * WPF * NH : 1];      // MEAN: the frame's wavefronts' partial sums
+  __shared__ float mred[MEAN && !MTAB ? FPB * WPF * NH : 1];      // MEAN: the frame's wavefronts' partial sums
 
   const unsigned tid = threadIdx.x;
   const unsigned t = tid % T;
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   const v2f32 *tw1row = tw1 + (t & 15) * 17;
   // (integer samples at 75 % overlap: the registers push the three-wavefront form over its 168 and the 2-4 spilled dwords cost
   // 4-6 %: the LDS row there -- profiles/r03_h_tw1_regs.txt)
-  constexpr bool TW1R = GLFER16H_TW1_REGS != 0 && !(FMT != GLFER_FMT_F32 && SHIFT == 4);
+  constexpr bool TW1R = GLFER16H_TW1_REGS != 0 && !(FMT != GLFER_FMT_F32 && SHIFT == 4 && MTAB == 0);
   v2f32 tw1reg[16];
   if constexpr (TW1R) {
 #pragma unroll
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   auto sample_pair = [&](auto mc, auto rotc) -> v2f32 {
     constexpr int m = (decltype(mc)::value + decltype(rotc)::value) & 15;
     v2f32 x;
-    if constexpr (FMT == GLFER_FMT_F32) {
+    if constexpr (FMT == GLFER_FMT_F32 || MTAB != 0) {   // (MTAB: absorbed pairs are floats in every format)
       x = px[m];
     } else if constexpr (FMT == GLFER_FMT_S16) {
       const int raw = (int)__float_as_uint(px[m].x);
@@ -360,13 +368,42 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   // hop_means_seq_kernel -- as means[global hop index] in sample units; here they are used in the units
   // the samples are held in (integer formats: raw, the power-of-two scale rides in the window: exact).
   // The newest hop of frame F of the stream is hop F.
-  const bool mean_table = MEAN != 0 && p.means != nullptr;
+  const bool mean_table = MTAB != 0 || (MEAN != 0 && p.means != nullptr);
   auto table_mean = [&](long long rel, int back) -> float {      // the mean of the hop `back` hops before frame rel's newest
     const long long last_rel = (long long)p.nframes - 1 - start;
     const long long F = p.frame0 + start + (rel < last_rel ? rel : last_rel);
     return p.means[F - back] * (1.0f / kSampleScale);
   };
-  if constexpr (MEAN != 0) {
+  // MTAB: pairs FROM..15 of the frame at rotation ROT as floats (integer formats: unscaled) minus `mean`, in place
+  auto absorb = [&](auto fromc, auto toc, auto rotc, float mean) {
+    static_for<decltype(fromc)::value, decltype(toc)::value>([&](auto mc) {
+      constexpr int q = (decltype(mc)::value + decltype(rotc)::value) & 15;
+      v2f32 x;
+      if constexpr (FMT == GLFER_FMT_F32) {
+        x = px[q];
+      } else if constexpr (FMT == GLFER_FMT_S16) {
+        const int raw = (int)__float_as_uint(px[q].x);
+        x = v2f32{(float)(short)(raw & 0xffff), (float)(raw >> 16)};
+      } else {
+        const unsigned raw = __float_as_uint(px[q].x);
+        x = v2f32{(float)(raw & 0xffu) - 128.0f, (float)((raw >> 8) & 0xffu) - 128.0f};
+      }
+      {
+#pragma clang fp contract(off)
+        px[q] = v2f32{x.x - mean, x.y - mean};             // fft.c:93-95, rounded on its own
+      }
+    });
+  };
+  float mu_new = 0.0f;                                     // MTAB: the mean of the newest hop of the frame about to be formed
+  if constexpr (MTAB != 0) {
+    // the first frame of the slot: its older hops now, its newest hop at the top of the frame like every frame's
+    static_for<0, NH - 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      absorb(std::integral_constant<int, q * KM>{}, std::integral_constant<int, (q + 1) * KM>{}, std::integral_constant<int, 0>{},
+             table_mean(rel_of(0), NH - 1 - q));
+    });
+    mu_new = table_mean(rel_of(0), 0);
+  } else if constexpr (MEAN != 0) {
     if (mean_table) {
 #pragma unroll
       for (int q = 0; q < NH; q++) mu[q] = table_mean(rel_of(0), NH - 1 - q);
@@ -389,6 +426,11 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   const int ntap = MT ? p.htapers : 1;
   auto frame_body = [&](auto rotc) -> bool {
     const bool has_next = it + 1 < per;
+    float mu_next = 0.0f;
+    if constexpr (MTAB != 0) {
+      mu_next = table_mean(rel_of(has_next ? it + 1 : it), 0);   // wanted at the end of the frame
+      absorb(std::integral_constant<int, 16 - KM>{}, std::integral_constant<int, 16>{}, rotc, mu_new);   // this frame's newest hop
+    }
     if constexpr (PF2) {
       // this frame's new pairs were requested two frames ago (frame 1's: before the loop) into the landing
       // set of its parity; their px slots -- the previous frame's oldest pairs -- are free since that frame's
@@ -412,7 +454,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     static_for<0, 16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       xs[m] = sample_pair(mc, rotc);
-      if constexpr (MEAN != 0) {                       // fft.c:93-95 (the subtraction is rounded on its own: no contraction into the window product)
+      if constexpr (MEAN != 0 && MTAB == 0) {          // fft.c:93-95 (the subtraction is rounded on its own: no contraction into the window product)
 #pragma clang fp contract(off)
         xs[m].x = xs[m].x - mu[m / KM];
         xs[m].y = xs[m].y - mu[m / KM];
@@ -568,7 +610,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     if constexpr (MEAN != 0) {
       // the next frame's newest hop is in px by now (requested during this frame's passes): its sum
       // crosses the frame's wavefronts over the barrier that ends the iteration
-      if (has_next && last && !mean_table) {           // (the multitaper form: after the frame's last taper)
+      if (MTAB == 0 && has_next && last && !mean_table) {           // (the multitaper form: after the frame's last taper)
         constexpr int ROTN = (SHIFT == 4 || SHIFT == 8) ? ((decltype(rotc)::value + SHIFT) & 15) : 0;
         next_part = hop_partial(std::integral_constant<int, NH - 1>{}, std::integral_constant<int, ROTN>{});
         publish(next_part, NH - 1);
@@ -577,10 +619,14 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();     // mirror entries read: buffer free
     if constexpr (MEAN != 0) {
       if (has_next && last) {
-        const float mn = mean_table ? table_mean(rel_of(it + 1), 0) : collect(next_part, NH - 1);
+        if constexpr (MTAB != 0) {
+          mu_new = mu_next;
+        } else {
+          const float mn = mean_table ? table_mean(rel_of(it + 1), 0) : collect(next_part, NH - 1);
 #pragma unroll
-        for (int h = 0; h + 1 < NH; h++) mu[h] = mu[h + 1];
-        mu[NH - 1] = mn;
+          for (int h = 0; h + 1 < NH; h++) mu[h] = mu[h + 1];
+          mu[NH - 1] = mn;
+        }
       }
     }
    }
@@ -652,6 +698,15 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
     const int k16 = (16 * p.H) % (1 << L) == 0 ? (16 * p.H) >> L : 0;
     unsigned g = (unsigned)(work / 4 < 8 * resident ? (work / 4 ? work / 4 : 1) : 8 * resident);
     if (g >= 64) g &= ~7u;
+    if (p.means) {                                   // the means are given: the table form, at the plain form's occupancy
+      constexpr int W = GLFER16H_WAVES_PER_SIMD;
+      if (k16 == 16) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, W, GLFER16H_VAR, 0, 0, 0, 1, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+      else if (k16 == 2) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, W, GLFER16H_VAR, 0, 0, 2, 1, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+      else if (k16 == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, W, GLFER16H_VAR, 0, 0, 4, 1, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+      else if (k16 == 8) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, W, GLFER16H_VAR, 0, 0, 8, 1, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+      else return hipErrorInvalidValue;
+      return hipGetLastError();
+    }
     if (k16 == 16) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, kMeanWps, GLFER16H_VAR, 0, 0, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
     else if (k16 == 2) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, kMeanWps, GLFER16H_VAR, 0, 0, 2, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
     else if (k16 == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, kMeanWps, GLFER16H_VAR, 0, 0, 4, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);

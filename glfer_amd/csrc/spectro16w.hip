@@ -416,10 +416,7 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
         // afterwards (post_scale) because the limiter is not linear (the table holds the plain window)
         if (p.a > 0.0f) x = v2f32{x.x / (p.a + x.x * x.x), x.y / (p.a + x.y * x.y)};
         v2f32 y = v2f32{x.x * ww.x, x.y * ww.y};
-        if (p.limiter) {
-          const float m0 = __expf(0.1f * __logf(fabsf(y.x))), m1 = __expf(0.1f * __logf(fabsf(y.y)));
-          y = v2f32{y.x > 0.0f ? m0 : -m0, y.y > 0.0f ? m1 : -m1};
-        }
+        if (p.limiter) y = v2f32{limiter_value(y.x), limiter_value(y.y)};
         zr[m] = y.x * p.post_scale;
         zi[m] = y.y * p.post_scale;
       } else {

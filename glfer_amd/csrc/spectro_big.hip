@@ -130,9 +130,8 @@ __global__ __launch_bounds__(256) void subfft_kernel(SpectroParams p, int W, int
         }
         float y0 = xv[0] * w0, y1 = xv[1] * w1;
         if (p.limiter) {
-          const float m0 = __expf(0.1f * __logf(fabsf(y0))), m1 = __expf(0.1f * __logf(fabsf(y1)));
-          y0 = y0 > 0.0f ? m0 : -m0;
-          y1 = y1 > 0.0f ? m1 : -m1;
+          y0 = limiter_value(y0);
+          y1 = limiter_value(y1);
         }
         zr[m] = y0 * p.post_scale;
         zi[m] = y1 * p.post_scale;

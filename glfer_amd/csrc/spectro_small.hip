@@ -55,10 +55,7 @@ __global__ __launch_bounds__(256) void spectro_small_kernel(SpectroParams p, int
           float xv = x[e];
           if (p.a > 0.0f) xv = xv / (p.a + xv * xv);
           float y = xv * ta;
-          if (p.limiter) {
-            const float mag = __expf(0.1f * __logf(fabsf(y)));
-            y = (y > 0.0f) ? mag : -mag;
-          }
+          if (p.limiter) y = limiter_value(y);
           re = y * p.post_scale;
           im = 0.0f;
         } else {

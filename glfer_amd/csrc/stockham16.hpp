@@ -79,6 +79,17 @@ __device__ __forceinline__ float buf_sample(__amdgpu_buffer_rsrc_t rsrc, unsigne
   }
 }
 
+// The limiter of prepare_audio (fft.c:151-156): `ftmp = log(fabs(y))` is a double logarithm rounded to the
+// reference's FLOAT ftmp, `exp(ftmp * 0.1)` a double product and a double exponential rounded to float on the
+// store into inbuf_fft.  Done exactly so (round 4; the fast float intrinsics were 2e-4 of the row maximum away:
+// |y|^0.1 flattens the frame, so every sample's rounding shows).  A cold path: the limiter is off by default
+// (glfer.c:241) and the estimator kernels reach it through their general form only.
+__device__ __forceinline__ float limiter_value(float y) {
+  const float ftmp = (float)log((double)fabsf(y));
+  const float mag = (float)exp((double)ftmp * 0.1);
+  return y > 0.0f ? mag : -mag;
+}
+
 // Workgroup w of a launch runs on XCD (w mod 8), each XCD with its own L2.  Overlapped frames share
 // samples with their neighbours, so neighbouring frame blocks should share an L2: logical block
 // index = the XCD's contiguous slice of the grid (gridDim.x a multiple of 8; identity otherwise).

@@ -39,6 +39,16 @@ typedef struct {
 enum {HANNING_WINDOW = 0, BLACKMAN_WINDOW, GAUSSIAN_WINDOW, WELCH_WINDOW, BARTLETT_WINDOW,
       RECTANGULAR_WINDOW, HAMMING_WINDOW, KAISER_WINDOW};
 
+/* fft.h:69-75 and fft.c:47-59: the window table the options dialog builds its menu from
+ * (g_options.c:47-48, 579-583) -- two DATA symbols of the object this library replaces */
+typedef struct _fft_window_t fft_window_t;
+struct _fft_window_t {
+  char *name;
+  int type;
+};
+extern fft_window_t fft_windows[];      /* "/Hanning" ... "/Kaiser", in the order of the enum above */
+extern int num_fft_windows;             /* 8 */
+
 /* mtm.h:36-44 */
 typedef struct {
   fft_params_t fft;

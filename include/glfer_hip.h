@@ -83,7 +83,8 @@ typedef struct glfer_hip_config {
   int window_type;     /* opt.window_type (FFT mode; MTM forces rectangular, source.c:344) */
   float limiter_a;     /* opt.limiter_a  -> fft_params_t.a        (FFT mode only acts)  */
   int enable_limiter;  /* opt.enable_limiter -> fft_params_t.limiter                    */
-  int sub_mean;        /* per-hop mean removal, fft.c:86-96: 0 off, GLFER_SUBMEAN_FAST (1), GLFER_SUBMEAN_EXACT (2) */
+  int sub_mean;        /* per-hop mean removal, fft.c:86-96: 0 off; 1 (= GLFER_SUBMEAN_EXACT, what fft_init stores:
+                          sub_mean = opt.autoscale) the reference's rows; GLFER_SUBMEAN_FAST (2) the opt-in below */
   int history_mode;    /* GLFER_HISTORY_*                                               */
   float mtm_w;         /* opt.mtm_w = N*W time-bandwidth product (g-l_dpss.c:295-297)   */
   int mtm_k;           /* opt.mtm_k = kmax; kmax+1 tapers are used (mtm.c:189)          */
@@ -111,7 +112,7 @@ typedef struct glfer_hip_config {
  *                        to the usual 1e-5 whatever the input.  Cost: the extra read -- C3 64 against 75,
  *                        C2 230 against 277, C1 772 against 1 108 M frames/s (tools/exact_mean_time.py).
  * The per-hop shims (glfer_compat.h) always take the reference's order. */
-enum { GLFER_SUBMEAN_OFF = 0, GLFER_SUBMEAN_FAST = 1, GLFER_SUBMEAN_EXACT = 2 };
+enum { GLFER_SUBMEAN_OFF = 0, GLFER_SUBMEAN_EXACT = 1, GLFER_SUBMEAN_FAST = 2 };
 
 /* Cutting a stream into launches, chunks or shards.
  * (1) Cut at frame indices that are multiples of GLFER_FRAME_ALIGN and every frame's PSD is

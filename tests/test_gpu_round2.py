@@ -485,9 +485,12 @@ def test_periodogram_register_reuse_over_long_launches(lib, oracle, torch_cuda, 
 @pytest.mark.parametrize("n,overlap,fmt,frames", [(4096, 0.75, "f32", 20011), (4096, 0.0, "f32", 3001), (1024, 0.5, "s16", 50001),
                                                   (512, 0.875, "u8", 30001), (2048, 0.75, "f32", 57), (16384, 0.5, "f32", 2049),
                                                   (8192, 0.0, "s16", 300)])
-def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, overlap, fmt, frames):
+@pytest.mark.parametrize("mean_mode", [1, 2], ids=["reference-order", "in-kernel-sums"])
+def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, overlap, fmt, frames, mean_mode):
     """Per-hop mean removal (the reference's default) done inside spectro16h (hops of 2/4/8/16
-    sixteenths of the block): against the oracle, against the pre-pass form (GLFER_MEAN_PREPASS=1:
+    sixteenths of the block) -- with the hop means given in the reference's own order (cfg.sub_mean = 1, round 4:
+    the table form, the means taken piece by piece beside the estimator launches) and with the kernel's own sums
+    (GLFER_SUBMEAN_FAST): against the oracle, against the pre-pass form (GLFER_MEAN_PREPASS=1:
     the hop means are summed in another order there -- rounding-level agreement), and the same rows
     bit for bit from a launch that starts elsewhere (other slots, other register rotations)."""
     h = oracle.hop(n, overlap)
@@ -500,7 +503,7 @@ def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, 
         xf, sf = oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
     else:
         raw, xf, sf = x, x, lib.SAMPLES_F32
-    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=7, overlap=overlap, sub_mean=1, sample_format=sf))
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=7, overlap=overlap, sub_mean=mean_mode, sample_format=sf))
     dx = torch_cuda.from_numpy(raw).cuda()
     got = sp.run(dx).cpu().numpy()
     nchk = min(frames, 600)                                             # the oracle on the first and last frames
@@ -532,7 +535,8 @@ def test_mean_removal_inside_the_periodogram_kernel(lib, oracle, torch_cuda, n, 
                                                        (16384, 0.0, 8, "f32", 1100), (8192, 0.0, 4, "s16", 2100), (16384, 0.0, 8, "u8", 70),
                                                        (16384, 0.5, 8, "f32", 1200), (8192, 0.75, 4, "f32", 2200), (16384, 0.75, 5, "s16", 140),
                                                        (8192, 0.5, 7, "s16", 900)])
-def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, n, overlap, kmax, fmt, frames):
+@pytest.mark.parametrize("mean_mode", [1, 2], ids=["reference-order", "in-kernel-sums"])
+def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, n, overlap, kmax, fmt, frames, mean_mode):
     """The same for spectro16y (N = 4096, odd taper counts: frames taken in pairs, a lone first or last
     frame and the stream's first frames through the corrected copy) and for the packed kernel (even
     taper counts -- N = 1024 with 8 tapers at overlap 0 is the reference's default multitaper
@@ -550,7 +554,7 @@ def test_mean_removal_inside_the_multitaper_kernel(lib, oracle, torch_cuda, n, o
         xf, sf = oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
     else:
         raw, xf, sf = x, x, lib.SAMPLES_F32
-    sp = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=1, sample_format=sf))
+    sp = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=mean_mode, sample_format=sf))
     dx = torch_cuda.from_numpy(raw).cuda()
     got = sp.run(dx).cpu().numpy()
     nchk = min(frames, 300)

@@ -182,7 +182,7 @@ def test_adversarial_pairs_with_mean_removal(lib, oracle, torch_cuda, n, kmax, n
         want = (oracle.spectrogram_mtm(x, n, overlap, nw, kmax, sub_mean=1) if mt else
                 oracle.spectrogram_fft(x, n, overlap, oracle.WINDOWS["hanning"], sub_mean=1))
         top = np.abs(want).max()
-        for mode, name in ((2, "exact"), (1, "fast")):
+        for mode, name in ((lib.SUBMEAN_EXACT, "exact"), (lib.SUBMEAN_FAST, "fast")):
             params = (lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=mode) if mt else
                       lib.FftParams(n=n, window_type=lib.WINDOWS["hanning"], overlap=overlap, sub_mean=mode))
             sp = lib.Spectrogram(params)
@@ -197,7 +197,7 @@ def test_adversarial_pairs_with_mean_removal(lib, oracle, torch_cuda, n, kmax, n
                     continue
                 e_max, e_l2 = rel_err(got[f], want[f])
                 worst[has_dc[f]] = max(worst[has_dc[f]], e_max)
-                bound = 1e-3 if (mode == 1 and has_dc[f]) else TOL
+                bound = 1e-3 if (mode == lib.SUBMEAN_FAST and has_dc[f]) else TOL
                 assert e_max <= bound and e_l2 <= bound, (name, n, kmax, overlap, f, e_max, e_l2)
             print("mean removal %s, N=%d T=%d overlap %.2f: worst %.2e (frames without a DC hop), %.2e (with one)"
                   % (name, n, kmax + 1, overlap, worst[False], worst[True]))
@@ -223,7 +223,7 @@ def test_exact_order_means_on_dc_heavy_streams(lib, oracle, torch_cuda):
         else:
             raw, xf = x, x
         want = oracle.spectrogram_fft(xf, n, overlap, oracle.WINDOWS["hanning"], sub_mean=1)
-        sp = lib.Spectrogram(lib.FftParams(n=n, window_type=lib.WINDOWS["hanning"], overlap=overlap, sub_mean=2, sample_format=fmt))
+        sp = lib.Spectrogram(lib.FftParams(n=n, window_type=lib.WINDOWS["hanning"], overlap=overlap, sub_mean=lib.SUBMEAN_EXACT, sample_format=fmt))
         d = torch.from_numpy(raw).cuda()
         got = sp.run(d).cpu().numpy()
         for f in range(frames):
@@ -237,7 +237,7 @@ def test_exact_order_means_on_dc_heavy_streams(lib, oracle, torch_cuda):
         frames = 71
         x = (0.45 + 0.3 * rng.standard_normal(frames * hop)).clip(-0.99, 0.99).astype(np.float32)
         want = oracle.spectrogram_mtm(x, n, overlap, nw, kmax, sub_mean=1)
-        sp = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=2))
+        sp = lib.Spectrogram(lib.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sub_mean=lib.SUBMEAN_EXACT))
         d = torch.from_numpy(x).cuda()
         got = sp.run(d).cpu().numpy()
         for f in range(frames):

@@ -50,6 +50,40 @@ def test_compat_reads_the_programs_own_globals(tmp_path):
     assert (size_opt, off_auto, size_glfer, off_first) == (184, 148, 88, 28)
 
 
+def test_kept_objects_link_against_the_library(tmp_path):
+    """glfer relinks with libglfer_compat.so in place of fft.o fft_radix2.o mtm.o g-l_dpss.o avg.o hparma.o
+    lmp.o wav_fmt.o only if the library has EVERY symbol the kept objects (glfer.c source.c g_main.c g_options.c) take from
+    those -- the data symbols fft_windows[] / num_fft_windows of fft.c:47-59 included (g_options.c:47-48, 579-583).  A C file
+    that references all of them is linked with --no-undefined; run without arguments it only walks the window table."""
+    import subprocess
+    libdir = os.path.join(ROOT, "glfer_amd", "lib")
+    exe = tmp_path / "c_compat_link_all"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_compat_link_all.c"), "-o", str(exe), "-Wl,--no-undefined", "-L", libdir,
+                    "-lglfer_compat", "-Wl,-rpath," + libdir, "-Wl,-rpath-link," + libdir], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "1", (r.returncode, r.stdout, r.stderr)
+    # and the list itself: where the reference tree is mounted, every non-static function or object the dropped files define
+    # that a kept file names must be in the library
+    ref = "/root/reference"
+    if os.path.isdir(ref):
+        dropped = ["fft.c", "fft_radix2.c", "mtm.c", "g-l_dpss.c", "avg.c", "hparma.c", "lmp.c", "wav_fmt.c"]
+        kept = [f for f in os.listdir(ref) if f.endswith(".c") and f not in dropped and f != "bell-p-w.c"]
+        defined = set()
+        for f in dropped:
+            for line in open(os.path.join(ref, f), errors="replace"):
+                m = re.match(r"^(?!static)[A-Za-z_][\w \*]*?\**\b(\w+)\s*(\(|\[\]\s*=|=)", line)
+                if m and not line.rstrip().endswith(";") or (m and "=" in line):
+                    defined.add(m.group(1))
+        kept_text = " ".join(open(os.path.join(ref, f), errors="replace").read() for f in kept)
+        needed = sorted(s for s in defined if re.search(r"\b" + s + r"\b", kept_text) and s not in ("main", "opt", "glfer"))
+        assert "fft_windows" in needed and "num_fft_windows" in needed and "fft_do" in needed
+        import torch  # noqa: F401
+        L = ctypes.CDLL(os.path.join(libdir, "libglfer_compat.so"))
+        missing = [s for s in needed if not hasattr(L, s)]
+        assert not missing, missing
+
+
 def test_compat_struct_fields_follow_the_reference_header():
     """opt_t / glfer_t in include/glfer_compat.h list the fields of glfer.h:62-139 in the same
     order with the same scalar types (GTK pointers as void *).  Reads the reference header as text

@@ -1,6 +1,9 @@
-"""Throughput with per-hop mean removal off / in-kernel sums (GLFER_SUBMEAN_FAST) / the reference's own summation order
-(GLFER_SUBMEAN_EXACT: hop_means_seq_kernel + the means table handed to the kernels, or the corrected copy where a form
-takes no table), 2^30-sample f32 streams."""
+"""Throughput with per-hop mean removal off / the reference's own summation order (cfg.sub_mean = 1 = GLFER_SUBMEAN_EXACT:
+hop means by submean_seq.hip, handed to the kernels as a table, piece by piece beside the estimator launches) / the kernels'
+own sums (GLFER_SUBMEAN_FAST), 2^30-sample f32 streams with a DC offset.
+    python tools/exact_mean_time.py            the table DESIGN quotes (product defaults)
+    python tools/exact_mean_time.py sweep      + the knobs of glfer_hip.cpp launch_body_with_reference_means
+                                                 (GLFER_EXACT_PIECE_MB x GLFER_EXACT_STREAMS x GLFER_MEANS_HPW x GLFER_MEANS_BLOCKS)"""
 import os, sys, time
 sys.path.insert(0, '.')
 import torch
@@ -12,22 +15,49 @@ CASES = (("C1 periodogram N=1024 50%", G.FftParams, dict(n=1024, window_type=0, 
          ("glfer default: N=1024 Kaiser ovl 0", G.FftParams, dict(n=1024, window_type=7, overlap=0.0)),
          ("glfer default MTM: N=1024 8 tapers ovl 0", G.MtmParams, dict(n=1024, overlap=0.0, w=4.0, kmax=7)),
          ("C4 multitaper N=16384 9 tapers", G.MtmParams, dict(n=16384, overlap=0.0, w=4.5, kmax=8)))
-for name, cls, kw in CASES:
-    line = "%-44s" % name
-    for mode in (0, 1, 2):
-        sp = G.Spectrogram(cls(sub_mean=mode, **kw))
-        frames = min((1 << 30) // sp.hop, 1 << 21)
-        x = torch.randn(frames * sp.hop + (sp.n - sp.hop), device='cuda') * 0.2 + 0.1
-        out = torch.empty((sp.num_frames(x.numel()), sp.bins), device='cuda')
-        best = 1e9
-        for rep in range(3):
+KNOBS = ("GLFER_EXACT_PIECE_MB", "GLFER_EXACT_STREAMS", "GLFER_MEANS_HPW", "GLFER_MEANS_BLOCKS")
+
+
+def rate(cls, kw, mode, env=None):
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    for k, v in (env or {}).items():
+        os.environ[k] = str(v)
+    sp = G.Spectrogram(cls(sub_mean=mode, **kw))
+    frames = min((1 << 30) // sp.hop, 1 << 21)
+    x = torch.randn(frames * sp.hop + (sp.n - sp.hop), device='cuda') * 0.2 + 0.1
+    out = torch.empty((sp.num_frames(x.numel()), sp.bins), device='cuda')
+    best = 1e9
+    for rep in range(3):
+        sp.run(x, out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
             sp.run(x, out=out)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(4): sp.run(x, out=out)
-            torch.cuda.synchronize()
-            best = min(best, (time.perf_counter() - t0) / 4)
-        line += "  %s %8.1f M" % (("off", "fast", "exact")[mode], out.shape[0] / best / 1e6)
-        del x, out, sp
-        torch.cuda.empty_cache()
-    print(line, flush=True)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / 4)
+    n = out.shape[0]
+    del x, out, sp
+    torch.cuda.empty_cache()
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    return n / best / 1e6
+
+
+sweep = len(sys.argv) > 1 and sys.argv[1] == "sweep"
+for name, cls, kw in (CASES[:3] if sweep else CASES):
+    off, exact, fast = (rate(cls, kw, m) for m in (G.SUBMEAN_OFF, G.SUBMEAN_EXACT, G.SUBMEAN_FAST))
+    print("%-44s  off %8.1f M  reference order %8.1f M (%.3f of the in-kernel sums)  in-kernel sums %8.1f M"
+          % (name, off, exact, exact / fast, fast), flush=True)
+    if not sweep:
+        continue
+    for streams in (1, 2, 3):
+        for piece in ((0,) if streams == 1 else ()) + (16, 32, 48, 64, 96, 128):
+            for hpw in (64, 16, 4):
+                for blocks in ((0,) if streams == 1 else (0, 64, 128, 256)):
+                    if hpw == 64 and blocks:
+                        continue
+                    r = rate(cls, kw, G.SUBMEAN_EXACT, dict(GLFER_EXACT_PIECE_MB=piece, GLFER_EXACT_STREAMS=streams, GLFER_MEANS_HPW=hpw,
+                                                           GLFER_MEANS_BLOCKS=blocks))
+                    print("    streams %d  piece %4d MB  hops/wavefront %2d  means blocks %4d: %8.1f M (%.3f)"
+                          % (streams, piece, hpw, blocks, r, r / fast), flush=True)

@@ -10,7 +10,7 @@ pcm = np.round(synth(hops * hop, seed=37) * 32767).astype(np.int16)
 path = "/tmp/ra_long.wav"
 with wave.open(path, "wb") as w:
     w.setnchannels(1); w.setsampwidth(2); w.setframerate(48000); w.writeframes(pcm.tobytes())
-sp = G.Spectrogram(G.FftParams(n=n, window_type=0, overlap=0.5, sub_mean=2, sample_format=G.SAMPLES_S16))
+sp = G.Spectrogram(G.FftParams(n=n, window_type=0, overlap=0.5, sub_mean=G.SUBMEAN_EXACT, sample_format=G.SAMPLES_S16))
 L = G.api.lib()
 out = np.empty((hops, 513), np.float32)
 nf = C.c_size_t(0)
