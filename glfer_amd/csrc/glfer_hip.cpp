@@ -952,6 +952,7 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   glfer::ingest_ring_free(p->ring);
   for (hipStream_t a : p->aux)
     if (a) (void)hipStreamDestroy(a);
+  for (hipEvent_t ev : p->aux_events) (void)hipEventDestroy(ev);
   delete p;
 }
 
@@ -1320,15 +1321,27 @@ static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroPara
   if (e != hipSuccess) return hip_fail(e, "scratch (hop means)");
   SpectroParams q = bs;
   q.means = means - hop_lo;                                                    // indexed by GLOBAL hop (= frame) index
-  if (nstreams > 1) {                                                          // the side streams, once per plan
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < nstreams - 1 && e == hipSuccess; i++)
-      if (!p->aux[i]) e = hipStreamCreateWithFlags(&p->aux[i], hipStreamNonBlocking);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      nstreams = 1;
-      e = hipSuccess;
+  static std::mutex aux_mu;
+  bool own_aux = false;
+  if (nstreams > 1) {                                                          // the side streams and their events, once per plan
+    std::lock_guard<std::mutex> lock(aux_mu);
+    if (p->aux_busy) {
+      nstreams = 1;                                                            // another call of this plan is on them: stay on the caller's stream
+    } else {
+      for (int i = 0; i < nstreams - 1 && e == hipSuccess; i++)
+        if (!p->aux[i]) e = hipStreamCreateWithFlags(&p->aux[i], hipStreamNonBlocking);
+      while (e == hipSuccess && p->aux_events.size() < 2 * npieces + 1) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) p->aux_events.push_back(ev);
+      }
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        nstreams = 1;
+        e = hipSuccess;
+      } else {
+        p->aux_busy = own_aux = true;
+      }
     }
   }
   if (nstreams <= 1) {
@@ -1345,21 +1358,20 @@ static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroPara
     return e == hipSuccess ? GLFER_OK : hip_fail(e, "estimator launch (given hop means)");
   }
   // means(c) on aux[0]; estimator(c) on the caller's stream (or alternately aux[1]) after means(c); means(c + 2) not before
-  // estimator(c) is done, so that at most two pieces are between their two reads at any time
+  // estimator(c) is done, so that at most two pieces are between their two reads at any time.  (An event may be recorded
+  // again once every wait on its previous record has been ENQUEUED -- a wait captures the record it follows -- so the
+  // plan's events serve call after call.)
   hipStream_t sm = p->aux[0];
-  std::vector<hipEvent_t> ev_m(npieces, nullptr), ev_e(npieces, nullptr);
-  hipEvent_t ev_fork = nullptr;
-  auto make = [&](hipEvent_t *ev) { return hipEventCreateWithFlags(ev, hipEventDisableTiming); };
-  e = make(&ev_fork);
-  if (e == hipSuccess) e = hipEventRecord(ev_fork, st);                        // the stream's samples (and the scratch) are the caller's stream's
+  hipEvent_t *ev_m = p->aux_events.data(), *ev_e = ev_m + npieces, ev_fork = p->aux_events[2 * npieces];
+  e = hipEventRecord(ev_fork, st);                                             // the samples (and the scratch) are ordered on the caller's stream
   if (e == hipSuccess) e = hipStreamWaitEvent(sm, ev_fork, 0);
   if (e == hipSuccess && nstreams > 2) e = hipStreamWaitEvent(p->aux[1], ev_fork, 0);
+  size_t launched = 0;
   for (size_t c = 0; c < npieces && e == hipSuccess; c++) {
     const size_t f0 = b0 + c * piece, f1 = std::min(b1, f0 + piece);
     const size_t h0 = c == 0 ? hop_lo : f0;
     if (c >= 2) e = hipStreamWaitEvent(sm, ev_e[c - 2], 0);
     if (e == hipSuccess) e = launch_reference_means(p, bs, h0, f1 - h0, means + (h0 - hop_lo), c == 0 ? 0 : means_blocks, sm);
-    if (e == hipSuccess) e = make(&ev_m[c]);
     if (e == hipSuccess) e = hipEventRecord(ev_m[c], sm);
     hipStream_t se = (nstreams > 2 && (c & 1)) ? p->aux[1] : st;
     if (e == hipSuccess) e = hipStreamWaitEvent(se, ev_m[c], 0);
@@ -1367,23 +1379,21 @@ static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroPara
     q.nframes = (int)(f1 - f0);
     q.psd = bs.psd + (f0 - b0) * (size_t)p->bins;
     if (e == hipSuccess) e = launch_by_n(q, p->n, se);
-    if (e == hipSuccess) e = make(&ev_e[c]);
     if (e == hipSuccess) e = hipEventRecord(ev_e[c], se);
+    if (e == hipSuccess) launched = c + 1;
   }
-  // join: everything the side streams were given completes before the caller's stream goes on (also on an error path)
-  for (size_t c = 0; c < npieces; c++) {
-    if (ev_e[c] && (nstreams > 2 && (c & 1))) (void)hipStreamWaitEvent(st, ev_e[c], 0);
-    if (ev_m[c] && c + 1 == npieces) (void)hipStreamWaitEvent(st, ev_m[c], 0);
-  }
-  if (e != hipSuccess) {                                                       // a launch failed midway: the side stream may hold work that no estimator waited for
+  // join: the caller's stream goes on after everything the side streams were given
+  if (nstreams > 2)
+    for (size_t c = launched >= 2 ? launched - 2 : 0; c < launched; c++)
+      if (c & 1) (void)hipStreamWaitEvent(st, ev_e[c], 0);
+  if (e != hipSuccess) {                                                       // a launch failed midway: the side streams may hold work nothing waits for
     (void)hipStreamSynchronize(sm);
     if (nstreams > 2) (void)hipStreamSynchronize(p->aux[1]);
   }
   glfer::scratch_free(means, st);
-  if (ev_fork) (void)hipEventDestroy(ev_fork);
-  for (size_t c = 0; c < npieces; c++) {
-    if (ev_m[c]) (void)hipEventDestroy(ev_m[c]);
-    if (ev_e[c]) (void)hipEventDestroy(ev_e[c]);
+  if (own_aux) {
+    std::lock_guard<std::mutex> lock(aux_mu);
+    p->aux_busy = false;
   }
   return e == hipSuccess ? GLFER_OK : hip_fail(e, "estimator launch (given hop means, piecewise)");
 }

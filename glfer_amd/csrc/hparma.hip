@@ -94,6 +94,30 @@ __device__ __forceinline__ void wave_sum3(double &a, double &b, double &c, bool 
   b = from(2);
 }
 
+// Sums of a, b, c over the 16 lanes of a DPP row, the SAME bits in every lane of the row (the lanes take a rotation's
+// skip / swap decisions one by one): a butterfly whose two partners add the same two values -- x + y and y + x -- at every
+// level (lane ^ 1, lane ^ 2, then the quads 0 <-> 1, 2 <-> 3 by row_half_mirror and the halves by row_mirror: every quad is
+// uniform by then, so a mirror is a swap).  Four rows of a wavefront run four different rotations side by side.
+__device__ __forceinline__ void row_sum3(double &a, double &b, double &c) {
+  auto dpp = [](double x, auto ctrl) -> double {
+    constexpr int C = decltype(ctrl)::value;
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    // (mov_dpp: no previous value to merge -- all rows and banks are written -- so no register has to be filled in first)
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, C, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), C, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  };
+  auto level = [&](auto ctrl) {
+    a += dpp(a, ctrl);
+    b += dpp(b, ctrl);
+    c += dpp(c, ctrl);
+  };
+  level(std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  level(std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  level(std::integral_constant<int, 0x141>{});   // row_half_mirror
+  level(std::integral_constant<int, 0x140>{});   // row_mirror
+}
+
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -117,7 +141,7 @@ __device__ __forceinline__ float hp_sample(__amdgpu_buffer_rsrc_t rsrc, unsigned
 
 template <int FMT>
 __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
-  extern __shared__ float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const SpectroParams &p = hp.s;
   const int N = hp.n, t = hp.t, ncol = hp.ncol;
   const int lane = threadIdx.x;
@@ -167,7 +191,113 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
     int count = 1, sweep = 0;
     const bool fast = t <= 128 && ncol <= 64;
     const bool odd = (lane & 1) != 0, bit1 = (lane & 2) != 0;
-    while (count > 0 && sweep <= sweepmax) {
+    // Round 4: ROTATIONS ON AN ANTI-DIAGONAL RUN SIDE BY SIDE.  compute_svd's rotation (j, k) touches columns j and k of
+    // A and Q only, its skip tests are local to the pair and `count` is a per-sweep sum (util.c:301-355); two rotations
+    // that share a column come in the same order by j + k as in the reference's row-cyclic walk ((j', j), (j, k') and
+    // (j', k) with j' < j, k' < k all have a smaller index sum than (j, k); (j, k''), (j'', k), (k, m) a larger one), and
+    // rotations that share none commute exactly.  So the pairs with j + k = d are independent and see the inputs they see
+    // in the reference: up to 16 per step of d and 2 ncol - 3 steps per sweep instead of ncol (ncol - 1) / 2 rotations
+    // one after the other.  A rotation is laid over a 16-lane DPP row -- a lane holds rows 4 l .. 4 l + 3 and 64 + 4 l ..
+    // 64 + 4 l + 3 of the two columns (two conflict-free ds_read_b128 a column) and rows l, l + 16 ... of Q -- so a wavefront
+    // does FOUR rotations at once, the sums need four row-local butterfly levels instead of six wave-wide ones, and the
+    // ~80 double-precision instructions of the angle (two divisions, two square roots) are issued once for four rotations.
+    // Every rotation's arithmetic is what it was; the sums associate differently (eight rows in a lane, then the
+    // butterfly), as they already differed from the reference's row-by-row order.  t a multiple of 4.
+    const bool diag = t <= 128 && ncol <= 64 && (t & 3) == 0 && ncol >= 2;
+    typedef float v4f32 __attribute__((ext_vector_type(4)));
+    while (diag && count > 0 && sweep <= sweepmax) {
+      const int grp = lane >> 4, l16 = lane & 15;
+      const int r0 = 4 * l16, r1 = 64 + 4 * l16;
+      const bool c0 = r0 < t, c1 = r1 < t;
+      int skipped = 0;
+      for (int d = 1; d <= 2 * ncol - 3; d++) {
+        const int jlo = d > ncol - 1 ? d - (ncol - 1) : 0, cnt = ((d - 1) >> 1) - jlo + 1;
+        for (int s0 = 0; s0 < cnt; s0 += 4) {
+          const bool act = s0 + grp < cnt;
+          const int j = jlo + (act ? s0 + grp : 0), k = d - j;
+          float *Aj = A + j * t, *Ak = A + k * t, *Qj = Q + j * ncol, *Qk = Q + k * ncol;
+          const v4f32 z4 = v4f32{0.0f, 0.0f, 0.0f, 0.0f};
+          const v4f32 aj0 = c0 ? *reinterpret_cast<const v4f32 *>(Aj + r0) : z4, ak0 = c0 ? *reinterpret_cast<const v4f32 *>(Ak + r0) : z4;
+          const v4f32 aj1 = c1 ? *reinterpret_cast<const v4f32 *>(Aj + r1) : z4, ak1 = c1 ? *reinterpret_cast<const v4f32 *>(Ak + r1) : z4;
+          float qj[4], qk[4];
+#pragma unroll
+          for (int m = 0; m < 4; m++) {                  // (unconditional loads of a clamped row: a branch per load would wait for each in turn)
+            const int qr = l16 + 16 * m < ncol ? l16 + 16 * m : ncol - 1;
+            qj[m] = Qj[qr];
+            qk[m] = Qk[qr];
+          }
+          double pp = 0.0, qq = 0.0, rr = 0.0;          // (float products are exact in double: fma and multiply + add round alike)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const double a = aj0[i], b = ak0[i];
+            pp = __builtin_fma(a, b, pp);
+            qq = __builtin_fma(a, a, qq);
+            rr = __builtin_fma(b, b, rr);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const double a = aj1[i], b = ak1[i];
+            pp = __builtin_fma(a, b, pp);
+            qq = __builtin_fma(a, a, qq);
+            rr = __builtin_fma(b, b, rr);
+          }
+          row_sum3(pp, qq, rr);
+          bool rotate = act;
+          if (qq * rr < 2.22e-16) rotate = false;                                  // util.c:316-320
+          else if (pp * pp < 1.0e-12 * (qq * rr)) rotate = false;                  // util.c:321-325, without the division (qq * rr > 0 here)
+          skipped += (act && !rotate) ? 1 : 0;
+          if (rotate) {
+            double cs, sn;
+            if (qq < rr) {                                                          // util.c:327-335
+              cs = 0.0;
+              sn = 1.0;
+            } else {
+              qq -= rr;
+              const double v = sqrt(4.0 * pp * pp + qq * qq);
+              cs = sqrt((v + qq) / (2.0 * v));
+              sn = pp / (v * cs);
+            }
+            auto turn = [&](float xj, float xk, float &oj, float &ok) {            // util.c:338-350
+              const double a = xj, b = xk;
+              oj = (float)(a * cs + b * sn);
+              ok = (float)(-a * sn + b * cs);
+            };
+            float nj[4], nk[4];
+            if (c0) {
+#pragma unroll
+              for (int i = 0; i < 4; i++) turn(aj0[i], ak0[i], nj[i], nk[i]);
+              *reinterpret_cast<v4f32 *>(Aj + r0) = v4f32{nj[0], nj[1], nj[2], nj[3]};
+              *reinterpret_cast<v4f32 *>(Ak + r0) = v4f32{nk[0], nk[1], nk[2], nk[3]};
+            }
+            if (c1) {
+#pragma unroll
+              for (int i = 0; i < 4; i++) turn(aj1[i], ak1[i], nj[i], nk[i]);
+              *reinterpret_cast<v4f32 *>(Aj + r1) = v4f32{nj[0], nj[1], nj[2], nj[3]};
+              *reinterpret_cast<v4f32 *>(Ak + r1) = v4f32{nk[0], nk[1], nk[2], nk[3]};
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+              if (16 * m < ncol) {                                                  // (uniform: slots past the last row of Q are skipped)
+                float oj, ok;
+                turn(qj[m], qk[m], oj, ok);
+                if (l16 + 16 * m < ncol) {
+                  Qj[l16 + 16 * m] = oj;
+                  Qk[l16 + 16 * m] = ok;
+                }
+              }
+            }
+          }
+          wave_fence();                                  // the next step's rotations read these columns from other lanes
+        }
+      }
+      // `count` (util.c:298, 318, 323): the sweep's pairs minus the skipped ones, over the four rows
+      int sk = 0;
+#pragma unroll
+      for (int g = 0; g < 4; g++) sk += __builtin_amdgcn_readlane(skipped, 16 * g);
+      count = ncol * (ncol - 1) / 2 - sk;
+      sweep++;
+    }
+    while (!diag && count > 0 && sweep <= sweepmax) {
       count = ncol * (ncol - 1) / 2;
       if (fast) {
         const int i0 = lane, i1 = lane + 64;

@@ -113,6 +113,8 @@ struct glfer_hip_plan {
   // side streams of the piecewise mean pass (glfer_hip.cpp launch_mean_inkernel): [0] runs the hop means of piece c+1
   // beside piece c's estimator launch, [1] takes every other estimator launch; made on first use
   hipStream_t aux[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> aux_events;  // their events, made once (hipEventCreate per piece cost more than a piece's kernels)
+  bool aux_busy = false;               // one call at a time forks onto the side streams; a second one meanwhile stays on its own stream
 };
 
 // frames [first, first+nframes) of a device-resident stream (virtual base allowed); psd and/or
