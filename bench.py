@@ -58,22 +58,27 @@ KERNELS = {"fft1k": ("spectro16h_kernel<10, ..., SHIFT 8> (register reuse across
            "hparma": ("hparma_kernel", None)}
 
 
+# what binds each row (confirmed by the counter passes under profiles/): the roofline object's `bound`
+BOUND = {"fft1k": "hbm", "fft": "hbm", "mtm": "valu", "mtm75": "valu", "mtm16k": "valu", "hparma": "fp64-valu"}
+
+# Context for a row's fraction.  NOTHING in these strings is measured by this run: every figure is quoted from the committed
+# file named beside it (earlier rounds' ablation and counter passes); this run's own measurements are the numeric fields.
 ROOFLINE_NOTES = {
-    "mtm": "not HBM-bound (traffic 1.00x algorithmic): FP32 VALU at two wavefronts per SIMD (248 VGPRs, 2 x 35 KB LDS). "
-           "Counters (profiles/r03_stall_picture.txt): a wavefront executes VALU 51 % / LDS 10 % of its time and waits 34.5 %; "
-           "VALU pipe 47-48 %, LDS array 33 % busy. Measured ceiling of this instruction stream with the exchange removed "
-           "(tools/xbench GLFER_ABL, profiles/r01_xbench_exchange_ablation.txt): 98 M frames/s = 0.30 of the HBM roofline; with the "
-           "sample stream served from L2 instead of HBM (same instructions): 93-95 M -- on this chip an L2-hit load (the taper "
-           "tables) waits behind other wavefronts' HBM misses (tools/tcpbench), and no placement of the loads gets that back "
+    "mtm": "from profiles/ (not this run): not HBM-bound (traffic 1.00x algorithmic): FP32 VALU at two wavefronts per SIMD (248 VGPRs, "
+           "2 x 35 KB LDS); a wavefront executes VALU 51 % / LDS 10 % of its time and waits 34.5 %, VALU pipe 47-48 %, LDS array 33 % busy "
+           "(profiles/r03_stall_picture.txt); ceiling of this instruction stream with the exchange removed 98 M frames/s "
+           "(profiles/r01_xbench_exchange_ablation.txt), with the samples served from L2 instead of HBM 93-95 M "
            "(profiles/r03_y_sample_misses.txt)",
-    "mtm75": "FP32-VALU-bound at two wavefronts per SIMD, as the headline (profiles/r03_stall_picture.txt): see valu.frac",
-    "mtm16k": "FP32-VALU-bound on this chip (SURVEY 7): see valu.frac",
-    "fft": "HBM-bound. Measured ceiling (tools/mixbench, profiles/r03_streaming_ceilings.txt): a kernel that only streams this "
-           "frame's 4 KB in : 8 KB out reaches 0.65-0.66 of the 8 TB/s spec with aligned 16-byte stores and 0.58-0.61 with this "
-           "interface's dense rows of 2049 floats (4-byte stores, 256-byte instructions off the 128-byte lines); read-only 0.79",
-    "fft1k": "HBM-bound. Measured ceiling (tools/mixbench, profiles/r03_streaming_ceilings.txt): a kernel that only streams this "
-             "frame's 2 KB in : 2 KB out reaches 0.63-0.64 of the 8 TB/s spec (read-only 0.79, write-only 0.71, copy 0.69)",
-    "hparma": "not HBM-bound (24.6 KB per frame of algorithmic traffic): compute/latency-bound, see valu (FP64)",
+    "mtm75": "from profiles/ (not this run): FP32-VALU-bound at two wavefronts per SIMD, as the headline (profiles/r03_stall_picture.txt)",
+    "mtm16k": "from profiles/ (not this run): bound by its barrier and exchanges at two wavefronts per SIMD, VALU 41 % / waiting 45 % of a "
+              "wavefront's time (profiles/r03_stall_picture.txt)",
+    "fft": "from profiles/ (not this run): HBM-bound; a kernel that only streams this frame's 4 KB in : 8 KB out reaches 0.65-0.66 of the "
+           "8 TB/s spec with aligned 16-byte stores and 0.58-0.61 into this interface's dense rows of 2049 floats, read-only 0.79 "
+           "(tools/mixbench, profiles/r03_streaming_ceilings.txt)",
+    "fft1k": "from profiles/ (not this run): HBM-bound; a kernel that only streams this frame's 2 KB in : 2 KB out reaches 0.63-0.64 of the "
+             "8 TB/s spec (read-only 0.79, write-only 0.71, copy 0.69; profiles/r03_streaming_ceilings.txt)",
+    "hparma": "not HBM-bound (24.6 KB per frame of algorithmic traffic): bound by the double-precision vector instructions of the Jacobi "
+              "rotations, see valu (FP64)",
 }
 
 
@@ -220,20 +225,20 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
-def make_params(G, workload):
+def make_params(G, workload, **kw):
     name, n, overlap, nw, kmax, _, _ = WORKLOADS[workload]
     if workload in ("mtm", "mtm16k", "mtm75"):
-        return G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax)
+        return G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, **kw)
     if workload == "hparma":
-        return G.HparmaParams(n=n, overlap=overlap, t=128, p_e=32)
-    return G.FftParams(n=n, window_type=G.WINDOWS["hanning"], overlap=overlap)
+        return G.HparmaParams(n=n, overlap=overlap, t=128, p_e=32, **kw)
+    return G.FftParams(n=n, window_type=G.WINDOWS["hanning"], overlap=overlap, **kw)
 
 
 def pmc_summary(pmc_name):
     """Committed rocprofv3 PMC summary of a workload (newest round first): (dict, path) or (None, None)."""
     if pmc_name is None:
         return None, None
-    for rnd in ("r03_", "r02_", "r01_"):
+    for rnd in ("r04_", "r03_", "r02_", "r01_"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", rnd + pmc_name))), "profiles/" + rnd + pmc_name
         except Exception:
@@ -241,7 +246,7 @@ def pmc_summary(pmc_name):
     return None, None
 
 
-def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local, rehearse):
+def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local, rehearse, params_kw=None, avg_depth=0, dc=0.0):
     """W untimed + K timed passes of one workload over this rank's frame range; the timed region is
     bracketed by barrier + synchronize on both sides and the MAX over ranks is taken.  Returns a dict
     (every rank; only rank 0 uses it)."""
@@ -249,7 +254,7 @@ def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local,
     dev = torch.device("cuda", local)
     frames = frames or default_frames               # a 2^30-sample stream per GPU
     fs = 8000.0 if workload == "fft1k" else 48000.0
-    sp = G.Spectrogram(make_params(G, workload), device=local)
+    sp = G.Spectrogram(make_params(G, workload, **(params_kw or {})), device=local)
     hop, bins = sp.hop, sp.bins
     # Weak scaling: the job is world*frames frames of one long stream; this rank owns the
     # contiguous frame range frame_range() gives it and holds only the samples of its window
@@ -258,10 +263,21 @@ def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local,
     first, count = frame_range(frames * world, rank, world)
     begin, end = sample_window(first, count, hop, n)
     shard = synth_on_device(torch, end - begin, dev, seed=rank, fs=fs)
+    if dc:
+        shard += dc                                   # a DC level: what mean removal is for (and where the order of the hop's sum shows)
     psd = torch.empty((count, bins), dtype=torch.float32, device=dev)
+    avg_out = None
+    if avg_depth:                                     # update_avg_plain (avg.c:108-159) over the rows, the fused kernel: 8 B out per bin
+        avg_out = (torch.empty((count, bins), dtype=torch.float64, device=dev), torch.empty((count, 4), dtype=torch.float64, device=dev))
+    import ctypes as C
 
     def step():
         run_shard(sp, shard, begin, first, count, out=psd)
+        if avg_depth:
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = G.api.lib().glfer_hip_avg_device(G.AVG_PLAIN, psd.data_ptr(), count, bins, bins, avg_depth, 0, bins, 0,
+                                                  avg_out[0].data_ptr(), avg_out[1].data_ptr(), st)
+            assert rc == 0, rc
 
     def barrier():
         torch.cuda.synchronize()
@@ -293,7 +309,7 @@ def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local,
            "ms_per_step": dt / steps * 1e3, "b_alg": 4 * hop + 4 * bins,
            "kernel_ms_first": each[0], "kernel_ms_min": min(each), "kernel_ms_max": max(each)}
     res["achieved_gbs"] = frames * res["b_alg"] / (kernel_ms * 1e-3) / 1e9
-    del shard, psd
+    del shard, psd, avg_out
     sp.close()
     torch.cuda.empty_cache()
     return res
@@ -365,6 +381,99 @@ def parity_vs_oracle(torch, G, workload, local, frames=64):
             "norms": "per frame max|d|/max(ref) and ||d||2/||ref||2, worst frame", "tolerance": 1e-5}
 
 
+def roofline_of(res, workload, traffic=None, traffic_src=None, kernel_ms_triplet=None):
+    """The contract's roofline object.  achieved / peak / frac are ALGORITHMIC HBM bytes over the kernel's time against
+    the 8 TB/s spec -- the fraction north_star asks for on every row -- and `bound` says which resource actually binds
+    the row; where that is not HBM the binding resource's own fraction rides along as `binding`."""
+    v = hparma_view(res) if workload == "hparma" else valu_view(res)
+    r = {"bound": BOUND[workload], "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic,
+         "algorithmic_bytes_per_frame": res["b_alg"], "algorithmic_bytes_per_launch": res["frames"] * res["b_alg"],
+         "kernel": KERNELS[workload][0], "kernel_ms": res["kernel_ms"], "note": ROOFLINE_NOTES.get(workload, "")}
+    if traffic_src:
+        r["traffic_unit"] = "bytes per launch, rocprofv3 PMC (%s)" % traffic_src
+    if kernel_ms_triplet:
+        r["kernel_ms_first_min_max"] = kernel_ms_triplet
+    if BOUND[workload] == "valu":
+        r["binding"] = {"resource": "fp32 vector ALU", "achieved": v["achieved_Tops"], "peak": v["peak_Tops"], "unit": "T lane-op/s",
+                        "frac": v["frac"], "peak_is": "nominal: 256 CU x 4 SIMD x 32 lanes x %.1f GHz; the counter passes ran this kernel at "
+                        "2.03-2.28 GHz (profiles/r03_stall_picture.txt)" % CLOCK_GHZ}
+    elif BOUND[workload] == "fp64-valu":
+        r["binding"] = {"resource": "fp64 vector ALU", "achieved": v["achieved_TFLOPs"], "peak": v["peak_TFLOPs"], "unit": "TFLOP/s (counted lower bound)",
+                        "frac": v["frac"]}
+    return r
+
+
+def end_to_end(torch, G, local, frames=131072, reps=3):
+    """SURVEY 8(d)'s separate row: the headline workload host memory to host memory -- a PINNED 16-bit PCM buffer (what a
+    WAV file holds, wav_fmt.c:111-114) in, pinned float rows out, through glfer_hip_spectrogram_host's two-stream ring
+    (source.c:112-171 as a batch).  PCIe-inclusive: never the headline value."""
+    import numpy as np
+    name, n, overlap, nw, kmax, _, _ = WORKLOADS["mtm"]
+    sp = G.Spectrogram(G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sample_format=G.SAMPLES_S16), device=local)
+    x = synth_on_device(torch, frames * sp.hop, torch.device("cuda", local), seed=7)
+    pcm = G.pinned_empty((frames * sp.hop,), np.int16)
+    pcm[:] = (x * 32767.0).round().to(torch.int16).cpu().numpy()
+    del x
+    best, first = 1e9, None
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        rows = sp.run_host(pcm, pinned=True)
+        dt = time.perf_counter() - t0
+        if first is None:
+            first = dt                                  # (the first call makes the plan's ring: pinned and device buffers)
+        else:
+            best = min(best, dt)
+        assert rows.shape == (frames, sp.bins)
+        del rows
+    nbytes = frames * (2 * sp.hop + 4 * sp.bins)
+    sp.close()
+    return {"workload": name + ", 16-bit PCM", "path": "pinned host samples -> glfer_hip_spectrogram_host -> pinned host rows",
+            "frames": frames, "value": frames / best, "unit": "frames/s", "seconds": best, "first_call_seconds": first,
+            "pcie_gbs_both_directions": nbytes / best / 1e9, "bytes_in_per_frame": 2 * sp.hop, "bytes_out_per_frame": 4 * sp.bins,
+            "note": "best of %d calls after the first; PCIe Gen5 x16 is ~63 GB/s each way" % reps}
+
+
+def c4_as_worded(torch, G, local):
+    """BASELINE config 4 as worded: a 1-hour 48 kHz mono 16-bit WAV (346 MB, written to /dev/shm here) through
+    glfer_hip_spectrogram_wav_multi on every visible GPU -- multitaper N = 16384, 9 tapers -- wall seconds, file to rows
+    in host memory (source.c:193, wav_fmt.c:45-121 as a batch)."""
+    import struct
+    import tempfile
+    name, n, overlap, nw, kmax, _, _ = WORKLOADS["mtm16k"]
+    nsamples = 3600 * 48000
+    d = "/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(d, "glfer_c4_%d.wav" % os.getpid())
+    try:
+        x = synth_on_device(torch, nsamples, torch.device("cuda", local), seed=4)
+        pcm = (x * 32767.0).round().to(torch.int16).cpu().numpy()
+        del x
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 48000, 96000, 2, 16))
+            f.write(b"data" + struct.pack("<I", pcm.nbytes))
+            pcm.tofile(f)
+        del pcm
+        devices = list(range(torch.cuda.device_count()))
+        params = G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sample_format=G.SAMPLES_S16)
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rows = G.spectrogram_wav_workers(params, path, devices)
+            times.append(time.perf_counter() - t0)
+            frames = rows.shape[0]
+            del rows
+        return {"workload": "C4 as worded: multitaper N=16384 NW=4.5 mtm_k=8 over a 1-hour 48 kHz 16-bit mono WAV", "file_bytes": 44 + 2 * nsamples,
+                "gpus": len(devices), "frames": frames, "wall_seconds": min(times), "first_call_seconds": times[0],
+                "value": frames / min(times), "unit": "frames/s",
+                "path": "glfer_hip_spectrogram_wav_multi: every worker reads its part of the file, rows to pageable host memory",
+                "note": "file in %s (page cache); best of 3 calls, each with its own plans and rings" % d}
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
 # the default run's secondary rows (BASELINE.json configs other than the headline): workload -> timed steps
 SECONDARY = (("fft1k", 5), ("fft", 5), ("mtm75", 5), ("mtm16k", 5), ("hparma", 5))
 SECONDARY_WARMUP = 3    # untimed passes per secondary row: the first pass over a freshly allocated 8 GB of rows runs 10 % slow on a fresh box
@@ -433,15 +542,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU)" if rehearse else ""),
             "config": {"workload": res["name"], "frames_per_gpu_per_step": frames, "n": n, "hop": hop,
                        "tapers": res["ntapers"], "sharding": "frame ranges, no collective"},
-            "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch, rocprofv3 PMC (%s)" % traffic_src,
-                         "algorithmic_bytes_per_launch": frames * b_alg,
-                         "kernel": kernel,
-                         "kernel_ms": kernel_ms,
-                         "kernel_ms_first_min_max": [res["kernel_ms_first"], res["kernel_ms_min"], res["kernel_ms_max"]],
-                         "algorithmic_bytes_per_frame": b_alg,
-                         "note": ROOFLINE_NOTES.get(args.workload, "")},
+            "roofline": roofline_of(res, args.workload, traffic, traffic_src, [res["kernel_ms_first"], res["kernel_ms_min"], res["kernel_ms_max"]]),
             "hbm_gbs_aggregate": res["fps"] * b_alg / 1e9,
         }
         line["valu"] = valu_view(res)
@@ -466,15 +567,31 @@ def main():
             r = measure(torch, G, dist, wl, 0, k, SECONDARY_WARMUP, world, rank, local, rehearse)
             row = {"workload": r["name"], "key": wl, "value": r["fps"], "unit": "frames/s", "steps": k, "warmup": SECONDARY_WARMUP,
                    "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"], "kernel": KERNELS[wl][0],
-                   "frames_per_step": r["frames"],
-                   "roofline": {"bound": "hbm", "achieved": r["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": r["achieved_gbs"] / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": r["b_alg"],
-                                "note": ROOFLINE_NOTES.get(wl, "")}}
+                   "frames_per_step": r["frames"], "roofline": roofline_of(r, wl)}
             v = hparma_view(r) if wl == "hparma" else valu_view(r)
             row["valu_frac"] = v["frac"]
             rows.append(row)
+        # the reference's DEFAULT setting -- per-hop mean removal on (glfer.c:275), the hop summed in the reference's own order
+        # (cfg.sub_mean = 1) -- on the two periodogram rows and the headline, on a stream with a DC level
+        for wl, k in (("fft1k", 5), ("fft", 5), ("mtm", 5)):
+            r = measure(torch, G, dist, wl, 0, k, SECONDARY_WARMUP, world, rank, local, rehearse, params_kw=dict(sub_mean=G.SUBMEAN_EXACT), dc=0.1)
+            rows.append({"workload": r["name"] + ", per-hop mean removal on (the reference's summation order)", "key": wl + "+mean", "value": r["fps"],
+                         "unit": "frames/s", "steps": k, "warmup": SECONDARY_WARMUP, "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"],
+                         "frames_per_step": r["frames"], "roofline": roofline_of(r, wl)})
+        # SURVEY 8(d)'s avg-on row: C2 followed by update_avg_plain, depth 4, over the whole band (avg.c:108-159; one fused kernel)
+        r = measure(torch, G, dist, "fft", 262144, 5, SECONDARY_WARMUP, world, rank, local, rehearse, avg_depth=4)
+        rows.append({"workload": r["name"] + " + update_avg_plain depth 4 (avg_fused_kernel, 8 B out per bin)", "key": "fft+avg", "value": r["fps"],
+                     "unit": "frames/s", "steps": 5, "warmup": SECONDARY_WARMUP, "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"],
+                     "frames_per_step": r["frames"],
+                     "roofline": {"bound": "hbm", "achieved": r["frames"] * (4 * r["hop"] + 4 * r["bins"] + 12 * r["bins"]) / (r["kernel_ms"] * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": r["frames"] * (4 * r["hop"] + 4 * r["bins"] + 12 * r["bins"]) / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_frame": 4 * r["hop"] + 4 * r["bins"] + 12 * r["bins"],
+                                  "note": "both launches: the hop in, the PSD row out, the row in again and 8 B per bin of averages out"}})
         line["secondary"] = rows
         line["parity"] = parity_vs_oracle(torch, G, args.workload, local)
+        line["end_to_end"] = end_to_end(torch, G, local)
+        line["c4_as_worded"] = c4_as_worded(torch, G, local)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             _, n, overlap, nw, kmax, _, cpu_frames = WORKLOADS[args.workload]

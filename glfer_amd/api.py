@@ -45,6 +45,8 @@ EXPORTS = [
     "glfer_hip_spectrogram_wav_multi", "glfer_hip_spectrogram_wav_workers", "glfer_hip_levels_host",
     "glfer_hip_waterfall_map_device", "glfer_hip_waterfall_host_workers", "glfer_hip_waterfall_wav_workers",
     "glfer_hip_waterfall_wav_multi", "glfer_hip_submean_exact_device",
+    # round 4
+    "glfer_hip_numa_node_of_bus_id", "glfer_hip_numa_node_cpus",
 ]
 
 
@@ -157,6 +159,8 @@ def lib():
     L.glfer_hip_levels_host.argtypes = [dispp, vp, sz, vp, C.c_int]
     L.glfer_hip_waterfall_map_device.argtypes = [dispp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, sz, C.c_int,
                                                  vp, vp, vp, vp]
+    L.glfer_hip_numa_node_of_bus_id.argtypes = [C.c_char_p, C.c_char_p]
+    L.glfer_hip_numa_node_cpus.argtypes = [C.c_int, C.c_char_p, vp, sz]
     L.glfer_hip_scratch_trim.argtypes = [C.c_int, sz]
     L.glfer_hip_scratch_trim.restype = sz
     L.glfer_hip_scratch_held.argtypes = [C.c_int]

@@ -13,6 +13,8 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <cctype>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +24,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <sched.h>
 
 using glfer::DeviceGuard;
 using glfer::hip_fail;
@@ -327,6 +331,59 @@ void frame_range(size_t total, unsigned rank, unsigned world, size_t *first, siz
 
 extern "C" {
 
+// The NUMA node of a PCI function: <sysfs_root>/bus/pci/devices/<bus id, lower case>/numa_node (sysfs_root NULL = "/sys").
+// -1: unknown (no such file, an unparsable one, or the kernel's own -1 on a one-node host).
+int glfer_hip_numa_node_of_bus_id(const char *bus_id, const char *sysfs_root) {
+  if (!bus_id || !*bus_id) return -1;
+  std::string id(bus_id);
+  for (char &c : id) c = (char)tolower((unsigned char)c);
+  if (id.find("..") != std::string::npos || id.find('/') != std::string::npos) return -1;
+  if (id.size() == 7) id = "0000:" + id;                                  // "c1:00.0": the domain left out
+  const std::string path = std::string(sysfs_root ? sysfs_root : "/sys") + "/bus/pci/devices/" + id + "/numa_node";
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node < 0 ? -1 : node;
+}
+
+// The CPUs of a node: <sysfs_root>/devices/system/node/node<N>/cpulist ("0-15,128-143") as a bit mask (bit c of
+// mask[c / 8]); returns the number of CPUs set, -1 when the list cannot be read or parsed.
+int glfer_hip_numa_node_cpus(int node, const char *sysfs_root, unsigned char *mask, size_t mask_bytes) {
+  if (node < 0 || !mask || !mask_bytes) return -1;
+  const std::string path = std::string(sysfs_root ? sysfs_root : "/sys") + "/devices/system/node/node" + std::to_string(node) + "/cpulist";
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  char text[4096];
+  const size_t got = fread(text, 1, sizeof text - 1, f);
+  fclose(f);
+  text[got] = 0;
+  memset(mask, 0, mask_bytes);
+  int count = 0;
+  const char *q = text;
+  while (*q) {
+    while (*q == ',' || *q == ' ' || *q == '\n') q++;
+    if (!*q) break;
+    char *end = nullptr;
+    const long a = strtol(q, &end, 10);
+    if (end == q || a < 0) return -1;
+    long b = a;
+    q = end;
+    if (*q == '-') {
+      b = strtol(q + 1, &end, 10);
+      if (end == q + 1 || b < a) return -1;
+      q = end;
+    }
+    for (long c = a; c <= b; c++)
+      if ((size_t)c < mask_bytes * 8 && !(mask[c >> 3] >> (c & 7) & 1)) {
+        mask[c >> 3] |= (unsigned char)(1u << (c & 7));
+        count++;
+      }
+  }
+  return count;
+}
+
 void *glfer_hip_host_alloc(size_t bytes) {
   void *p = nullptr;
   if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
@@ -506,14 +563,49 @@ int check_devices(const int *devices, int nworkers) {
   return GLFER_OK;
 }
 
+// ---- host-side placement of a GPU's worker ("scaling risk is host-side only -- PCIe, NUMA placement of
+// pinned buffers, thread wake-ups").  A worker thread is bound to the CPUs of its GPU's NUMA node BEFORE it makes its plan
+// and its pinned ring (hipHostMalloc places pinned memory where the allocating thread runs; the rows' host copy is spread
+// over threads this one starts, which inherit the binding, so the caller's row range is first touched on that node
+// too).  The node is the GPU's PCI function's: /sys/bus/pci/devices/<bus id>/numa_node, its CPUs from
+// /sys/devices/system/node/node<N>/cpulist, intersected with what this process may use (a 1-GPU box hands a job 16 of
+// the host's cores).  Nothing is bound when the node is unknown (-1: a one-node host), the intersection is empty or
+// GLFER_NUMA_BIND=0.
+bool numa_bind_on() {
+  static const bool on = [] { const char *e = getenv("GLFER_NUMA_BIND"); return !(e && *e == '0'); }();
+  return on;
+}
+
 // runs work(r) for r = 0 .. world-1, one host thread each (this thread takes worker 0); the first
-// failure's code and text are what the caller sees
-int on_workers(unsigned world, const std::function<int(unsigned)> &work) {
+// failure's code and text are what the caller sees.  devices (may be null): worker r's GPU, for the placement above.
+int on_workers(unsigned world, const std::function<int(unsigned)> &work, const int *devices = nullptr) {
   std::vector<int> rcs(world, GLFER_OK);
   std::vector<std::string> msgs(world);
   auto run = [&](unsigned r) {
+    cpu_set_t saved, want;
+    bool bound = false;
+    if (devices && world > 1 && numa_bind_on() && sched_getaffinity(0, sizeof saved, &saved) == 0) {
+      char bus[32] = {0};
+      if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, devices[r]) == hipSuccess) {
+        unsigned char mask[CPU_SETSIZE / 8];
+        const int node = glfer_hip_numa_node_of_bus_id(bus, nullptr);
+        if (node >= 0 && glfer_hip_numa_node_cpus(node, nullptr, mask, sizeof mask) > 0) {
+          CPU_ZERO(&want);
+          int n = 0;
+          for (int c = 0; c < CPU_SETSIZE; c++)
+            if ((mask[c >> 3] >> (c & 7) & 1) && CPU_ISSET(c, &saved)) {
+              CPU_SET(c, &want);
+              n++;
+            }
+          bound = n > 0 && sched_setaffinity(0, sizeof want, &want) == 0;
+        }
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     rcs[r] = work(r);
     if (rcs[r]) msgs[r] = glfer::error_text();
+    if (bound) (void)sched_setaffinity(0, sizeof saved, &saved);          // (worker 0 is the caller's own thread)
   };
   std::vector<std::thread> th;
   for (unsigned r = 1; r < world; r++) {
@@ -568,7 +660,7 @@ int psd_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, c
     glfer_hip_plan_destroy(plan);
     if (rc) glfer::set_error_text(msg);
     return rc;
-  });
+  }, devices);
 }
 
 // The waterfall of main_window_draw (g_main.c:1099-1236) over several workers.  The level tracking is
@@ -631,7 +723,7 @@ int waterfall_workers(const glfer_hip_config *cfg, const int *devices, int nwork
     if (rc) return rc;
     e = hipMemcpy(stats.data() + w.first * 4, w.d_stats + w.lead * 4, w.count * 4 * sizeof(float), hipMemcpyDeviceToHost);
     return e == hipSuccess ? GLFER_OK : hip_fail(e, "waterfall workers: statistics");
-  });
+  }, devices);
   // (2) one walk over all columns
   if (rc == GLFER_OK) rc = glfer_hip_levels_host(disp, stats.data(), frames, levels.data(), devices[0]);
   // (3) the pixel map, each worker its own columns
@@ -662,7 +754,7 @@ int waterfall_workers(const glfer_hip_config *cfg, const int *devices, int nwork
       if (d_rgb) (void)hipFree(d_rgb);
       if (d_lev) (void)hipFree(d_lev);
       return rc;
-    });
+    }, devices);
   std::string msg = rc ? glfer::error_text() : std::string();
   release();
   if (rc) glfer::set_error_text(msg);

@@ -229,6 +229,16 @@ void glfer_hip_host_free(void *p);
 int glfer_hip_spectrogram_host_multi(const glfer_hip_config *cfg, unsigned device_mask,
                                      const void *h_stream, size_t nsamples, float *h_psd,
                                      size_t *nframes_out);
+/* Host-side placement: every worker thread of the *_multi / *_workers entries is bound, before it makes its
+ * plan and pinned ring, to the CPUs of its GPU's NUMA node -- /sys/bus/pci/devices/<bus id>/numa_node and
+ * /sys/devices/system/node/node<N>/cpulist, intersected with the CPUs this process may use -- so pinned staging memory,
+ * and the first touch of the worker's range of the caller's rows, land beside the GPU; the calling thread's own
+ * affinity is restored.  Unknown node (-1), a one-worker call or GLFER_NUMA_BIND=0: nothing is bound.  The two
+ * look-ups are exported (sysfs_root NULL = "/sys"): the node of a PCI bus id (-1 = unknown) and a node's CPUs as a bit
+ * mask (returns how many, -1 on a missing or malformed list). */
+int glfer_hip_numa_node_of_bus_id(const char *bus_id, const char *sysfs_root);
+int glfer_hip_numa_node_cpus(int node, const char *sysfs_root, unsigned char *mask, size_t mask_bytes);
+
 /* The same with the workers listed: one host thread + plan + streams + pinned ring per entry of
  * devices[0..nworkers); an ordinal may repeat (workers then share that GPU -- how a one-GPU machine
  * runs, and tests, the multi-worker path).  _multi is this with the mask's devices, one worker each. */

@@ -290,3 +290,42 @@ def test_headers_compile_as_c99(tmp_path):
                              capture_output=True, text=True).stdout
         have |= {line.split()[-1] for line in out.splitlines() if line.strip()}
     assert wanted and wanted <= have, wanted - have
+
+
+def test_numa_lookups_for_the_worker_placement(lib, tmp_path):
+    """a multi-GPU worker thread is bound to the CPUs of its GPU's NUMA node before it allocates its
+    pinned ring (ingest.cpp on_workers).  The two look-ups it uses, against a fake sysfs tree: PCI bus id -> node
+    (upper-case ids as hipDeviceGetPCIBusId prints them, a missing domain, the kernel's -1, a missing device, a
+    malformed file) and node -> CPU mask (ranges, singles, a trailing newline, a malformed list)."""
+    import ctypes as C
+    L = lib.api.lib()
+    root = tmp_path / "sys"
+    for bus, node in (("0000:c1:00.0", "3\n"), ("0000:05:00.0", "0\n"), ("0001:e5:00.0", "-1\n"), ("0000:75:00.0", "garbage\n")):
+        d = root / "bus" / "pci" / "devices" / bus
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(node)
+    for node, cpus in ((0, "0-15,128-143\n"), (3, "48-63,176-191"), (5, "7\n"), (6, "3-1\n"), (7, "0-3,x\n")):
+        d = root / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus)
+    r = str(root).encode()
+    f = L.glfer_hip_numa_node_of_bus_id
+    assert f(b"0000:C1:00.0", r) == 3 and f(b"0000:c1:00.0", r) == 3 and f(b"c1:00.0", r) == 3
+    assert f(b"0000:05:00.0", r) == 0
+    assert f(b"0001:E5:00.0", r) == -1                       # the kernel says -1: unknown
+    assert f(b"0000:75:00.0", r) == -1                       # not a number
+    assert f(b"0000:99:00.0", r) == -1                       # no such device
+    assert f(b"../../etc", r) == -1 and f(b"", r) == -1 and f(None, r) == -1
+    mask = (C.c_ubyte * 128)()
+
+    def cpus(node):
+        n = L.glfer_hip_numa_node_cpus(node, r, mask, len(mask))
+        return n, [c for c in range(1024) if mask[c >> 3] >> (c & 7) & 1]
+    n, got = cpus(0)
+    assert n == 32 and got == list(range(0, 16)) + list(range(128, 144))
+    n, got = cpus(3)
+    assert n == 32 and got == list(range(48, 64)) + list(range(176, 192))
+    assert cpus(5) == (1, [7])
+    assert cpus(6)[0] == -1 and cpus(7)[0] == -1 and cpus(9)[0] == -1 and cpus(-1)[0] == -1
+    # the real tree of this host, if it has one: a node's list parses or the call says so -- never a crash
+    assert L.glfer_hip_numa_node_cpus(0, None, mask, len(mask)) >= -1
