@@ -265,7 +265,7 @@ def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local,
     shard = synth_on_device(torch, end - begin, dev, seed=rank, fs=fs)
     if dc:
         shard += dc                                   # a DC level: what mean removal is for (and where the order of the hop's sum shows)
-    psd = torch.empty((count, bins), dtype=torch.float32, device=dev)
+    psd = torch.empty((count, sp.pitch), dtype=torch.float32, device=dev)       # (sp.pitch = bins unless cfg.psd_pitch)
     avg_out = None
     if avg_depth:                                     # update_avg_plain (avg.c:108-159) over the rows, the fused kernel: 8 B out per bin
         avg_out = (torch.empty((count, bins), dtype=torch.float64, device=dev), torch.empty((count, 4), dtype=torch.float64, device=dev))
@@ -578,6 +578,12 @@ def main():
             rows.append({"workload": r["name"] + ", per-hop mean removal on (the reference's summation order)", "key": wl + "+mean", "value": r["fps"],
                          "unit": "frames/s", "steps": k, "warmup": SECONDARY_WARMUP, "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"],
                          "frames_per_step": r["frames"], "roofline": roofline_of(r, wl)})
+        # the same C2 into rows at a 64-byte-multiple pitch (cfg.psd_pitch = 2112 floats: an interface addition); the
+        # algorithmic bytes stay the P = 2049 bins of a row, not the pitch
+        r = measure(torch, G, dist, "fft", 0, 5, SECONDARY_WARMUP, world, rank, local, rehearse, params_kw=dict(psd_pitch=2112))
+        rows.append({"workload": r["name"] + ", rows at a pitch of 2112 floats (cfg.psd_pitch)", "key": "fft+pitch2112", "value": r["fps"],
+                     "unit": "frames/s", "steps": 5, "warmup": SECONDARY_WARMUP, "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"],
+                     "frames_per_step": r["frames"], "roofline": roofline_of(r, "fft")})
         # SURVEY 8(d)'s avg-on row: C2 followed by update_avg_plain, depth 4, over the whole band (avg.c:108-159; one fused kernel)
         r = measure(torch, G, dist, "fft", 262144, 5, SECONDARY_WARMUP, world, rank, local, rehearse, avg_depth=4)
         rows.append({"workload": r["name"] + " + update_avg_plain depth 4 (avg_fused_kernel, 8 B out per bin)", "key": "fft+avg", "value": r["fps"],

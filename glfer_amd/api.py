@@ -46,7 +46,7 @@ EXPORTS = [
     "glfer_hip_waterfall_map_device", "glfer_hip_waterfall_host_workers", "glfer_hip_waterfall_wav_workers",
     "glfer_hip_waterfall_wav_multi", "glfer_hip_submean_exact_device",
     # round 4
-    "glfer_hip_numa_node_of_bus_id", "glfer_hip_numa_node_cpus",
+    "glfer_hip_numa_node_of_bus_id", "glfer_hip_numa_node_cpus", "glfer_hip_floor_device_pitched",
 ]
 
 
@@ -60,7 +60,7 @@ class Config(C.Structure):
                 ("window_type", C.c_int), ("limiter_a", C.c_float), ("enable_limiter", C.c_int),
                 ("sub_mean", C.c_int), ("history_mode", C.c_int), ("mtm_w", C.c_float),
                 ("mtm_k", C.c_int), ("sample_format", C.c_int), ("device", C.c_int),
-                ("hparma_t", C.c_int), ("hparma_p_e", C.c_int), ("lmp_av", C.c_int)]
+                ("hparma_t", C.c_int), ("hparma_p_e", C.c_int), ("lmp_av", C.c_int), ("psd_pitch", C.c_int)]
 
 
 class Display(C.Structure):
@@ -69,12 +69,12 @@ class Display(C.Structure):
     _fields_ = [("scale_type", C.c_int), ("autoscale", C.c_int), ("overlap", C.c_float),
                 ("max_level_db", C.c_float), ("min_level_db", C.c_float), ("thr_level", C.c_float),
                 ("palette", C.c_int), ("first_buffer", C.c_int), ("display_max_lvl", C.c_float),
-                ("display_min_lvl", C.c_float)]
+                ("display_min_lvl", C.c_float), ("psd_pitch", C.c_int)]
 
     def __init__(self, scale_type=2, autoscale=1, overlap=0.0, max_level_db=-10.0, min_level_db=-60.0,
-                 thr_level=0.0, palette=0, first_buffer=1):
+                 thr_level=0.0, palette=0, first_buffer=1, psd_pitch=0):
         super().__init__(scale_type, autoscale, overlap, max_level_db, min_level_db, thr_level,
-                         palette, first_buffer, 0.0, 0.0)
+                         palette, first_buffer, 0.0, 0.0, psd_pitch)
 
 
 SCALE_LIN, SCALE_LIN_MAX0, SCALE_LOG, SCALE_LOG_MAX0 = range(4)          # glfer.h:43
@@ -127,6 +127,7 @@ def lib():
     L.glfer_hip_submean_device.argtypes = [vp, vp, C.c_int, sz, C.c_int, vp]
     L.glfer_hip_submean_exact_device.argtypes = [vp, vp, C.c_int, sz, C.c_int, vp]
     L.glfer_hip_floor_device.argtypes = [vp, sz, C.c_int, vp, vp]
+    L.glfer_hip_floor_device_pitched.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp]
     L.glfer_hip_palette.argtypes = [C.c_int, vp]
     L.glfer_hip_display_device.argtypes = [C.POINTER(Display), vp, vp, vp, sz, C.c_int, vp, vp, vp, vp]
     L.glfer_hip_avg_device.argtypes = [C.c_int, vp, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -204,8 +205,9 @@ class FftParams:
     """What source.c:320-325 sets before fft_init(): n, window_type, overlap, a, limiter."""
 
     def __init__(self, n=1024, window_type=7, overlap=0.0, a=0.0, limiter=0, sub_mean=0,
-                 history_mode=HISTORY_ZERO_FIRST, sample_format=SAMPLES_F32):
+                 history_mode=HISTORY_ZERO_FIRST, sample_format=SAMPLES_F32, psd_pitch=0):
         self.mode = MODE_FFT
+        self.psd_pitch = psd_pitch                      # cfg.psd_pitch: floats from one PSD row to the next (0 = dense)
         self.n, self.window_type, self.overlap = n, window_type, overlap
         self.a, self.limiter, self.sub_mean = a, limiter, sub_mean
         self.history_mode, self.sample_format = history_mode, sample_format
@@ -216,8 +218,9 @@ class MtmParams:
     """What source.c:343-350 sets before mtm_init(): fft.{n,overlap}, w (=N*W), kmax."""
 
     def __init__(self, n=1024, overlap=0.0, w=4.0, kmax=7, sub_mean=0,
-                 history_mode=HISTORY_ZERO_FIRST, sample_format=SAMPLES_F32):
+                 history_mode=HISTORY_ZERO_FIRST, sample_format=SAMPLES_F32, psd_pitch=0):
         self.mode = MODE_MTM
+        self.psd_pitch = psd_pitch
         self.n, self.overlap, self.w, self.kmax = n, overlap, w, kmax
         self.window_type = WINDOWS["rectangular"]       # source.c:344
         self.a, self.limiter, self.sub_mean = 0.0, 0, sub_mean
@@ -263,7 +266,7 @@ def make_config(params, device=0):
     return Config(params.mode, params.n, params.overlap, params.window_type, params.a,
                   params.limiter, params.sub_mean, params.history_mode, params.w, params.kmax,
                   params.sample_format, device, getattr(params, "t", 0), getattr(params, "p_e", 0),
-                  getattr(params, "avg", 0))
+                  getattr(params, "avg", 0), getattr(params, "psd_pitch", 0))
 
 
 class Spectrogram:
@@ -278,6 +281,7 @@ class Spectrogram:
         self.n = params.n
         self.hop = lib().glfer_hip_hop(self._h)
         self.bins = lib().glfer_hip_bins(self._h)
+        self.pitch = getattr(params, "psd_pitch", 0) or self.bins     # floats from one row of run()'s output to the next
         self.ntapers = lib().glfer_hip_num_tapers(self._h)
 
     def close(self):
@@ -317,8 +321,8 @@ class Spectrogram:
         if nframes is None:
             nframes = total - first_frame
         if out is None:
-            out = torch.empty((nframes, self.bins), dtype=torch.float32, device=stream.device)
-        assert out.is_contiguous() and out.numel() >= nframes * self.bins
+            out = torch.empty((nframes, self.pitch), dtype=torch.float32, device=stream.device)
+        assert out.is_contiguous() and out.numel() >= nframes * self.pitch
         st = C.c_void_p(torch.cuda.current_stream(stream.device).cuda_stream)
         if spectrum:
             spec = torch.empty((nframes, self.n), dtype=torch.float32, device=stream.device)
@@ -329,7 +333,7 @@ class Spectrogram:
         _check(lib().glfer_hip_spectrogram_device(self._h, stream.data_ptr(), stream.numel(),
                                                   first_frame, nframes, out.data_ptr(), st),
                "glfer_hip_spectrogram_device")
-        return out
+        return out                                       # (with cfg.psd_pitch: [nframes][pitch], a row's first `bins` floats are its bins)
 
     def run_wav(self, path, chunk_frames=0, max_frames=None, partial_tail=False):
         """Whole WAV file -> numpy psd [frames][bins], streamed through pinned buffers.

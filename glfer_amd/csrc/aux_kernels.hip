@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t fkey(float v) {
 // scan from 0.0, fft.c:284-291); floor = (sum of the `m` smallest bins)/0.05/bins where the
 // reference sorts all bins (qsort, fft.c:265) and adds sorted[(int)(bins*0.95) ..].  Here the
 // m-th smallest is found by a 4x8-bit radix select on the row held in LDS; no sort.
-__global__ __launch_bounds__(256) void floor_kernel(const float *__restrict__ psd, int bins, int m,
+__global__ __launch_bounds__(256) void floor_kernel(const float *__restrict__ psd, int bins, int pitch, int m,
                                                     float *__restrict__ stats) {
   extern __shared__ float row[];                 // bins floats, then 256 uint32 + scratch
   uint32_t *hist = reinterpret_cast<uint32_t *>(row + bins);
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void floor_kernel(const float *__restrict__ ps
   __shared__ uint32_t sel_prefix, sel_need, wtot[4];
 
   const int tid = threadIdx.x;
-  const float *src = psd + (size_t)blockIdx.x * bins;
+  const float *src = psd + (size_t)blockIdx.x * pitch;
   float best = 0.0f;
   int besti = 0;
   for (int i = tid; i < bins; i += 256) {
@@ -263,7 +263,7 @@ constexpr int floor_groups(int epl) { return epl <= 33 ? 1 : (epl <= 65 ? 2 : 4)
 // v_med3 + v_min for the lane's two smallest keys.  The peak's INDEX is found afterwards, by
 // ballots over the keys in ascending group order (33 compares at worst instead of 66 selects).
 template <int EPL, bool EXACT>
-__global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict__ psd, long long nframes, int bins, int m,
+__global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict__ psd, long long nframes, int bins, int pitch, int m,
                                                          float *__restrict__ stats) {
   constexpr bool kCompact = EPL >= 17;           // (at 9 keys per lane the detour costs what it saves)
   constexpr int G = floor_groups(EPL), CAP = G == 4 ? 48 : 8 * G;   // (8193 bins: a quarter of the rows pass 32 keys per lane)
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void floor_wave_kernel(const float *__restrict
   const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (r >= nframes) return;                      // wavefront-uniform
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(psd + (size_t)r * bins), 0, bins * 4, 0x00020000);   // reads past the row's end return 0
+      const_cast<float *>(psd + (size_t)r * pitch), 0, bins * 4, 0x00020000);   // reads past the row's end return 0
   uint32_t key[EPL];                             // the row as keys only: fkey_inv() gives the value back
   float best = 0.0f;                             // strict > scan from 0.0 (fft.c:284-291): NaNs and bins <= 0 never win
   uint32_t kmin = 0xFFFFFFFFu, s1[G], s2[G];     // s1 <= s2: the two smallest keys of the lane's group g (keys j = g mod G)
@@ -961,16 +961,17 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
 
 using namespace glfer;
 
-extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int bins, int m, float *stats,
+// pitch: floats from one row to the next (>= bins; cfg.psd_pitch)
+extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int bins, int pitch, int m, float *stats,
                                          hipStream_t st) {
   if (nframes == 0) return hipSuccess;
-  if (m < 1 || m > bins) return hipErrorInvalidValue;
+  if (m < 1 || m > bins || pitch < bins) return hipErrorInvalidValue;
   const unsigned wgrid = (unsigned)((nframes + 3) / 4);          // one wavefront per row, four rows per block
   const long long nf = (long long)nframes;
 #define GLFER_FLOOR_WAVE(E)                                                                                        \
   do {                                                                                                             \
-    if (bins == 64 * (E - 1) + 1) hipLaunchKernelGGL((floor_wave_kernel<E, true>), dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats); \
-    else hipLaunchKernelGGL((floor_wave_kernel<E, false>), dim3(wgrid), dim3(256), 0, st, psd, nf, bins, m, stats); \
+    if (bins == 64 * (E - 1) + 1) hipLaunchKernelGGL((floor_wave_kernel<E, true>), dim3(wgrid), dim3(256), 0, st, psd, nf, bins, pitch, m, stats); \
+    else hipLaunchKernelGGL((floor_wave_kernel<E, false>), dim3(wgrid), dim3(256), 0, st, psd, nf, bins, pitch, m, stats); \
   } while (0)
   if (bins <= 64 * 3) GLFER_FLOOR_WAVE(3);
   else if (bins <= 64 * 5) GLFER_FLOOR_WAVE(5);
@@ -984,7 +985,7 @@ extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int b
     const size_t shmem = (size_t)bins * sizeof(float) + 256 * sizeof(uint32_t);
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(floor_kernel), shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(floor_kernel, dim3((unsigned)nframes), dim3(256), shmem, st, psd, bins, m, stats);
+    hipLaunchKernelGGL(floor_kernel, dim3((unsigned)nframes), dim3(256), shmem, st, psd, bins, pitch, m, stats);
   }
   return hipGetLastError();
 }

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void levels_fixed_kernel(long long nframes, fl
 // with unaligned global access enabled and the compiler emits dwordx3/dwordx2 for it), instead of
 // twelve byte stores and four short stores; the palette sits in LDS as one dword per colour.
 template <typename SRC>
-__global__ __launch_bounds__(256) void map_kernel(const SRC *__restrict__ src, int n, int scale_log,
+__global__ __launch_bounds__(256) void map_kernel(const SRC *__restrict__ src, int n, int src_pitch, int scale_log,
                                                   double thr255, double one_m_thr,
                                                   const float *__restrict__ levels,
                                                   const unsigned char *__restrict__ colortab,
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void map_kernel(const SRC *__restrict__ src, i
   };
   tab[c0] = rgb_of(c0);
   const size_t fr = blockIdx.x;
-  const SRC *row = src + fr * (size_t)n;
+  const SRC *row = src + fr * (size_t)src_pitch;
   const float display_max = levels[fr * 4 + 0];
   const float display_min = levels[fr * 4 + 1];
   const RowScale rs = row_scale(display_max, display_min);
@@ -342,16 +342,17 @@ extern "C" hipError_t glfer_launch_levels_fixed(size_t nframes, float dmax, floa
   return hipGetLastError();
 }
 
-extern "C" hipError_t glfer_launch_map(const float *psd, const double *avg, size_t nframes, int n,
+// psd_pitch: floats from one PSD row to the next (cfg.psd_pitch; the averaged rows are dense)
+extern "C" hipError_t glfer_launch_map(const float *psd, const double *avg, size_t nframes, int n, int psd_pitch,
                                        int scale_log, double thr255, double one_m_thr, const float *levels,
                                        const unsigned char *colortab, const double *log_thr, unsigned char *rgb,
                                        short *lev, hipStream_t st) {
   if (nframes == 0) return hipSuccess;
   if (avg)
-    hipLaunchKernelGGL(map_kernel<double>, dim3((unsigned)nframes), dim3(256), 0, st, avg, n, scale_log,
+    hipLaunchKernelGGL(map_kernel<double>, dim3((unsigned)nframes), dim3(256), 0, st, avg, n, n, scale_log,
                        thr255, one_m_thr, levels, colortab, log_thr, rgb, lev);
   else
-    hipLaunchKernelGGL(map_kernel<float>, dim3((unsigned)nframes), dim3(256), 0, st, psd, n, scale_log,
+    hipLaunchKernelGGL(map_kernel<float>, dim3((unsigned)nframes), dim3(256), 0, st, psd, n, psd_pitch, scale_log,
                        thr255, one_m_thr, levels, colortab, log_thr, rgb, lev);
   return hipGetLastError();
 }

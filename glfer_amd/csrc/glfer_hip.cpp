@@ -22,7 +22,7 @@
 
 extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const uint16_t *lagmap,
                                           const float2 *unit, hipStream_t st);
-extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int bins, int m, float *stats,
+extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int bins, int pitch, int m, float *stats,
                                          hipStream_t st);
 extern "C" hipError_t glfer_launch_avg(int mode, const float *psd, size_t nframes, int bins, int n_out,
                                        int depth, int minbin, int maxbin, int max0, double *avg,
@@ -379,8 +379,10 @@ struct MapAverages {
 // the carried state in *d untouched.
 static int display_columns(glfer_hip_display *d, const float *d_psd, const double *d_avg, const MapAverages *fused,
                            const float *d_stats, size_t nframes, int bins, unsigned char *d_rgb, short *d_lev,
-                           float *d_levels, void *hip_stream, const float *d_levels_in = nullptr) {
+                           float *d_levels, void *hip_stream, const float *d_levels_in = nullptr, int psd_pitch = 0) {
   if (!d || (!d_stats && !d_levels_in) || !d_rgb || bins < 1) return GLFER_E_ARG;
+  if (psd_pitch == 0) psd_pitch = bins;                  // floats from one row of d_psd to the next (cfg.psd_pitch)
+  if (psd_pitch < bins || (fused && psd_pitch != bins)) return GLFER_E_ARG;
   if ((d_psd != nullptr) + (d_avg != nullptr) + (fused != nullptr) != 1) return GLFER_E_ARG;
   if (d->scale_type < GLFER_SCALE_LIN || d->scale_type > GLFER_SCALE_LOG_MAX0) return GLFER_E_ARG;
   if (nframes == 0) return GLFER_OK;
@@ -431,7 +433,7 @@ static int display_columns(glfer_hip_display *d, const float *d_psd, const doubl
                               fused->minbin, fused->maxbin, fused->max0, scale_log, 255.0 * thr_level,
                               1.0 - thr_level, levels, d_tab, d_thr, d_rgb, d_lev, st);
     else
-      e = glfer_launch_map(d_psd, d_avg, nframes, bins, scale_log, 255.0 * thr_level, 1.0 - thr_level, levels,
+      e = glfer_launch_map(d_psd, d_avg, nframes, bins, psd_pitch, scale_log, 255.0 * thr_level, 1.0 - thr_level, levels,
                            d_tab, d_thr, d_rgb, d_lev, st);
     if (e != hipSuccess) fail(e);
   }
@@ -456,8 +458,8 @@ extern "C" {
 int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const double *d_avg, const float *d_stats,
                              size_t nframes, int bins, unsigned char *d_rgb, short *d_lev, float *d_levels,
                              void *hip_stream) {
-  if ((d_psd == nullptr) == (d_avg == nullptr)) return GLFER_E_ARG;
-  return display_columns(d, d_psd, d_avg, nullptr, d_stats, nframes, bins, d_rgb, d_lev, d_levels, hip_stream);
+  if (!d || (d_psd == nullptr) == (d_avg == nullptr)) return GLFER_E_ARG;
+  return display_columns(d, d_psd, d_avg, nullptr, d_stats, nframes, bins, d_rgb, d_lev, d_levels, hip_stream, nullptr, d->psd_pitch);
 }
 
 // compute_floor + update_avg_* + the display mapping of main_window_draw (g_main.c:1109-1236) for a
@@ -476,9 +478,10 @@ int glfer_hip_display_device(glfer_hip_display *d, const float *d_psd, const dou
 // sums of the first rows reach back into the batch's rows before row0, the levels are given.
 static int waterfall_columns(glfer_hip_display *d, int avg_mode, int depth, int minbin, int maxbin, int max0,
                              const float *d_batch, size_t row0, size_t nframes, int bins, unsigned char *d_rgb, short *d_lev,
-                             float *d_stats, void *hip_stream, const float *d_levels_in) {
-  const float *d_psd = d_batch ? d_batch + row0 * (size_t)bins : nullptr;
-  if (!d || !d_psd || !d_rgb || bins < 1 || bins > 32769) return GLFER_E_ARG;
+                             float *d_stats, void *hip_stream, const float *d_levels_in, int pitch = 0) {
+  if (pitch == 0) pitch = bins;                          // floats from one PSD row to the next (cfg.psd_pitch)
+  const float *d_psd = d_batch ? d_batch + row0 * (size_t)pitch : nullptr;
+  if (!d || !d_psd || !d_rgb || bins < 1 || bins > 32769 || pitch < bins) return GLFER_E_ARG;
   const bool averaging = avg_mode != 0;
   if (averaging && (avg_mode < GLFER_AVG_SUMAVG || avg_mode > GLFER_AVG_SUMEXTREME || depth < 1 || minbin < 0 ||
                     maxbin <= minbin || maxbin > bins))
@@ -493,7 +496,7 @@ static int waterfall_columns(glfer_hip_display *d, int avg_mode, int depth, int 
   // applies (no averaged rows in memory at all: GLFER_WATERFALL_FUSED=0 forces the staged form, for
   // A/B runs and tests); staged, averaged rows are 8 B per bin: 4 GiB of them per tile.  Otherwise
   // only the 16 B of statistics per row are scratch.
-  bool fused = averaging;
+  bool fused = averaging && pitch == bins;               // (the average-in-the-map kernel walks dense rows)
   if (const char *e = getenv("GLFER_WATERFALL_FUSED")) fused = fused && atoi(e) != 0;
   size_t tile = (averaging && !fused) ? std::max<size_t>(16384, ((size_t)4 << 30) / ((size_t)bins * sizeof(double))) : (size_t)1 << 22;
   if (const char *e = getenv("GLFER_WATERFALL_TILE")) {    // rows per tile, for tests of the tile seams and for tuning
@@ -523,7 +526,7 @@ static int waterfall_columns(glfer_hip_display *d, int avg_mode, int depth, int 
     const float *tlevels = d_levels_in ? d_levels_in + f0 * 4 : nullptr;
     unsigned char *trgb = d_rgb + f0 * (size_t)bins * 3;
     short *tlev = d_lev ? d_lev + f0 * (size_t)bins : nullptr;
-    if (tstats) rc = glfer_hip_floor_device(d_psd + f0 * (size_t)bins, nf, bins, tstats, st);
+    if (tstats) rc = glfer_hip_floor_device_pitched(d_psd + f0 * (size_t)pitch, nf, bins, pitch, tstats, st);
     if (rc != GLFER_OK) break;
     if (fused) {
       // the sliding sums of the tile's first rows reach back into the rows before it by themselves
@@ -536,13 +539,14 @@ static int waterfall_columns(glfer_hip_display *d, int avg_mode, int depth, int 
       // the sums of the tile's first rows reach `depth` rows back: run from there (from an empty
       // state at row 0 of the batch, as update_avg does after alloc_avg) and use the tile's rows
       const size_t lead = std::min(back, row0 + f0);
-      rc = glfer_hip_avg_device(avg_mode, d_batch + (row0 + f0 - lead) * (size_t)bins, nf + lead, bins, bins, depth, minbin, maxbin, max0,
+      // (update_avg's `bins` is its rows' stride; the band is minbin..maxbin, the averaged rows are dense)
+      rc = glfer_hip_avg_device(avg_mode, d_batch + (row0 + f0 - lead) * (size_t)pitch, nf + lead, pitch, bins, depth, minbin, maxbin, max0,
                                 avg, ret, st);
       src_avg = avg + lead * (size_t)bins;
     }
     if (rc == GLFER_OK)
-      rc = display_columns(d, averaging ? nullptr : d_psd + f0 * (size_t)bins, src_avg, nullptr, tstats, nf, bins, trgb, tlev,
-                           nullptr, st, tlevels);
+      rc = display_columns(d, averaging ? nullptr : d_psd + f0 * (size_t)pitch, src_avg, nullptr, tstats, nf, bins, trgb, tlev,
+                           nullptr, st, tlevels, pitch);
   }
   if (avg) glfer::scratch_free(avg, st);
   if (ret) glfer::scratch_free(ret, st);
@@ -556,7 +560,7 @@ int glfer_hip_waterfall_device(glfer_hip_display *d, int avg_mode, int depth, in
                                const float *d_psd, size_t nframes, int bins, unsigned char *d_rgb, short *d_lev,
                                float *d_stats, void *hip_stream) {
   return waterfall_columns(d, avg_mode, depth, minbin, maxbin, max0, d_psd, 0, nframes, bins, d_rgb, d_lev, d_stats, hip_stream,
-                           nullptr);
+                           nullptr, d ? d->psd_pitch : 0);
 }
 
 // The two halves of glfer_hip_waterfall_device for columns that live on several GPUs.  The level
@@ -609,7 +613,7 @@ int glfer_hip_waterfall_map_device(const glfer_hip_display *d, int avg_mode, int
   if (!d || !d_levels) return GLFER_E_ARG;
   glfer_hip_display copy = *d;               // the carried state is not touched: the walk was glfer_hip_levels_host's
   return waterfall_columns(&copy, avg_mode, depth, minbin, maxbin, max0, d_batch, first, nframes, bins, d_rgb, d_lev, nullptr,
-                           hip_stream, d_levels);
+                           hip_stream, d_levels, d->psd_pitch);
 }
 
 size_t glfer_hip_scratch_trim(int device, size_t keep_bytes) { return glfer::scratch_trim(device, keep_bytes); }
@@ -664,6 +668,10 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   p->bins = n / 2 + 1;
   p->lanes = n / 64;
   if (p->hop <= 0) { delete p; return GLFER_E_ARG; }
+  // cfg.psd_pitch: floats from one PSD row to the next in the DEVICE entries' d_psd (0 = dense, N/2+1).  The LMP statistic
+  // and the host / file entries (their rows go home through a dense ring) keep dense rows.
+  p->pitch = cfg->psd_pitch ? cfg->psd_pitch : p->bins;
+  if (cfg->psd_pitch < 0 || p->pitch < p->bins || (cfg->psd_pitch && cfg->mode == GLFER_MODE_LMP)) { delete p; return GLFER_E_ARG; }
 
   // --- host tables
   p->window.assign(n, 1.0f);
@@ -1148,7 +1156,7 @@ static hipError_t launch_by_n(const SpectroParams &sp, int n, hipStream_t st) {
     SpectroParams q = sp;
     q.frame0 = from;
     q.nframes = (int)(to - from);
-    q.psd = sp.psd + (size_t)(from - lo) * (size_t)(n / 2 + 1);
+    q.psd = sp.psd + (size_t)(from - lo) * (size_t)sp.pitch;
     q.mean_inkernel = 0;                           // (head and tail frames: never with mean_inkernel, see above)
     q.means = nullptr;
     return q;
@@ -1179,6 +1187,7 @@ static void fill_params(const glfer_hip_plan *p, SpectroParams &sp) {
   sp.R = p->keep;
   sp.npairs = p->npairs;
   sp.history_mode = p->cfg.history_mode ? 1 : 0;
+  sp.pitch = p->pitch;
   sp.fmt = p->cfg.sample_format;
   sp.nonlin = p->nonlin ? 1 : 0;
   sp.limiter = (p->cfg.enable_limiter == 1);
@@ -1302,7 +1311,7 @@ static hipError_t launch_reference_means(const glfer_hip_plan *p, const SpectroP
 // caller's stream and a second side stream as well), GLFER_MEANS_BLOCKS (grid of the tiled means kernel beside an
 // estimator launch) are the knobs tools/exact_mean_time.py sweeps.
 static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroParams &bs, size_t b0, size_t b1, hipStream_t st) {
-  const long piece_mb = [] { const char *e = getenv("GLFER_EXACT_PIECE_MB"); return e && *e ? atol(e) : 48L; }();   // (read per call: the sweep sets them between calls)
+  const long piece_mb = [] { const char *e = getenv("GLFER_EXACT_PIECE_MB"); return e && *e ? atol(e) : 0L; }();   // (read per call: the sweep sets them between calls)
   const int nstreams_env = [] { const char *e = getenv("GLFER_EXACT_STREAMS"); return e && *e ? atoi(e) : 2; }();
   const unsigned means_blocks = [] { const char *e = getenv("GLFER_MEANS_BLOCKS"); return e && *e ? (unsigned)atol(e) : 0u; }();
   const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop);
@@ -1351,7 +1360,7 @@ static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroPara
       e = launch_reference_means(p, bs, h0, f1 - h0, means + (h0 - hop_lo), 0, st);
       q.frame0 = (long long)f0;
       q.nframes = (int)(f1 - f0);
-      q.psd = bs.psd + (f0 - b0) * (size_t)p->bins;
+      q.psd = bs.psd + (f0 - b0) * (size_t)p->pitch;
       if (e == hipSuccess) e = launch_by_n(q, p->n, st);
     }
     glfer::scratch_free(means, st);
@@ -1377,7 +1386,7 @@ static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroPara
     if (e == hipSuccess) e = hipStreamWaitEvent(se, ev_m[c], 0);
     q.frame0 = (long long)f0;
     q.nframes = (int)(f1 - f0);
-    q.psd = bs.psd + (f0 - b0) * (size_t)p->bins;
+    q.psd = bs.psd + (f0 - b0) * (size_t)p->pitch;
     if (e == hipSuccess) e = launch_by_n(q, p->n, se);
     if (e == hipSuccess) e = hipEventRecord(ev_e[c], se);
     if (e == hipSuccess) launched = c + 1;
@@ -1420,7 +1429,7 @@ static int launch_mean_inkernel(glfer_hip_plan *p, const SpectroParams &sp, size
     SpectroParams hs = sp;
     hs.frame0 = (long long)from;
     hs.nframes = (int)(to - from);
-    hs.psd = d_psd + (from - first) * (size_t)p->bins;
+    hs.psd = d_psd + (from - first) * (size_t)p->pitch;
     float *scratch = nullptr;
     rc = submean_scratch(p, hs, from, to - from, st, &scratch);
     if (rc == GLFER_OK) {
@@ -1434,7 +1443,7 @@ static int launch_mean_inkernel(glfer_hip_plan *p, const SpectroParams &sp, size
     SpectroParams bs = sp;
     bs.frame0 = (long long)b0;
     bs.nframes = (int)(b1 - b0);
-    bs.psd = d_psd + (b0 - first) * (size_t)p->bins;
+    bs.psd = d_psd + (b0 - first) * (size_t)p->pitch;
     bs.spec = nullptr;
     bs.mean_inkernel = 1;
     if (!reference_means(p)) {
@@ -1599,6 +1608,7 @@ int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t n
   }
   SpectroParams sp;
   fill_params(p, sp);
+  sp.pitch = p->bins;                    // (the statistic and this entry's scratch rows are dense)
   sp.stream = d_stream;
   sp.npairs = 1;
   sp.nonlin = 0;
@@ -1687,13 +1697,17 @@ int glfer_hip_submean_exact_device(const void *d_in, float *d_out, int hop, size
   return e == hipSuccess ? GLFER_OK : hip_fail(e, "glfer_hip_submean_exact_device");
 }
 
-int glfer_hip_floor_device(const float *d_psd, size_t nframes, int bins, float *d_stats, void *hip_stream) {
-  if (!d_psd || !d_stats || bins < 1 || bins > 32769) return GLFER_E_ARG;
+int glfer_hip_floor_device_pitched(const float *d_psd, size_t nframes, int bins, int pitch, float *d_stats, void *hip_stream) {
+  if (!d_psd || !d_stats || bins < 1 || bins > 32769 || pitch < bins) return GLFER_E_ARG;
   const int m = bins - (int)(bins * 0.95);                       // fft.c:271: i = N2*0.95 .. N2-1
   DeviceGuard guard(data_device(d_psd));
   HIP_TRY(guard.error());
-  HIP_TRY(glfer_launch_floor(d_psd, nframes, bins, m, d_stats, (hipStream_t)hip_stream));
+  HIP_TRY(glfer_launch_floor(d_psd, nframes, bins, pitch, m, d_stats, (hipStream_t)hip_stream));
   return GLFER_OK;
+}
+
+int glfer_hip_floor_device(const float *d_psd, size_t nframes, int bins, float *d_stats, void *hip_stream) {
+  return glfer_hip_floor_device_pitched(d_psd, nframes, bins, bins, d_stats, hip_stream);
 }
 
 int glfer_hip_avg_device(int avg_mode, const float *d_psd, size_t nframes, int bins, int n_out, int depth,

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
     wave_fence();
     // ---- |A(f)|^2/N by Horner at z = exp(-2 pi i k/N) (what the zero-padded N-point FFT of
     // hparma.c:140-153 evaluates), reciprocal below Nyquist (hparma.c:154-156)
-    float *o = p.psd + (size_t)f * (N / 2 + 1);
+    float *o = p.psd + (size_t)f * (size_t)p.pitch;
     for (int k = lane; k <= N / 2; k += 64) {
       const float2 z = hp.unit[k];
       // double Horner: the reciprocal below magnifies evaluation error at the spectral peaks

@@ -118,6 +118,8 @@ struct Job {
 int run_job(const Job &job, size_t *frames_done) {
   glfer_hip_plan *p = job.p;
   *frames_done = 0;
+  // rows go home through a dense ring: a pitched plan (cfg.psd_pitch) or display belongs to the device entries
+  if (p->pitch != p->bins || (job.sink.disp && job.sink.disp->psd_pitch)) return GLFER_E_ARG;
   if (job.frames == 0) return GLFER_OK;
   const size_t esz = sample_bytes(p->cfg.sample_format);
   const size_t hop = (size_t)p->hop, bins = (size_t)p->bins;
@@ -407,6 +409,7 @@ void glfer_hip_frame_range(size_t total_frames, unsigned rank, unsigned world, s
 int glfer_hip_spectrogram_host(glfer_hip_plan *p, const void *h_stream, size_t nsamples, float *h_psd,
                                size_t *nframes_out) {
   if (!p || !h_stream || !nframes_out) return GLFER_E_ARG;
+  if (p->pitch != p->bins) return GLFER_E_ARG;                 // host rows are dense (cfg.psd_pitch: the device entries)
   const size_t frames = nsamples / (size_t)p->hop;
   *nframes_out = frames;
   if (frames == 0) return GLFER_OK;

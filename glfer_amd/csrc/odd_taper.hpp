@@ -125,12 +125,12 @@ __device__ __forceinline__ void separate_and_store(const SpectroParams &p, const
     xb[t + T * (m - 8)] = v2f32{zr[r], zi[r]};
   });
   frame_sync<T>();
-  constexpr unsigned ROWB = (N / 2 + 1) * 4u;
+  const unsigned ROWB = (unsigned)p.pitch * 4u;            // bytes from row to row (cfg.psd_pitch)
   const long long leftA = p.nframes - fblk, leftB = p.nframes - (fblk + FPB);
   const unsigned recA = (unsigned)((leftA > FPB ? FPB : leftA) * (long long)ROWB);
   const unsigned recB = leftB > 0 ? (unsigned)((leftB > FPB ? FPB : leftB) * (long long)ROWB) : 0u;
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)fblk * (N / 2 + 1), 0, recA, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)(fblk + (leftB > 0 ? FPB : 0)) * (N / 2 + 1), 0, recB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)fblk * (size_t)p.pitch, 0, recA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(p.psd + (size_t)(fblk + (leftB > 0 ? FPB : 0)) * (size_t)p.pitch, 0, recB, 0x00020000);
   const unsigned voff = fl * ROWB + t * 4u;
   const float uA = scale_out(hxA), uB = scale_out(hxB);
   static_for<0, 8>([&](auto mc) {

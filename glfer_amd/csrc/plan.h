@@ -80,6 +80,7 @@ void ingest_ring_free(IngestRing *r);
 struct glfer_hip_plan {
   glfer_hip_config cfg;
   int n, hop, keep, bins, ntapers, npairs, lanes;
+  int pitch = 0;                    // floats from one PSD row to the next in the device entries (cfg.psd_pitch, or bins)
   int lmp_av = 0;                   // LMP mode: periodograms in the ring (lmp.c:85)
   std::vector<float> window;        // [n] as the reference stores it (unit power)
   std::vector<double> tapers;       // [ntapers][n]

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
       }
       frame_sync<T>();
       if (live) {
-        float *o = p.psd + (size_t)f * (N / 2 + 1);
+        float *o = p.psd + (size_t)f * (size_t)p.pitch;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const int k = T * m + (int)t;

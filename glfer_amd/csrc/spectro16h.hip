@@ -515,19 +515,19 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       // rows go out through a buffer descriptor over this block's frames: one VGPR offset per
       // direction (bins k upwards, bins M-k downwards) plus scalar offsets, no address arithmetic,
       // and frame slots past the last frame fall outside num_records (their stores are dropped)
-      constexpr unsigned ROWB = (unsigned)(M + 1) * 4u;
+      const unsigned ROWB = (unsigned)p.pitch * 4u;        // bytes from row to row (cfg.psd_pitch)
       // a descriptor over the workgroup's rows: rows past the launch's last frame fall outside
       // num_records and their stores are dropped
       const long long left = p.nframes - start, span = per * FPB;
       const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-          p.psd + (size_t)start * (M + 1), 0, (unsigned)((left > span ? span : left) * (long long)ROWB), 0x00020000);
+          p.psd + (size_t)start * (size_t)p.pitch, 0, (unsigned)((left > span ? span : left) * (long long)ROWB), 0x00020000);
       const unsigned row = (unsigned)rel_of(it) * ROWB;
       const unsigned vup = row + t * 4u, vdown = row + (unsigned)(M - 7 * T - (int)t) * 4u;
       // STAGE: the row's floats into the exchange buffer's free upper part (the mirror step uses entries
       // 0 .. M/2), at the offset s16 they have inside their 64-byte granule in memory
       constexpr bool STAGE = GLFER16H_STAGE_ROWS != 0 && T >= 64 && (PADM - M / 2 - 8) * 2 >= M + 1 + 16 + 4 && !(GLFER_H_ABL & 1);
       float *stg = reinterpret_cast<float *>(xb + (M / 2 + 8));
-      const unsigned long long gfl = (unsigned long long)(start + rel_of(it)) * (unsigned long long)(M + 1) +
+      const unsigned long long gfl = (unsigned long long)(start + rel_of(it)) * (unsigned long long)p.pitch +
                                      (unsigned long long)(reinterpret_cast<__SIZE_TYPE__>(p.psd) >> 2);
       const unsigned s16 = (unsigned)gfl & 15u;          // (uniform over the frame's wavefronts)
       float *sup = stg + (s16 + t), *sdown = stg + (s16 + (unsigned)(M - 7 * T - (int)t));   // the staged bins t and M - 7T - t

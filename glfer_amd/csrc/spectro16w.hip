@@ -355,7 +355,7 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
   // before the next barrier.
   constexpr bool kStagger = GLFER16W_DEPHASE != 0 && SETS == 2 && W * FPB >= 8;
   const bool late = kStagger && w >= W / 2;
-  constexpr unsigned ROWB = (unsigned)(M + 1) * 4u;
+  const unsigned ROWB = (unsigned)p.pitch * 4u;            // bytes from row to row (cfg.psd_pitch)
   constexpr int KMAX = LF * (IPL - 1) + 1024 * (W - 1);    // largest k1 + 1024 k2 offset of a lane's items
   float acc[MT ? IPL * 2 * W : 1];                         // MT: [item][k2][bin k | bin M-k]
 
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
     // last frame fall outside num_records (their stores are dropped)
     const long long left = p.nframes - cf;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.psd + (size_t)cf * (M + 1), 0, (unsigned)((left > FPB ? FPB : left) * (long long)ROWB), 0x00020000);
+        p.psd + (size_t)cf * (size_t)p.pitch, 0, (unsigned)((left > FPB ? FPB : left) * (long long)ROWB), 0x00020000);
     // one VGPR offset per direction (bins k upwards from u, bins M-k from the lane's lowest one),
     // everything else a compile-time scalar offset.  (MT stores once per frame, after the last
     // taper: there the offsets are computed at the store, so that no scalar registers stay reserved

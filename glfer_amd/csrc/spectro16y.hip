@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void spectro16y_kernel(SpectroParams p) {
         load_x(xA, nfA);
         load_x(xB, nfA + 1);
       }
-      if (t == 0) p.psd[(size_t)fA * (N / 2 + 1)] = psdA[0] + psdB[0] + nyqA + nyqB + (float)(hxA + hxB);
+      if (t == 0) p.psd[(size_t)fA * (size_t)p.pitch] = psdA[0] + psdB[0] + nyqA + nyqB + (float)(hxA + hxB);
       if (!has_next) break;
       fA = nfA;
       continue;

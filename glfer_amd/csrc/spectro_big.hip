@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void combine_kernel(SpectroParams p, int ntap, 
       acc[2 * k2 + 1] = __builtin_fmaf(x2r, x2r, __builtin_fmaf(x2i, x2i, acc[2 * k2 + 1]));
     });
   }
-  float *o = p.psd + (size_t)(f0 + fr) * (M + 1);
+  float *o = p.psd + (size_t)(f0 + fr) * (size_t)p.pitch;
 #pragma unroll
   for (int k2 = 0; k2 < W; k2++) {
     o[k1 + 1024 * k2] = acc[2 * k2];
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64) void combine2_kernel(SpectroParams p, int ntap,
       acc[2 * k2b + 1] = __builtin_fmaf(x2r, x2r, __builtin_fmaf(x2i, x2i, acc[2 * k2b + 1]));
     });
   }
-  float *o = p.psd + (size_t)(f0 + fr) * (size_t)(M + 1);
+  float *o = p.psd + (size_t)(f0 + fr) * (size_t)p.pitch;
 #pragma unroll
   for (int k2b = 0; k2b < W1; k2b++) {
     const long long k = k1 + 1024LL * (k2a + 32 * k2b);

@@ -37,7 +37,8 @@ struct SpectroParams {
   const float *xtaps;      /* device: [4][N/16][4] last taper, sqrt(1/(4N(1+sig))) folded               */
   /* odd taper counts with LDS-resident half tables, spectro16xl.hip; NULL when not built */
   const float *ltaps;      /* device: [npairs-1][8][N/16][2] pair halves, then [8][N/16] the last taper */
-  float *psd;              /* device: [nframes][N/2+1]                                       */
+  float *psd;              /* device: [nframes][pitch], the first N/2+1 floats of a row are its bins */
+  int pitch;               /* floats from one PSD row to the next (cfg.psd_pitch; N/2+1 = dense)      */
   float *spec;             /* device, optional: [nframes][N] halfcomplex spectrum            */
   /* harmonic F statistic (mtm.c:165-174, 203-233) inside spectro16_kernel; ftest NULL = off.  taps then holds
      [rounds][2N] tables with ONE taper each (im part zero): hn first when ft_mu_live, then tapers 0..ntap-1 */
@@ -86,7 +87,7 @@ hipError_t glfer_launch_levels(const float *stats, size_t nframes, int scale_log
                                float *levels, float *chunk_state, hipStream_t st);
 hipError_t glfer_launch_levels_fixed(size_t nframes, float dmax, float dmin, float max_lvl, float min_lvl,
                                      float *levels, hipStream_t st);
-hipError_t glfer_launch_map(const float *psd, const double *avg, size_t nframes, int n, int scale_log,
+hipError_t glfer_launch_map(const float *psd, const double *avg, size_t nframes, int n, int psd_pitch, int scale_log,
                             double thr255, double one_m_thr, const float *levels,
                             const unsigned char *colortab, const double *log_thr, unsigned char *rgb, short *lev,
                             hipStream_t st);

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void spectro_small_kernel(SpectroParams p, int
       __syncthreads();
     }
     if (live) {
-      float *o = p.psd + (size_t)f * (N / 2 + 1);
+      float *o = p.psd + (size_t)f * (size_t)p.pitch;
       o[l] = acc[l] + acc[(N - l) & (N - 1)];
       if (l == 0) o[N / 2] = 2.0f * acc[N / 2];
     }

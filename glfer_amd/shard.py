@@ -54,7 +54,7 @@ def run_shard(sp, local, begin, first, count, out=None):
     from . import api
     esz = local.element_size()
     if out is None:
-        out = torch.empty((count, sp.bins), dtype=torch.float32, device=local.device)
+        out = torch.empty((count, sp.pitch), dtype=torch.float32, device=local.device)      # (sp.pitch = bins unless cfg.psd_pitch)
     if count == 0:
         return out
     st = C.c_void_p(torch.cuda.current_stream(local.device).cuda_stream)

@@ -93,6 +93,14 @@ typedef struct glfer_hip_config {
   int hparma_t;        /* opt.hparma_t: number of equations (rows), HP-ARMA mode (source.c:373) */
   int hparma_p_e;      /* opt.hparma_p_e: number of poles (source.c:374); q_e is fixed to -1 (source.c:375) */
   int lmp_av;          /* opt.lmp_av: periodograms in the LMP estimator's ring (source.c:397, lmp.c:85) */
+  int psd_pitch;       /* OURS (round 4): floats from one PSD row to the next in the DEVICE entries' d_psd; 0 = dense rows of
+                          N/2+1 floats (what every caller of the reference sees: one psd_buf, source.c:317-318).  A multiple
+                          of 16 floats -- 2112 for N = 4096 -- puts every row on a 64-byte boundary: dense rows of 2049 floats
+                          start 4 bytes further off the cache lines each and cap every row-writing stage at 0.58-0.61 of the
+                          HBM peak (profiles/r03_streaming_ceilings.txt); d_psd then holds nframes * psd_pitch floats, the
+                          first N/2+1 of a row are its bins, the rest is never written.  glfer_hip_floor_device_pitched and
+                          glfer_hip_display.psd_pitch read such rows; update_avg takes the pitch as its `bins` (its band is
+                          minbin..maxbin).  Not with GLFER_MODE_LMP; the host / file entries keep dense rows. */
 } glfer_hip_config;
 
 /* cfg.sub_mean.  The reference sums a hop sample after sample in a float (fft.c:88-92).
@@ -316,6 +324,9 @@ int glfer_hip_submean_exact_device(const void *d_in, float *d_out, int hop, size
  * d_stats: [nframes][4] floats = {sig (max bin), floor, peak value, peak bin as float}. */
 int glfer_hip_floor_device(const float *d_psd, size_t nframes, int bins, float *d_stats,
                            void *hip_stream);
+/* the same over rows `pitch` floats apart (cfg.psd_pitch; pitch >= bins) */
+int glfer_hip_floor_device_pitched(const float *d_psd, size_t nframes, int bins, int pitch, float *d_stats,
+                                   void *hip_stream);
 
 /* update_avg_* (avg.c:108-298) over consecutive PSD rows: the sliding sum over the last
  * `depth` frames per bin in [minbin,maxbin) and the three output normalisations.
@@ -348,6 +359,8 @@ typedef struct {
   int first_buffer;        /* glfer.first_buffer                                               */
   float display_max_lvl;   /* the two function statics of g_main.c:1081                        */
   float display_min_lvl;
+  int psd_pitch;           /* floats from one row of d_psd to the next in glfer_hip_display_device / glfer_hip_waterfall_device /
+                              glfer_hip_waterfall_map_device (0 = dense: `bins`); cfg.psd_pitch of the plan that wrote the rows */
 } glfer_hip_display;
 
 /* set_palette (g_main.c:651-762): 256 RGB triplets into host memory. */

@@ -349,3 +349,99 @@ def test_scratch_cap_bounds_what_is_kept(lib, torch_cuda):
             os.environ.pop("GLFER_MEAN_PREPASS", None)
         else:
             os.environ["GLFER_MEAN_PREPASS"] = saved
+
+
+# ---- item 7: a caller-chosen row pitch for the device entries --------------------------------------------------------
+PITCH_CASES = [("fft", 64, 0.5, {}), ("fft", 256, 0.0, {}), ("fft", 1024, 0.5, dict(sub_mean=1)), ("fft", 4096, 0.75, {}),
+               ("fft", 4096, 0.75, dict(sub_mean=1)), ("fft", 4096, 0.75, dict(sub_mean=2)), ("fft", 4096, 0.3, {}),
+               ("fft", 4096, 0.5, dict(history_mode=1)), ("fft", 16384, 0.5, {}), ("fft", 65536, 0.5, {}), ("fft", 131072, 0.5, {}),
+               ("mtm", 1024, 0.5, dict(kmax=4)), ("mtm", 1024, 0.0, dict(kmax=7)), ("mtm", 2048, 0.25, dict(kmax=4)),
+               ("mtm", 4096, 0.0, dict(kmax=4)), ("mtm", 4096, 0.0, dict(kmax=4, sub_mean=1)), ("mtm", 4096, 0.75, dict(kmax=3)),
+               ("mtm", 8192, 0.5, dict(kmax=4)), ("mtm", 16384, 0.0, dict(kmax=8, w=4.5)), ("hparma", 1024, 0.5, {})]
+
+
+@pytest.mark.parametrize("case", PITCH_CASES, ids=lambda c: "%s-%d-%.2f-%s" % (c[0], c[1], c[2], "-".join("%s%s" % kv for kv in sorted(c[3].items()))))
+def test_rows_at_a_callers_pitch(lib, torch_cuda, case):
+    """cfg.psd_pitch: every estimator kernel writes its rows `pitch` floats apart -- the bins of a row
+    bit-identical to the dense run's, the floats between rows never written -- whole launches, a launch inside the
+    stream, the first frames of a stream (zero history: the packed kernel) and the frames off the frame-group grid
+    included."""
+    torch = torch_cuda
+    mode, n, overlap, kw = case
+    bins = n // 2 + 1
+    pitch = (bins + 15) // 16 * 16 + (16 if n <= 256 else 0)
+    if mode == "fft":
+        mk = lambda p: lib.FftParams(n=n, window_type=0, overlap=overlap, psd_pitch=p, **kw)
+    elif mode == "mtm":
+        rest = {a: b for a, b in kw.items() if a not in ("w", "kmax")}
+        mk = lambda p: lib.MtmParams(n=n, overlap=overlap, w=kw.get("w", 2.5), kmax=kw["kmax"], psd_pitch=p, **rest)
+    else:
+        def mk(p):
+            q = lib.HparmaParams(n=n, overlap=overlap, t=96, p_e=16)
+            q.psd_pitch = p
+            return q
+    hop = int(n * (1.0 - float(np.float32(overlap))))
+    frames = 5 if n > 16384 else (70 if mode == "hparma" else 333)
+    x = torch.from_numpy(synth(frames * hop + 7, seed=n % 89) + np.float32(0.1)).cuda()
+    dense = lib.Spectrogram(mk(0)).run(x)
+    sp = lib.Spectrogram(mk(pitch))
+    assert sp.pitch == pitch and dense.shape == (frames, bins)
+    out = torch.full((frames, pitch), float("nan"), device="cuda")
+    sentinel = out.view(torch.int32)[0, 0].item()
+    sp.run(x, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :bins].contiguous().view(torch.int32), dense.view(torch.int32))
+    assert (out.view(torch.int32)[:, bins:] == sentinel).all()
+    if frames > 100:
+        part = torch.full((frames - 50, pitch), float("nan"), device="cuda")
+        sp.run(x, first_frame=37, nframes=frames - 50, out=part)
+        ref = lib.Spectrogram(mk(0)).run(x, first_frame=37, nframes=frames - 50)
+        assert torch.equal(part[:, :bins].contiguous().view(torch.int32), ref.view(torch.int32))
+        assert (part.view(torch.int32)[:, bins:] == sentinel).all()
+    with pytest.raises(lib.GlferHipError):
+        lib.Spectrogram(mk(bins - 1))
+    if mode != "hparma":
+        with pytest.raises(lib.GlferHipError):
+            sp.run_host(np.zeros(4 * hop, np.float32))            # host rows are dense
+
+
+def test_per_column_stages_read_pitched_rows(lib, torch_cuda):
+    """compute_floor, update_avg_*, the display map and the one-call waterfall on rows 2112 floats apart: the same
+    statistics, averages, pixels and levbuf as on the dense rows (glfer_hip_floor_device_pitched,
+    glfer_hip_display.psd_pitch; update_avg takes the pitch as its row stride)."""
+    import ctypes as C
+    torch = torch_cuda
+    L = lib.api.lib()
+    n, bins, pitch, frames = 4096, 2049, 2112, 700
+    x = torch.from_numpy(synth(frames * 1024 + 3072, seed=9)).cuda()
+    dense = lib.Spectrogram(lib.FftParams(n=n, window_type=0, overlap=0.75)).run(x)
+    rows = lib.Spectrogram(lib.FftParams(n=n, window_type=0, overlap=0.75, psd_pitch=pitch)).run(x)
+    frames = dense.shape[0]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s_d = lib.compute_floor(dense)
+    s_p = torch.empty_like(s_d)
+    assert L.glfer_hip_floor_device_pitched(rows.data_ptr(), frames, bins, pitch, s_p.data_ptr(), st) == 0
+    assert torch.equal(s_d.view(torch.int32), s_p.view(torch.int32))
+    for mode in (lib.AVG_PLAIN, lib.AVG_SUMAVG, lib.AVG_SUMEXTREME):
+        a_d, r_d = lib.update_avg(mode, dense, 5, 30, 2000, max0=1)
+        a_p = torch.empty_like(a_d)
+        r_p = torch.empty_like(r_d)
+        assert L.glfer_hip_avg_device(int(mode), rows.data_ptr(), frames, pitch, bins, 5, 30, 2000, 1, a_p.data_ptr(), r_p.data_ptr(), st) == 0
+        assert torch.equal(a_d.view(torch.int64), a_p.view(torch.int64)) and torch.equal(r_d.view(torch.int64), r_p.view(torch.int64))
+    kw = dict(scale_type=lib.SCALE_LOG, autoscale=1, overlap=0.75, palette=7)
+    rgb_d, lev_d, _ = lib.display(lib.Display(**kw), dense, s_d)
+    dp = lib.Display(psd_pitch=pitch, **kw)
+    rgb_p = torch.empty_like(rgb_d)
+    lev_p = torch.empty_like(lev_d)
+    assert L.glfer_hip_display_device(C.byref(dp), C.c_void_p(rows.data_ptr()), None, C.c_void_p(s_d.data_ptr()), frames, bins,
+                                      C.c_void_p(rgb_p.data_ptr()), C.c_void_p(lev_p.data_ptr()), None, st) == 0
+    assert torch.equal(rgb_d, rgb_p) and torch.equal(lev_d, lev_p)
+    for mode in (0, lib.AVG_PLAIN, lib.AVG_SUMAVG):
+        av = dict(avg_mode=mode, depth=4, minbin=10, maxbin=2000, max0=1)
+        w_rgb, w_lev, _ = lib.waterfall(lib.Display(**kw), dense, **av)
+        p_rgb = torch.empty_like(w_rgb)
+        p_lev = torch.empty_like(w_lev)
+        dpp = lib.Display(psd_pitch=pitch, **kw)
+        assert L.glfer_hip_waterfall_device(C.byref(dpp), int(mode), 4, 10, 2000, 1, rows.data_ptr(), frames, bins, p_rgb.data_ptr(),
+                                            p_lev.data_ptr(), None, st) == 0
+        assert torch.equal(w_rgb, p_rgb) and torch.equal(w_lev, p_lev), mode
