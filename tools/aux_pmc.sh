@@ -1,12 +1,14 @@
 # usage (GPU box, repo root): bash tools/aux_pmc.sh <outdir under gpurun_out>
+# Each rocprofv3 pass runs under `timeout -k 10 240` (a pass that aborts inside rocprofv3 must not hang the box
+# until its silence limit), the program itself still directly after `--`.
 # FETCH_SIZE / WRITE_SIZE / SQ passes (separate runs) over tools/aux_sweep.py: HBM bytes per row of the
 # per-column kernels (floor / average / levels / map), per kernel the LARGEST launch (131072 rows).
 R=$PWD; D=$R/gpurun_out/$1; rm -rf $D; mkdir -p $D
 cd /tmp && export TMPDIR=/tmp && cd $R
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D/fetch -- python3 tools/aux_sweep.py > $D/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D/write -- python3 tools/aux_sweep.py > $D/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $D/sq -- python3 tools/aux_sweep.py > $D/sq.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 tools/aux_sweep.py > $D/stats.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D/fetch -- python3 tools/aux_sweep.py > $D/fetch.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D/write -- python3 tools/aux_sweep.py > $D/write.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $D/sq -- python3 tools/aux_sweep.py > $D/sq.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 tools/aux_sweep.py > $D/stats.log 2>&1
 python3 - $D <<'PY'
 import csv, glob, sys, collections
 d = sys.argv[1]

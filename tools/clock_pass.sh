@@ -1,9 +1,11 @@
 # usage (GPU box): [GLFER_LIB_PATH=...] bash tools/clock_pass.sh <workload> <tag>
+# Each rocprofv3 pass runs under `timeout -k 10 240` (a pass that aborts inside rocprofv3 must not hang the box
+# until its silence limit), the program itself still directly after `--`.
 # shader clock of the workload's estimator kernel: GRBM_GUI_ACTIVE / 8 over the kernel's own duration (one rocprofv3 --pmc pass)
 W=$1; TAG=$2; R=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $R
 D=gpurun_out/clock_$TAG; rm -rf $D; mkdir -p $D
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU --output-format csv -d $D/a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --workload $W > $D/a.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU --output-format csv -d $D/a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --workload $W > $D/a.log 2>&1
 python3 - $D $TAG <<'PY'
 import csv, glob, sys, collections
 d, tag = sys.argv[1], sys.argv[2]

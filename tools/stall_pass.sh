@@ -1,4 +1,6 @@
 # usage (GPU box): bash tools/stall_pass.sh <workload> <tag>
+# Each rocprofv3 pass runs under `timeout -k 10 240` (a pass that aborts inside rocprofv3 must not hang the box
+# until its silence limit), the program itself still directly after `--`.
 # VALU / LDS / VMEM issue and stall counters of one bench workload's spectro16* kernels, the counters
 # in small groups (a pass whose counters do not fit, or whose name this stack does not know, fails
 # alone); the program itself right after `--`.  Output: gpurun_out/stall_<tag>/summary.txt
@@ -14,7 +16,7 @@ for G in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTI
          "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES" \
          "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_IFETCH SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $D/g$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --workload $W > $D/g$i.log 2>&1 || echo "group $i failed: $G" >> $D/failed.txt
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $D/g$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --workload $W > $D/g$i.log 2>&1 || echo "group $i failed: $G" >> $D/failed.txt
 done
 python3 - $D <<'PY' > $D/summary.txt
 import csv, glob, sys, collections

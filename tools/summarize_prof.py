@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a gpurun_out/prof[_<workload>]/ tree (rocprofv3 --kernel-trace --stats and --pmc
 passes over bench.py) into the small summaries kept under profiles/.
-usage: summarize_prof.py <round-tag> [mtm|fft|mtm16k]"""
+usage: summarize_prof.py <round-tag> [mtm|fft|mtm16k|fft1k|hparma]"""
 import collections
 import csv
 import glob
@@ -30,7 +30,7 @@ with open(os.path.join(out, tag + "_kernel_stats" + suffix + ".csv"), "w") as f:
     for r in rows:
         w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
                     r["MaxNs"], r["StdDev"]])
-k = max((r for r in rows if "spectro16" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+k = max((r for r in rows if "spectro16" in r["Name"] or "hparma_kernel" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
 KNAME = k["Name"]
 
 
@@ -40,6 +40,9 @@ def pmc(path, name):
     return sum(v) / len(v)
 
 
+if workload == "hparma":          # not an HBM-bound row: the kernel stats are the summary
+    print(k)
+    sys.exit(0)
 fetch = pmc(one("fetch/*/*_counter_collection.csv"), "FETCH_SIZE")
 write = pmc(one("write/*/*_counter_collection.csv"), "WRITE_SIZE")
 sq = collections.defaultdict(list)
@@ -51,6 +54,7 @@ frames, hop, bins, wname = {
     "mtm": (262144, 4096, 2049, "C3 MTM N=4096 NW=2.5 mtm_k=4 overlap 0, %d frames per launch"),
     "fft": (1048576, 1024, 2049, "C2 periodogram Hanning N=4096 overlap 75 %%, %d frames per launch"),
     "mtm16k": (65536, 16384, 8193, "C4 MTM N=16384 NW=4.5 mtm_k=8 (9 tapers) overlap 0, %d frames per launch"),
+    "fft1k": (2097152, 512, 513, "C1 periodogram Hanning N=1024 overlap 50 %%, %d frames per launch"),
 }[workload]
 alg = frames * (4 * hop + 4 * bins)
 # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports exactly half
