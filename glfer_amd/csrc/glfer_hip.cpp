@@ -711,9 +711,32 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     p->npairs = (p->ntapers + 1) / 2;
     p->tapers.resize((size_t)p->ntapers * n);
     p->sig.resize(p->ntapers);
-    if (!glfer::make_dpss(n, cfg->mtm_k, (double)cfg->mtm_w, p->tapers.data(), p->sig.data())) {
-      delete p;
-      return GLFER_E_NUMERIC;
+    // gl_dpss (g-l_dpss.c:288-347) is the expensive part of mtm_init -- 0.1-0.3 s at N = 16384 with 9 tapers -- and the
+    // *_multi / *_workers entries make a plan per worker and call: the last few results are kept (same doubles, bit for bit)
+    {
+      struct Kept { int n, kmax; float w; std::vector<double> tapers, sig; };
+      static std::mutex mu;
+      static std::vector<Kept> kept;
+      bool hit = false;
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Kept &k : kept)
+          if (k.n == n && k.kmax == cfg->mtm_k && k.w == cfg->mtm_w) {
+            p->tapers = k.tapers;
+            p->sig = k.sig;
+            hit = true;
+            break;
+          }
+      }
+      if (!hit) {
+        if (!glfer::make_dpss(n, cfg->mtm_k, (double)cfg->mtm_w, p->tapers.data(), p->sig.data())) {
+          delete p;
+          return GLFER_E_NUMERIC;
+        }
+        std::lock_guard<std::mutex> lock(mu);
+        if (kept.size() >= 4) kept.erase(kept.begin());
+        kept.push_back(Kept{n, cfg->mtm_k, cfg->mtm_w, p->tapers, p->sig});
+      }
     }
     taps.assign((size_t)2 * p->npairs * n, 0.0f);
     for (int j = 0; j < p->ntapers && !huge; j++) {

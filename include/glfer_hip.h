@@ -103,23 +103,31 @@ typedef struct glfer_hip_config {
                           minbin..maxbin).  Not with GLFER_MODE_LMP; the host / file entries keep dense rows. */
 } glfer_hip_config;
 
-/* cfg.sub_mean.  The reference sums a hop sample after sample in a float (fft.c:88-92).
- *   GLFER_SUBMEAN_FAST   the hop is summed inside the estimator kernels (lane partials, then across
- *                        the lanes): the more accurate sum, 1-3 % over no mean removal -- and not
- *                        the reference's.  Indistinguishable (<= 1e-6 of a row's maximum) while a
- *                        hop's mean is small against its rms, i.e. for AC-coupled audio; on a hop
- *                        with a DC level the reference's sum drifts by up to ~H*eps/4 of the mean
- *                        and the rows differ at the low bins by up to ~7e-4 x |mean|/rms of the row
- *                        maximum (measured at |mean| = rms: 6.6e-4 Hanning periodogram, 7e-5
- *                        multitaper, N = 4096, 50 % overlap; tests/test_gpu_round3.py) -- so above
- *                        |mean|/rms ~ 0.01 take the other one.
- *   GLFER_SUBMEAN_EXACT  the means are accumulated in the reference's own order (hop_means_seq_kernel: one
- *                        lane walks a hop, 64 hops side by side; one more read of the stream) and handed
- *                        to the estimator kernels as a table (periodograms, even taper counts, 5 / 7 ...
- *                        tapers at N = 4096; the other forms read a corrected copy): the reference's rows
- *                        to the usual 1e-5 whatever the input.  Cost: the extra read -- C3 64 against 75,
- *                        C2 230 against 277, C1 772 against 1 108 M frames/s (tools/exact_mean_time.py).
- * The per-hop shims (glfer_compat.h) always take the reference's order. */
+/* cfg.sub_mean.  The reference sums a hop sample after sample in a float (fft.c:88-92), and on a hop with a DC level the
+ * ORDER of that sum is observable in the rows (up to 6.6e-4 of a row's maximum at |mean| = rms).
+ *   GLFER_SUBMEAN_EXACT  (1: what fft_init stores, sub_mean = opt.autoscale -- the DEFAULT meaning of "on" since round 4)
+ *                        the reference's rows: the means are accumulated in the reference's own order (submean_seq.hip: one
+ *                        lane walks a hop, 64 hops side by side: one more read of the stream, at 6.1 TB/s) and handed to the
+ *                        estimator kernels as a table (periodograms -- a form of its own at the plain periodogram's
+ *                        occupancy that corrects a hop's samples once, in place --, even taper counts, 5 / 7 ... tapers at
+ *                        N = 4096; the other forms read a corrected copy).  To the usual 1e-5 of the oracle whatever the
+ *                        input up to N = 4096; above, where the REFERENCE's own recurrence-twiddle transform is 1e-5 and
+ *                        more from exact arithmetic on noise-like frames (1.0-1.6e-5 at N = 16384), to
+ *                        max(1e-5, 1.1 x the oracle's distance from exact), the device itself within 3e-6 of exact
+ *                        (tests/test_gpu_round4.py).  Cost against no mean removal on 2^30-sample device-resident f32
+ *                        streams: the extra read -- C1 774 against 1 125, C2 269 against 336, C3 67 against 84 M frames/s
+ *                        (bench.py's "+mean" rows; against GLFER_SUBMEAN_FAST: 0.69 / 0.94 / 0.83).  Taking the means
+ *                        piece by piece so that the estimator's read of a piece comes out of the Infinity Cache was built
+ *                        and measured (GLFER_EXACT_PIECE_MB): launches of a few tens of microseconds cost more than the
+ *                        cache saves (profiles/r04_piecewise_means.txt) -- one piece is the default.  Behind a PCIe or file
+ *                        source (the host / WAV entries) the pass is hidden: it runs per chunk at 60x the link's rate.
+ *   GLFER_SUBMEAN_FAST   (2, opt-in) the hop is summed inside the estimator kernels (lane partials, then across the lanes):
+ *                        the more accurate sum, 0-3 % over no mean removal (C2: the two-wavefront form, 14 %) -- and not
+ *                        the reference's.  Indistinguishable (<= 1e-6 of a row's maximum) while a hop's mean is small
+ *                        against its rms, i.e. for AC-coupled audio; on a hop with a DC level the rows differ at the low
+ *                        bins by up to ~7e-4 x |mean|/rms of the row maximum (measured at |mean| = rms: 6.6e-4 Hanning
+ *                        periodogram, 7e-5 multitaper, N = 4096, 50 % overlap; tests/test_gpu_round3.py).
+ * Any other non-zero value is taken as GLFER_SUBMEAN_EXACT.  The per-hop shims (glfer_compat.h) take the reference's order. */
 enum { GLFER_SUBMEAN_OFF = 0, GLFER_SUBMEAN_EXACT = 1, GLFER_SUBMEAN_FAST = 2 };
 
 /* Cutting a stream into launches, chunks or shards.

@@ -45,10 +45,18 @@ def rate(cls, kw, mode, env=None):
 
 
 sweep = len(sys.argv) > 1 and sys.argv[1] == "sweep"
-for name, cls, kw in (CASES[:3] if sweep else CASES):
+big = len(sys.argv) > 1 and sys.argv[1] == "big"          # a few LARGE pieces on two / three streams: does the means pass hide beside the estimator?
+for name, cls, kw in (CASES[:3] if (sweep or big) else CASES):
     off, exact, fast = (rate(cls, kw, m) for m in (G.SUBMEAN_OFF, G.SUBMEAN_EXACT, G.SUBMEAN_FAST))
     print("%-44s  off %8.1f M  reference order %8.1f M (%.3f of the in-kernel sums)  in-kernel sums %8.1f M"
           % (name, off, exact, exact / fast, fast), flush=True)
+    if big:
+        for streams in (1, 2, 3):
+            for piece in (512, 1024, 2048):
+                for hpw in (64, 16):
+                    r = rate(cls, kw, G.SUBMEAN_EXACT, dict(GLFER_EXACT_PIECE_MB=piece, GLFER_EXACT_STREAMS=streams, GLFER_MEANS_HPW=hpw))
+                    print("    streams %d  piece %4d MB  hops/wavefront %2d: %8.1f M (%.3f)" % (streams, piece, hpw, r, r / fast), flush=True)
+        continue
     if not sweep:
         continue
     for streams in (1, 2, 3):
