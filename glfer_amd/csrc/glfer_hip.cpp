@@ -20,7 +20,7 @@
 #include "host_tables.h"
 #include "spectro_params.h"
 
-extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const uint16_t *lagmap,
+extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const int *rot_sched, int rot_steps, const uint16_t *lagmap,
                                           const float2 *unit, hipStream_t st);
 extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int bins, int pitch, int m, float *stats,
                                          hipStream_t st);
@@ -882,8 +882,53 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   // Simulated here with lag labels instead of values.
   std::vector<uint16_t> lagmap;
   std::vector<float> unit;
+  std::vector<int> rot_sched;                                      // [steps][8]: j | k << 8, or -1 (hparma.hip, round 4)
   if (cfg->mode == GLFER_MODE_HPARMA) {
     const int t = cfg->hparma_t, ncol = cfg->hparma_p_e + 1;
+    // The Jacobi sweep of compute_svd (util.c:301-355) as a STATIC SCHEDULE of steps of up to eight rotations that share
+    // no column.  Two rotations that share a column must keep the order of the reference's row-cyclic walk -- nothing
+    // else orders them (a rotation touches its two columns only, its skip tests are its own) -- so the walk is a DAG in
+    // which (j, k) waits for the last earlier rotation on column j and the last on column k; list scheduling by longest
+    // remaining path fills steps of eight: 80 steps for 33 columns (66 would be full steps; anti-diagonal by anti-diagonal
+    // it is 94).
+    if (ncol >= 2 && ncol <= 64) {
+      std::vector<std::pair<int, int>> rots;
+      for (int j = 0; j < ncol - 1; j++)
+        for (int k = j + 1; k < ncol; k++) rots.push_back({j, k});
+      const int R = (int)rots.size();
+      std::vector<std::vector<int>> succ(R);
+      std::vector<int> indeg(R, 0), lastc(ncol, -1), lp(R, 1);
+      for (int i = 0; i < R; i++) {
+        const int cs[2] = {rots[i].first, rots[i].second};
+        int seen = -1;
+        for (int c : cs) {
+          if (lastc[c] >= 0 && lastc[c] != seen) {
+            succ[lastc[c]].push_back(i);
+            indeg[i]++;
+            seen = lastc[c];
+          }
+          lastc[c] = i;
+        }
+      }
+      for (int i = R - 1; i >= 0; i--)
+        for (int s : succ[i]) lp[i] = std::max(lp[i], 1 + lp[s]);
+      std::vector<int> ready;
+      for (int i = 0; i < R; i++)
+        if (!indeg[i]) ready.push_back(i);
+      int done = 0;
+      while (done < R) {
+        std::sort(ready.begin(), ready.end(), [&](int a, int b) { return lp[a] != lp[b] ? lp[a] > lp[b] : a < b; });
+        const int take = std::min<int>(8, (int)ready.size());
+        std::vector<int> cur(ready.begin(), ready.begin() + take);
+        ready.erase(ready.begin(), ready.begin() + take);
+        for (int g = 0; g < 8; g++) rot_sched.push_back(g < take ? (rots[cur[g]].first | rots[cur[g]].second << 8) : -1);
+        for (int i : cur) {
+          done++;
+          for (int s : succ[i])
+            if (--indeg[s] == 0) ready.push_back(s);
+        }
+      }
+    }
     std::vector<int> flat((size_t)(t + 1) * ncol, -1);
     for (int i = 0; i < t; i++) flat[i] = i;                       // r_xx[0][i] = r(i)
     for (int i = 1; i < t; i++)
@@ -950,6 +995,11 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     e = hipMalloc((void **)&p->d_lagmap, lagmap.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_unit, unit.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->d_lagmap, lagmap.data(), lagmap.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !rot_sched.empty()) {
+      e = hipMalloc((void **)&p->d_rot_sched, rot_sched.size() * sizeof(int));
+      if (e == hipSuccess) e = hipMemcpy(p->d_rot_sched, rot_sched.data(), rot_sched.size() * sizeof(int), hipMemcpyHostToDevice);
+      p->rot_steps = (int)(rot_sched.size() / 8);
+    }
     if (e == hipSuccess) e = hipMemcpy(p->d_unit, unit.data(), unit.size() * sizeof(float), hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) {
@@ -979,6 +1029,7 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (p->d_bigtw) (void)hipFree(p->d_bigtw);
   if (p->d_ltaps) (void)hipFree(p->d_ltaps);
   if (p->d_lagmap) (void)hipFree(p->d_lagmap);
+  if (p->d_rot_sched) (void)hipFree(p->d_rot_sched);
   if (p->d_unit) (void)hipFree(p->d_unit);
   glfer::ingest_ring_free(p->ring);
   for (hipStream_t a : p->aux)
@@ -1315,7 +1366,9 @@ static hipError_t launch_reference_means(const glfer_hip_plan *p, const SpectroP
   const char *src = (const char *)sp.stream + hop_lo * (size_t)p->hop * esz;
   const int forced = [] { const char *e = getenv("GLFER_MEANS_HPW"); return e && *e ? atoi(e) : 0; }();
   int hpw = forced;
-  if (!hpw) hpw = nhops >= 262144 ? 64 : (nhops >= 32768 || p->hop % 1024 != 0 ? 16 : 4);
+  // (measured, profiles/r04_piecewise_means.txt: on a whole 2^30-sample stream the tiled form with 16 hops per wavefront and
+  // 16-byte loads is the faster one at H = 1024 -- C2 285 against 267 M frames/s --, level at H = 512, behind at H = 4096)
+  if (!hpw) hpw = nhops >= 262144 ? (p->hop <= 2048 ? 16 : 64) : (nhops >= 32768 || p->hop % 1024 != 0 ? 16 : 4);
   if (hpw == 4 && p->hop % 1024 != 0) hpw = 16;
   if (hpw == 16 && p->hop % 256 != 0) hpw = 64;
   if ((hpw == 16 || hpw == 4) && (reinterpret_cast<uintptr_t>(src) & (4 * esz - 1)) == 0)
@@ -1539,7 +1592,7 @@ int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, s
     }
   } else if (rc == GLFER_OK) {
     hipError_t e = p->cfg.mode == GLFER_MODE_HPARMA
-                       ? glfer_launch_hparma(&sp, p->n, p->cfg.hparma_t, p->cfg.hparma_p_e + 1, p->d_lagmap, p->d_unit, st)
+                       ? glfer_launch_hparma(&sp, p->n, p->cfg.hparma_t, p->cfg.hparma_p_e + 1, p->d_rot_sched, p->rot_steps, p->d_lagmap, p->d_unit, st)
                        : launch_by_n(sp, p->n, st);
     if (e != hipSuccess) rc = hip_fail(e, "estimator launch");
   }

@@ -118,6 +118,25 @@ __device__ __forceinline__ void row_sum3(double &a, double &b, double &c) {
   level(std::integral_constant<int, 0x140>{});   // row_mirror
 }
 
+// the same over the 8 lanes of half a DPP row (three levels: lane ^ 1, lane ^ 2, the two quads by row_half_mirror)
+__device__ __forceinline__ void octet_sum3(double &a, double &b, double &c) {
+  auto dpp = [](double x, auto ctrl) -> double {
+    constexpr int C = decltype(ctrl)::value;
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, C, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), C, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  };
+  auto level = [&](auto ctrl) {
+    a += dpp(a, ctrl);
+    b += dpp(b, ctrl);
+    c += dpp(c, ctrl);
+  };
+  level(std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  level(std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  level(std::integral_constant<int, 0x141>{});   // row_half_mirror: the other quad of the octet
+}
+
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -128,6 +147,8 @@ struct HparmaParams {
   int n;                    // block size N
   int t;                    // equations (rows)
   int ncol;                 // p_e + 1
+  const int *sched;         // [nsteps][8]: the Jacobi sweep as steps of up to eight column-disjoint rotations, j | k << 8 or -1 (glfer_hip.cpp)
+  int nsteps;
   const uint16_t *lagmap;   // [t][ncol]: which autocorrelation lag each matrix cell ends up holding
   const float2 *unit;       // [N/2+1]: exp(-2 pi i k / N)
 };
@@ -191,109 +212,112 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
     int count = 1, sweep = 0;
     const bool fast = t <= 128 && ncol <= 64;
     const bool odd = (lane & 1) != 0, bit1 = (lane & 2) != 0;
-    // Round 4: ROTATIONS ON AN ANTI-DIAGONAL RUN SIDE BY SIDE.  compute_svd's rotation (j, k) touches columns j and k of
-    // A and Q only, its skip tests are local to the pair and `count` is a per-sweep sum (util.c:301-355); two rotations
-    // that share a column come in the same order by j + k as in the reference's row-cyclic walk ((j', j), (j, k') and
-    // (j', k) with j' < j, k' < k all have a smaller index sum than (j, k); (j, k''), (j'', k), (k, m) a larger one), and
-    // rotations that share none commute exactly.  So the pairs with j + k = d are independent and see the inputs they see
-    // in the reference: up to 16 per step of d and 2 ncol - 3 steps per sweep instead of ncol (ncol - 1) / 2 rotations
-    // one after the other.  A rotation is laid over a 16-lane DPP row -- a lane holds rows 4 l .. 4 l + 3 and 64 + 4 l ..
-    // 64 + 4 l + 3 of the two columns (two conflict-free ds_read_b128 a column) and rows l, l + 16 ... of Q -- so a wavefront
-    // does FOUR rotations at once, the sums need four row-local butterfly levels instead of six wave-wide ones, and the
-    // ~80 double-precision instructions of the angle (two divisions, two square roots) are issued once for four rotations.
-    // Every rotation's arithmetic is what it was; the sums associate differently (eight rows in a lane, then the
-    // butterfly), as they already differed from the reference's row-by-row order.  t a multiple of 4.
-    const bool diag = t <= 128 && ncol <= 64 && (t & 3) == 0 && ncol >= 2;
+    // Round 4: COLUMN-DISJOINT ROTATIONS RUN SIDE BY SIDE.  compute_svd's rotation (j, k) touches columns j and k of A
+    // and Q only, its skip tests are local to the pair and `count` is a per-sweep sum (util.c:301-355): the only order that
+    // matters is the reference's row-cyclic order AMONG ROTATIONS THAT SHARE A COLUMN; rotations that share none commute
+    // exactly.  (Anti-diagonals j + k = d are such sets: (j', j), (j, k') and (j', k) with j' < j, k' < k all have a
+    // smaller index sum than (j, k), the later ones a larger.)  The host turns the walk into a static schedule of steps of
+    // up to EIGHT column-disjoint rotations (glfer_hip.cpp: list scheduling of the dependency graph by longest remaining
+    // path: 80 steps per sweep for 33 columns instead of 528 rotations one after the other; anti-diagonal by
+    // anti-diagonal, four at a time -- the first form of this round -- it was 156).  A rotation is laid over the 8 lanes
+    // of half a DPP row: a lane holds sixteen rows of the two columns (rows 32 c + 4 l .. + 3, c = 0..3: four
+    // ds_read_b128 a column) and rows l, l + 8 ... of Q; the sums need three octet-local butterfly levels whose partners
+    // add the same two values (x + y and y + x: the same bits in every lane, no read-back) instead of six wave-wide ones,
+    // and the ~80 double-precision instructions of the angle (two divisions, two square roots) are issued once for eight
+    // rotations.  Every rotation's own arithmetic is what it was; the sums associate differently (sixteen rows in a lane,
+    // then the butterfly), as they already differed from the reference's row-by-row order.  t a multiple of 4, <= 128.
+    const bool diag = hp.sched != nullptr && hp.nsteps > 0 && t <= 128 && ncol <= 64 && (t & 3) == 0 && ncol >= 2;
     typedef float v4f32 __attribute__((ext_vector_type(4)));
     while (diag && count > 0 && sweep <= sweepmax) {
-      const int grp = lane >> 4, l16 = lane & 15;
-      const int r0 = 4 * l16, r1 = 64 + 4 * l16;
-      const bool c0 = r0 < t, c1 = r1 < t;
+      const int grp = lane >> 3, l8 = lane & 7;
       int skipped = 0;
-      for (int d = 1; d <= 2 * ncol - 3; d++) {
-        const int jlo = d > ncol - 1 ? d - (ncol - 1) : 0, cnt = ((d - 1) >> 1) - jlo + 1;
-        for (int s0 = 0; s0 < cnt; s0 += 4) {
-          const bool act = s0 + grp < cnt;
-          const int j = jlo + (act ? s0 + grp : 0), k = d - j;
-          float *Aj = A + j * t, *Ak = A + k * t, *Qj = Q + j * ncol, *Qk = Q + k * ncol;
-          const v4f32 z4 = v4f32{0.0f, 0.0f, 0.0f, 0.0f};
-          const v4f32 aj0 = c0 ? *reinterpret_cast<const v4f32 *>(Aj + r0) : z4, ak0 = c0 ? *reinterpret_cast<const v4f32 *>(Ak + r0) : z4;
-          const v4f32 aj1 = c1 ? *reinterpret_cast<const v4f32 *>(Aj + r1) : z4, ak1 = c1 ? *reinterpret_cast<const v4f32 *>(Ak + r1) : z4;
-          float qj[4], qk[4];
+      int e = hp.sched[grp];
+      for (int s0 = 0; s0 < hp.nsteps; s0++) {
+        const int en = hp.sched[(s0 + 1 < hp.nsteps ? s0 + 1 : s0) * 8 + grp];      // the next step's pair, requested a step ahead
+        const bool act = e >= 0;
+        const int j = act ? (e & 0xff) : 0, k = act ? (e >> 8) : 1;
+        float *Aj = A + j * t, *Ak = A + k * t, *Qj = Q + j * ncol, *Qk = Q + k * ncol;
+        const v4f32 z4 = v4f32{0.0f, 0.0f, 0.0f, 0.0f};
+        v4f32 aj[4], ak[4];
 #pragma unroll
-          for (int m = 0; m < 4; m++) {                  // (unconditional loads of a clamped row: a branch per load would wait for each in turn)
-            const int qr = l16 + 16 * m < ncol ? l16 + 16 * m : ncol - 1;
+        for (int c = 0; c < 4; c++) {
+          const int r = 32 * c + 4 * l8;
+          aj[c] = r < t ? *reinterpret_cast<const v4f32 *>(Aj + r) : z4;
+          ak[c] = r < t ? *reinterpret_cast<const v4f32 *>(Ak + r) : z4;
+        }
+        float qj[8], qk[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {                    // (unconditional loads of a clamped row: a branch per load would wait for each in turn)
+          if (8 * m < ncol) {                            // (uniform)
+            const int qr = l8 + 8 * m < ncol ? l8 + 8 * m : ncol - 1;
             qj[m] = Qj[qr];
             qk[m] = Qk[qr];
+          } else {
+            qj[m] = qk[m] = 0.0f;
           }
-          double pp = 0.0, qq = 0.0, rr = 0.0;          // (float products are exact in double: fma and multiply + add round alike)
+        }
+        double pp = 0.0, qq = 0.0, rr = 0.0;            // (float products are exact in double: fma and multiply + add round alike)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            const double a = aj0[i], b = ak0[i];
+            const double a = aj[c][i], b = ak[c][i];
             pp = __builtin_fma(a, b, pp);
             qq = __builtin_fma(a, a, qq);
             rr = __builtin_fma(b, b, rr);
           }
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const double a = aj1[i], b = ak1[i];
-            pp = __builtin_fma(a, b, pp);
-            qq = __builtin_fma(a, a, qq);
-            rr = __builtin_fma(b, b, rr);
+        }
+        octet_sum3(pp, qq, rr);
+        bool rotate = act;
+        if (qq * rr < 2.22e-16) rotate = false;                                    // util.c:316-320
+        else if (pp * pp < 1.0e-12 * (qq * rr)) rotate = false;                    // util.c:321-325, without the division (qq * rr > 0 here)
+        skipped += (act && !rotate) ? 1 : 0;
+        if (rotate) {
+          double cs, sn;
+          if (qq < rr) {                                                            // util.c:327-335
+            cs = 0.0;
+            sn = 1.0;
+          } else {
+            qq -= rr;
+            const double v = sqrt(4.0 * pp * pp + qq * qq);
+            cs = sqrt((v + qq) / (2.0 * v));
+            sn = pp / (v * cs);
           }
-          row_sum3(pp, qq, rr);
-          bool rotate = act;
-          if (qq * rr < 2.22e-16) rotate = false;                                  // util.c:316-320
-          else if (pp * pp < 1.0e-12 * (qq * rr)) rotate = false;                  // util.c:321-325, without the division (qq * rr > 0 here)
-          skipped += (act && !rotate) ? 1 : 0;
-          if (rotate) {
-            double cs, sn;
-            if (qq < rr) {                                                          // util.c:327-335
-              cs = 0.0;
-              sn = 1.0;
-            } else {
-              qq -= rr;
-              const double v = sqrt(4.0 * pp * pp + qq * qq);
-              cs = sqrt((v + qq) / (2.0 * v));
-              sn = pp / (v * cs);
-            }
-            auto turn = [&](float xj, float xk, float &oj, float &ok) {            // util.c:338-350
-              const double a = xj, b = xk;
-              oj = (float)(a * cs + b * sn);
-              ok = (float)(-a * sn + b * cs);
-            };
-            float nj[4], nk[4];
-            if (c0) {
+          auto turn = [&](float xj, float xk, float &oj, float &ok) {              // util.c:338-350
+            const double a = xj, b = xk;
+            oj = (float)(a * cs + b * sn);
+            ok = (float)(-a * sn + b * cs);
+          };
 #pragma unroll
-              for (int i = 0; i < 4; i++) turn(aj0[i], ak0[i], nj[i], nk[i]);
-              *reinterpret_cast<v4f32 *>(Aj + r0) = v4f32{nj[0], nj[1], nj[2], nj[3]};
-              *reinterpret_cast<v4f32 *>(Ak + r0) = v4f32{nk[0], nk[1], nk[2], nk[3]};
-            }
-            if (c1) {
+          for (int c = 0; c < 4; c++) {
+            const int r = 32 * c + 4 * l8;
+            if (r < t) {
+              float nj[4], nk[4];
 #pragma unroll
-              for (int i = 0; i < 4; i++) turn(aj1[i], ak1[i], nj[i], nk[i]);
-              *reinterpret_cast<v4f32 *>(Aj + r1) = v4f32{nj[0], nj[1], nj[2], nj[3]};
-              *reinterpret_cast<v4f32 *>(Ak + r1) = v4f32{nk[0], nk[1], nk[2], nk[3]};
+              for (int i = 0; i < 4; i++) turn(aj[c][i], ak[c][i], nj[i], nk[i]);
+              *reinterpret_cast<v4f32 *>(Aj + r) = v4f32{nj[0], nj[1], nj[2], nj[3]};
+              *reinterpret_cast<v4f32 *>(Ak + r) = v4f32{nk[0], nk[1], nk[2], nk[3]};
             }
+          }
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-              if (16 * m < ncol) {                                                  // (uniform: slots past the last row of Q are skipped)
-                float oj, ok;
-                turn(qj[m], qk[m], oj, ok);
-                if (l16 + 16 * m < ncol) {
-                  Qj[l16 + 16 * m] = oj;
-                  Qk[l16 + 16 * m] = ok;
-                }
+          for (int m = 0; m < 8; m++) {
+            if (8 * m < ncol) {                                                     // (uniform: slots past the last row of Q are skipped)
+              float oj, ok;
+              turn(qj[m], qk[m], oj, ok);
+              if (l8 + 8 * m < ncol) {
+                Qj[l8 + 8 * m] = oj;
+                Qk[l8 + 8 * m] = ok;
               }
             }
           }
-          wave_fence();                                  // the next step's rotations read these columns from other lanes
         }
+        wave_fence();                                    // the next step's rotations read these columns from other lanes
+        e = en;
       }
-      // `count` (util.c:298, 318, 323): the sweep's pairs minus the skipped ones, over the four rows
+      // `count` (util.c:298, 318, 323): the sweep's pairs minus the skipped ones, over the eight octets
       int sk = 0;
 #pragma unroll
-      for (int g = 0; g < 4; g++) sk += __builtin_amdgcn_readlane(skipped, 16 * g);
+      for (int g = 0; g < 8; g++) sk += __builtin_amdgcn_readlane(skipped, 8 * g);
       count = ncol * (ncol - 1) / 2 - sk;
       sweep++;
     }
@@ -460,14 +484,16 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
 
 using namespace glfer;
 
-extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const uint16_t *lagmap,
-                                          const float2 *unit, hipStream_t st) {
+extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const int *rot_sched, int rot_steps,
+                                          const uint16_t *lagmap, const float2 *unit, hipStream_t st) {
   if (sp->nframes <= 0) return hipSuccess;
   HparmaParams hp;
   hp.s = *sp;
   hp.n = n;
   hp.t = t;
   hp.ncol = ncol;
+  hp.sched = rot_sched;
+  hp.nsteps = rot_steps;
   hp.lagmap = lagmap;
   hp.unit = unit;
   const int big = n > t * ncol ? n : t * ncol;

@@ -112,8 +112,8 @@ typedef struct glfer_hip_config {
  *                        occupancy that corrects a hop's samples once, in place --, even taper counts, 5 / 7 ... tapers at
  *                        N = 4096; the other forms read a corrected copy).  To the usual 1e-5 of the oracle whatever the
  *                        input up to N = 4096; above, where the REFERENCE's own recurrence-twiddle transform is 1e-5 and
- *                        more from exact arithmetic on noise-like frames (1.0-1.6e-5 at N = 16384), to
- *                        max(1e-5, 1.1 x the oracle's distance from exact), the device itself within 3e-6 of exact
+ *                        more from exact arithmetic on noise-like frames (1.2-1.6e-5 at N = 8192 and 16384), to
+ *                        max(1e-5, 1.1 x the oracle's distance from exact), the device itself within 1e-6 of exact
  *                        (tests/test_gpu_round4.py).  Cost against no mean removal on 2^30-sample device-resident f32
  *                        streams: the extra read -- C1 774 against 1 125, C2 269 against 336, C3 67 against 84 M frames/s
  *                        (bench.py's "+mean" rows; against GLFER_SUBMEAN_FAST: 0.69 / 0.94 / 0.83).  Taking the means

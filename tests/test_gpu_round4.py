@@ -51,7 +51,7 @@ def test_flat_spectrum_parity_at_large_blocks(lib, oracle, torch_cuda, n, shape,
     """VERDICT r3 item 1.  Every earlier parity input at N >= 8192 was tone-dominated, which flatters a peak-normalised
     error: on noise-like frames the REFERENCE's own float32 transform with its recurrence twiddles (fft_radix2.c:127-141)
     is ~1e-5 from exact arithmetic at N = 16384 (the oracle's FFT is bit-identical to the reference's compiled object,
-    tests/test_oracle_pinning.py), while the device's table-twiddle transform stays ~1e-6 from exact.  So per frame
+    tests/test_oracle_pinning.py), while the device's table-twiddle transform stays within 4.2e-7 of exact.  So per frame
         err(device, oracle) <= max(1e-5, 1.1 x err(oracle, float64-exact))
     with both printed; `exact` = the same float32 samples, the hop means removed exactly as fft.c:88-95 does, the rest in
     float64 (tests/_exact.py).  Periodogram (Hanning, Kaiser) and multitaper (5 tapers; 9 tapers = C4's estimator),
@@ -77,7 +77,7 @@ def test_flat_spectrum_parity_at_large_blocks(lib, oracle, torch_cuda, n, shape,
         e_dev, e_ref, e_devx = max(rel_err(got[f], want[f])), max(rel_err(want[f], exact[f])), max(rel_err(got[f], exact[f]))
         worst = max(worst, (e_dev, e_ref, e_devx))
         assert e_dev <= max(TOL, 1.1 * e_ref), (n, shape, est, overlap, sub_mean, f, e_dev, e_ref, e_devx)
-        assert e_devx <= 3e-6, (n, shape, est, overlap, sub_mean, f, e_devx)        # the device itself: within 3e-6 of exact
+        assert e_devx <= 1e-6, (n, shape, est, overlap, sub_mean, f, e_devx)        # the device itself: within 1e-6 of exact (observed: 4.2e-7)
     print("flat spectrum N=%d %s %s ovl %.2f mean %d: worst frame err(device, oracle) %.2e  err(oracle, exact) %.2e  err(device, exact) %.2e"
           % (n, shape, est, overlap, sub_mean, *worst))
 
@@ -103,7 +103,7 @@ def test_the_case_round_3_dropped(lib, oracle, torch_cuda):
           % (e_dev[1], e_ref[1], e_devx[1], e_dev.max(), e_ref.max(), e_devx.max()))
     assert 1.0e-5 < e_ref[1] < 1.6e-5                 # the reference's own distance from exact on that frame
     assert (e_dev <= np.maximum(TOL, 1.1 * e_ref)).all()
-    assert e_devx.max() <= 3e-6
+    assert e_devx.max() <= 1e-6
 
 
 # ---- item 2: the limiter at 1e-5 --------------------------------------------------------------------------------
