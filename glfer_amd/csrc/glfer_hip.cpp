@@ -1199,9 +1199,13 @@ static bool route_takes_mean(BodyRoute r, const SpectroParams &sp, int n) {
 // kernel, spectro16y.hip
 static bool route_takes_table(BodyRoute r, const SpectroParams &sp, int n) {
   switch (r) {
+    // (round 4: every form that removes the means itself also takes them GIVEN -- spectro16w.hip's multitaper form (C4 with the
+    // reference's order used to go through the corrected copy: 6.7 against 8.1 M frames/s), spectro16h.hip's multitaper form,
+    // spectro16x / xl's frame loader)
     case ROUTE_PACKED: return true;
-    case ROUTE_REAL_INPUT: return sp.npairs == 1 && sp.htapers <= 1;
-    case ROUTE_SHARED_ODD: return n == 4096;
+    case ROUTE_REAL_INPUT: return true;
+    case ROUTE_SHARED_ODD: return true;
+    case ROUTE_WAVE_PRIVATE: return true;
     default: return false;
   }
 }

@@ -76,14 +76,23 @@ __device__ __forceinline__ void load_frame16_mean(const SpectroParams &p, unsign
   load_frame16<FMT, T, 0>(p, t, fl, fblk, dst);
   constexpr int NH = 16 / KM;
   float mu[NH];
+  if (p.means) {
+    // given means (cfg.sub_mean = 1: the reference's own summation order, submean_seq.hip), indexed by GLOBAL hop = the frame
+    // whose newest hop it is; the samples are floats in sample units here in every format
+    const long long f = fblk + fl;
+    const long long F = p.frame0 + (f < p.nframes ? f : (long long)p.nframes - 1);
 #pragma unroll
-  for (int q = 0; q < NH; q++) {
-    float sm = 0.0f;
+    for (int q = 0; q < NH; q++) mu[q] = p.means[F - (NH - 1) + q];
+  } else {
 #pragma unroll
-    for (int m = 0; m < KM; m++) sm += dst[q * KM + m];
+    for (int q = 0; q < NH; q++) {
+      float sm = 0.0f;
 #pragma unroll
-    for (int o = 1; o < T; o <<= 1) sm += __shfl_xor(sm, o);
-    mu[q] = sm / (float)p.H;                           // fft.c:91
+      for (int m = 0; m < KM; m++) sm += dst[q * KM + m];
+#pragma unroll
+      for (int o = 1; o < T; o <<= 1) sm += __shfl_xor(sm, o);
+      mu[q] = sm / (float)p.H;                         // fft.c:91
+    }
   }
 #pragma unroll
   for (int m = 0; m < 16; m++) dst[m] = dst[m] - mu[m / KM];

@@ -700,6 +700,17 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
     if (g >= 64) g &= ~7u;
     if (p.means) {                                   // the means are given: the table form, at the plain form's occupancy
       constexpr int W = GLFER16H_WAVES_PER_SIMD;
+      // GLFER_MTAB_WPS=2 (experiment, profiles/r04_piecewise_means.txt): two wavefronts per SIMD, so that a hop-means launch of the
+      // NEXT piece (side stream) finds registers and LDS beside this one
+      static const bool two = [] { const char *e = getenv("GLFER_MTAB_WPS"); return e && *e == '2'; }();
+      if (two && W > 2) {
+        if (k16 == 16) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 0, 1, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+        else if (k16 == 2) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 2, 1, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+        else if (k16 == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 4, 1, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+        else if (k16 == 8) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 8, 1, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+      }
       if (k16 == 16) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, W, GLFER16H_VAR, 0, 0, 0, 1, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
       else if (k16 == 2) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, W, GLFER16H_VAR, 0, 0, 2, 1, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);
       else if (k16 == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, W, GLFER16H_VAR, 0, 0, 4, 1, 1>), dim3(g), dim3(LC::BLOCK), 0, st, p);

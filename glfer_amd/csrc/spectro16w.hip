@@ -374,7 +374,14 @@ __global__ __launch_bounds__(LaunchW<LOGN>::BLOCK, WPS) void spectro16w_kernel(S
       if (sj == 0) static_for<0, 16>([&](auto mc) { px[decltype(mc)::value] = raw_pair(mc); });
     }
     if constexpr (KM != 0) {
-      if (sj == 0) {                                       // a new frame in px: its hops' means, once (every wavefront of the workgroup is here)
+      if (sj == 0 && p.means) {
+        // given means (cfg.sub_mean = 1: the reference's own summation order, submean_seq.hip), indexed by GLOBAL hop = the frame
+        // whose newest hop it is; in the units the samples are held in (integer formats: raw, the power of two rides in the tapers)
+        const long long fr = sf + fl < p.nframes ? sf + fl : (long long)p.nframes - 1;
+        const long long F = p.frame0 + fr;
+#pragma unroll
+        for (int q = 0; q < NH; q++) mu[q] = p.means[F - (NH - 1) + q] * (1.0f / kSampleScale);
+      } else if (sj == 0) {                                // a new frame in px: its hops' means, once (every wavefront of the workgroup is here)
         float part[NH];
 #pragma unroll
         for (int q = 0; q < NH; q++) part[q] = 0.0f;
