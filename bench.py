@@ -336,21 +336,26 @@ def valu_view(res):
 
 
 def hparma_view(res):
-    """HP-ARMA is neither HBM- nor FP32-bound: a counted FP64 model of hparma_do (hparma.c:74-157 +
-    compute_svd, util.c:261-386) at t = 128, p_e = 32: t lags x N double multiply-adds; the one-sided
-    Jacobi SVD, >= 12 sweeps x 528 column pairs x (three length-t dot products + the rotation of two
-    columns of the t x 33 matrix and of the 33 x 33 accumulator); Horner over N/2+1 bins x 33
-    coefficients, complex.  A LOWER bound (12 sweeps is the minimum the reference runs)."""
+    """HP-ARMA is neither HBM- nor FP32-bound: a counted FP64 model of hparma_do (hparma.c:74-157 + compute_svd,
+    util.c:261-386) at t = 128, p_e = 32 ON THIS STREAM: t lags x N double multiply-adds; the one-sided Jacobi SVD -- the
+    three length-t dot products of every TESTED column pair and, for every pair actually ROTATED, two columns of the
+    t x 33 matrix and of the 33 x 33 accumulator; Horner over N/2+1 bins x 33 coefficients, complex.  The loop runs until a
+    sweep rotates nothing: on the bench stream 8-9 sweeps of 528 tested pairs and 2 567-2 959 rotations per frame
+    (tools/hparma_sweep_count.py); the model takes the smallest (8 x 528 tested, 2 567 rotated): a LOWER bound.  (Rounds 1-3
+    counted 12 full sweeps -- sweepmax's floor, which the loop does not wait for -- and so overstated the fraction by 1.7x.)"""
     n, frames, kernel_ms = res["n"], res["frames"], res["kernel_ms"]
     t_, ncol = 128, 33
-    flops = 2.0 * t_ * n + 12 * (ncol * (ncol - 1) / 2) * (3 * 2 * t_ + 6 * t_ + 6 * ncol) + (n / 2 + 1) * ncol * 8
+    tested, rotated = 8 * (ncol * (ncol - 1) // 2), 2567
+    flops = 2.0 * t_ * n + tested * (3 * 2 * t_) + rotated * (6 * t_ + 6 * ncol) + (n / 2 + 1) * ncol * 8
     tf = frames * flops / (kernel_ms * 1e-3) / 1e12
-    return {"model": "counted FP64 flops of hparma_do, lower bound (12 Jacobi sweeps)", "flops_per_frame_f64": flops,
+    return {"model": "counted FP64 flops of hparma_do on this stream, lower bound (8 sweeps of 528 tested pairs, 2 567 rotations: tools/hparma_sweep_count.py)",
+            "flops_per_frame_f64": flops,
             "achieved_TFLOPs": tf, "peak_TFLOPs": 78.6, "frac": tf / 78.6,
-            "note": "bound by the vector instructions a Jacobi rotation issues (most of them double precision at 4 clocks each), not by latency "
-                    "(12 frames in flight per CU instead of 7: no change); one wavefront per frame walks the rotations in the reference's "
-                    "order.  Round 3: the rotation's three 64-lane sums share one reduction tree and its ratio test needs no division "
-                    "(0.42 -> 0.52 M frames/s, profiles/r03_hparma_shared_sums.txt)"}
+            "note": "bound by the double-precision vector instructions of the Jacobi rotations (4 clocks each) and, at seven wavefronts per CU "
+                    "(22 KB of LDS per frame), by the chain of ~60 dependent ones in a step's angle.  Round 4: column-disjoint rotations run side by "
+                    "side -- the sweep as a static schedule of eight rotations per step over 8-lane octets, 80 steps instead of 528 rotations; the "
+                    "reference's order among rotations that share a column, every rotation's arithmetic and the per-sweep count unchanged "
+                    "(0.526 -> 1.16 M frames/s, profiles/r04_hparma_schedule.txt)"}
 
 
 def parity_vs_oracle(torch, G, workload, local, frames=64):
