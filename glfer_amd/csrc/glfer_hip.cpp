@@ -1410,6 +1410,38 @@ static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroPara
   if (e != hipSuccess) return hip_fail(e, "scratch (hop means)");
   SpectroParams q = bs;
   q.means = means - hop_lo;                                                    // indexed by GLOBAL hop (= frame) index
+  // THE FUSED LAUNCH (round 4, the periodogram's table form, N <= 8192): the hop means are produced INSIDE the estimator's
+  // launch -- its first workgroups run the 64-hops-side-by-side chains of submean_seq.hip, the others transform and wait for
+  // the chunks of means their frames need (spectro16h.hip produce_hop_means).  One launch, so the two kinds of workgroup are
+  // co-resident whatever the streams' scheduling does: the means' read of the stream rides in the HBM bandwidth the
+  // periodogram kernel leaves idle (it runs at 0.52-0.58 of the peak) instead of in front of it.  A producer workgroup per CU
+  // leaves the transform two wavefronts per SIMD -- the occupancy at which it runs as fast as at three.
+  // GLFER_MEANS_PRODUCERS: producer workgroups (a multiple of 8; 0 = the separate launch).
+  {
+    const long producers = [] { const char *e = getenv("GLFER_MEANS_PRODUCERS"); return e && *e ? atol(e) : 256L; }();
+    const bool periodogram_table = body_route(bs, p->n) == ROUTE_REAL_INPUT && bs.npairs == 1 && bs.htapers <= 1 && p->n <= 8192;
+    // (short launches: the producers' lead over the first consumers is a bubble of nhops / producers' rate -- keep the two launches)
+    const long min_frames = [] { const char *e = getenv("GLFER_FUSED_MIN_FRAMES"); return e && *e ? atol(e) : 65536L; }();   // (tests lower it)
+    if (producers > 0 && periodogram_table && npieces == 1 && (long)(b1 - b0) >= min_frames) {
+      const int chunk = 4096;
+      const size_t nchunks = (nhops + chunk - 1) / chunk;
+      unsigned *ready = nullptr;
+      e = glfer::scratch_malloc((void **)&ready, nchunks * sizeof(unsigned), st);
+      if (e == hipSuccess) e = hipMemsetAsync(ready, 0, nchunks * sizeof(unsigned), st);
+      if (e == hipSuccess) {
+        q.nprod = (int)(producers / 8 * 8);
+        q.prod_chunk = chunk;
+        q.means_out = means - hop_lo;
+        q.means_ready = ready;
+        q.prod_hop0 = (long long)hop_lo;
+        q.prod_nhops = (long long)nhops;
+        e = launch_by_n(q, p->n, st);
+      }
+      if (ready) glfer::scratch_free(ready, st);
+      glfer::scratch_free(means, st);
+      return e == hipSuccess ? GLFER_OK : hip_fail(e, "estimator launch (hop means produced in the launch)");
+    }
+  }
   static std::mutex aux_mu;
   bool own_aux = false;
   if (nstreams > 1) {                                                          // the side streams and their events, once per plan

@@ -113,6 +113,54 @@ struct LaunchH {
 // frame's wavefronts combined through LDS across the iteration's last barrier -- no extra barrier);
 // the older hops' means move down with the frames a slot walks.  Wherever and whenever a hop's
 // mean is formed, it is formed from the same lanes' same registers in the same order: one value.
+// Producer side of the fused launch (SpectroParams::nprod): hop means in the reference's own order (fft.c:88-92: a float
+// accumulated sample after sample) for hops [prod_hop0, prod_hop0 + prod_nhops), the shape of submean_seq.hip -- a lane walks a
+// hop, 64 hops side by side in a wavefront, the samples coming in coalesced and transposed through a wavefront-private LDS
+// tile (here [64 hops][32 samples], row stride 33: 8.4 KB a wavefront out of the workgroup's exchange buffer) -- as waves of a
+// launch whose other workgroups transform.  A wavefront takes hop groups g = its index, + the number of producer wavefronts,
+// ...: in stream order, which is the order the consumer workgroups are dispatched in.  When a group's means are written (and
+// fenced) one lane adds 1 to the group's chunk counter; a consumer polls the counters of the chunks its hops lie in.
+template <int FMT>
+__device__ __forceinline__ void produce_hop_means(const SpectroParams &p, float *tile, unsigned lane, long long wave, long long nwaves) {
+  constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
+  const int H = p.H;
+  const long long groups = (p.prod_nhops + 63) / 64;
+  const unsigned half = lane >> 5, l32 = lane & 31u;
+  for (long long g = wave; g < groups; g += nwaves) {
+    const long long hop0 = p.prod_hop0 + g * 64;
+    const long long left = p.prod_hop0 + p.prod_nhops - hop0;
+    const int rows = (int)(left < 64 ? left : 64);
+    const long long span = (long long)rows * H * esz;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + hop0 * (long long)H * esz, 0,
+        (unsigned)(span > 0x7fffffffLL ? 0x7fffffffLL : span), 0x00020000);
+    float v[32];
+    auto fetch = [&](int k0) {                       // instruction j: hops 2j (lanes 0-31) and 2j + 1 (lanes 32-63), sample k0 + (lane & 31)
+      const unsigned base = k0 + (int)l32 < H ? ((unsigned)half * (unsigned)H + (unsigned)(k0 + (int)l32)) * esz : 0x80000000u;
+#pragma unroll
+      for (int j = 0; j < 32; j++) v[j] = buf_sample<FMT>(rs, base + (unsigned)(2 * j) * (unsigned)H * esz, 0u);
+    };
+    float s = 0.0f;
+    fetch(0);
+    for (int k0 = 0; k0 < H; k0 += 32) {
+#pragma unroll
+      for (int j = 0; j < 32; j++) tile[(2 * j + (int)half) * 33 + (int)l32] = v[j];
+      if (k0 + 32 < H) fetch(k0 + 32);               // the next tile's loads fly under this tile's chain
+      const int kn = H - k0 < 32 ? H - k0 : 32;
+      const float *row = tile + lane * 33;
+      if (kn == 32) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) s += row[k];    // fft.c:89-91: one float add per sample, in order (adds only: nothing to contract)
+      } else {
+        for (int k = 0; k < kn; k++) s += row[k];
+      }
+    }
+    if ((int)lane < rows) p.means_out[hop0 + lane] = s / (float)H;   // fft.c:92: float /= int
+    __threadfence();                                 // the group's means before its count (agent scope: the consumers sit on other XCDs)
+    if (lane == 0) atomicAdd(p.means_ready + (g * 64) / p.prod_chunk, 1u);
+  }
+}
+
 // MTAB = 1 (with MEAN = 1; round 4): the hop means are GIVEN (p.means, the reference's own summation order,
 // submean_seq.hip) -- a form of its own, so that it carries none of the summing code: it fits the three
 // wavefronts per SIMD of the plain periodogram where the summing form needs two, and the next frame's
@@ -146,6 +194,21 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   __shared__ float mred[MEAN && !MTAB ? FPB * WPF * NH : 1];      // MEAN: the frame's wavefronts' partial sums
 
   const unsigned tid = threadIdx.x;
+  // the fused launch (MTAB, p.nprod > 0): the first nprod workgroups produce the hop means, the others are the launch as it was
+  unsigned grid_w = gridDim.x, block_w = blockIdx.x;
+  if constexpr (MTAB != 0) {
+    if (p.nprod > 0) {
+      if (blockIdx.x < (unsigned)p.nprod) {
+        static_assert(L::BLOCK % 64 == 0 && (L::BLOCK / 64) * 64 * 33 * 4 <= L::LDS_WORDS * 8, "a [64][33] float tile per wavefront out of the exchange buffer");
+        const unsigned wv = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+        produce_hop_means<FMT>(p, reinterpret_cast<float *>(lds) + wv * (64 * 33), tid & 63u, (long long)blockIdx.x * (L::BLOCK / 64) + wv,
+                               (long long)p.nprod * (L::BLOCK / 64));
+        return;
+      }
+      grid_w = gridDim.x - (unsigned)p.nprod;
+      block_w = blockIdx.x - (unsigned)p.nprod;
+    }
+  }
   const unsigned t = tid % T;
   const unsigned fl = tid / T;
   v2f32 *xb = lds + fl * PADM;
@@ -324,9 +387,30 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   // whatever the other workgroups are doing.  (Neighbouring ranges sit on the same XCD:
   // xcd_block_index.)  Without SHIFT the FPB slots take adjacent frames each iteration (measured:
   // 2 % better than a contiguous part per slot); with SHIFT each slot needs consecutive frames.
-  const long long per = ((long long)p.nframes + (long long)gridDim.x * FPB - 1) / ((long long)gridDim.x * FPB);   // frames per slot
-  start = (long long)xcd_block_index() * per * FPB;
+  const long long per = ((long long)p.nframes + (long long)grid_w * FPB - 1) / ((long long)grid_w * FPB);   // frames per slot
+  // (xcd_block_index() over the consumer part of the grid: workgroup w runs on XCD w mod 8 whatever the producers in front)
+  const unsigned lblock = (grid_w & 7u) || (MTAB != 0 && (p.nprod & 7)) ? block_w : (block_w & 7u) * (grid_w >> 3) + (block_w >> 3);
+  start = (long long)lblock * per * FPB;
   if (start >= p.nframes) return;
+  if constexpr (MTAB != 0) {
+    if (p.nprod > 0) {
+      // this workgroup's hops: the newest hop of frame F is hop F, a frame reaches NH - 1 hops back.  Wait for their chunks (the
+      // producers walk the stream in order, as the consumers are dispatched); every wavefront polls for itself, so that the
+      // acquire that follows is its own.  The poll is bounded: a launch must end whatever happens to its producers.
+      const long long left = p.nframes - start, span = per * FPB;
+      const long long h_lo = p.frame0 + start - (NH - 1), h_hi = p.frame0 + start + (left < span ? left : span);   // [h_lo, h_hi)
+      const long long c_lo = (h_lo - p.prod_hop0) / p.prod_chunk, c_hi = (h_hi - 1 - p.prod_hop0) / p.prod_chunk;
+      for (long long c = c_lo; c <= c_hi; c++) {
+        const long long in_chunk = p.prod_nhops - c * p.prod_chunk < p.prod_chunk ? p.prod_nhops - c * p.prod_chunk : p.prod_chunk;
+        const unsigned need = (unsigned)((in_chunk + 63) / 64);
+        for (int spin = 0; spin < (1 << 24); spin++) {
+          if (__hip_atomic_load(p.means_ready + c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+          __builtin_amdgcn_s_sleep(16);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
   auto rel_of = [&](long long i) { return SHIFT > 0 ? (long long)fl * per + i : i * FPB + (long long)fl; };
   long long it = 0;                                        // frames done by every slot
   prefetch_x(rel_of(0));
@@ -700,6 +784,11 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
     if (g >= 64) g &= ~7u;
     if (p.means) {                                   // the means are given: the table form, at the plain form's occupancy
       constexpr int W = GLFER16H_WAVES_PER_SIMD;
+      if (p.nprod > 0) {                             // the fused launch: producers in front of the grid as it would have been
+        if (p.nprod & 7) return hipErrorInvalidValue;
+        grid += (unsigned)p.nprod;
+        g += (unsigned)p.nprod;
+      }
       // GLFER_MTAB_WPS=2 (experiment, profiles/r04_piecewise_means.txt): two wavefronts per SIMD, so that a hop-means launch of the
       // NEXT piece (side stream) finds registers and LDS beside this one
       static const bool two = [] { const char *e = getenv("GLFER_MTAB_WPS"); return e && *e == '2'; }();

@@ -51,6 +51,15 @@ struct SpectroParams {
   const float *means;      /* device, optional (with mean_inkernel): means[h] = the mean of hop h of the whole stream (virtual
                               base), taken in the reference's own order (submean_seq.hip, GLFER_SUBMEAN_EXACT); the kernel
                               subtracts these instead of summing the hops itself                */
+  /* spectro16h.hip's table form with the means PRODUCED INSIDE THE SAME LAUNCH (round 4): the first nprod workgroups take the
+     hop means in the reference's own order (the 64-hops-side-by-side chains of submean_seq.hip) while the others transform;
+     a consumer workgroup waits for the chunks its frames' hops lie in.  nprod = 0: the means table was filled by an earlier launch. */
+  int nprod;               /* producer workgroups at the head of the grid                                            */
+  int prod_chunk;          /* hops per chunk of means_ready (a multiple of 64)                                       */
+  float *means_out;        /* = means, writable                                                                       */
+  unsigned *means_ready;   /* device: [ceil(prod_nhops / prod_chunk)] hop groups of the chunk that are written (zeroed before the launch) */
+  long long prod_hop0;     /* the hops to produce: [prod_hop0, prod_hop0 + prod_nhops) of the whole stream             */
+  long long prod_nhops;
 };
 
 #ifdef __cplusplus

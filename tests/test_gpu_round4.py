@@ -164,7 +164,7 @@ def test_reference_means_piece_by_piece(lib, oracle, torch_cuda, case):
               lib.MtmParams(n=n, overlap=overlap, w=2.5, kmax=4, sub_mean=lib.SUBMEAN_EXACT, sample_format=sf))
     sp = lib.Spectrogram(params)
     d = torch.from_numpy(raw).cuda()
-    knobs = ("GLFER_EXACT_PIECE_MB", "GLFER_EXACT_STREAMS", "GLFER_MEANS_HPW", "GLFER_MEANS_BLOCKS")
+    knobs = ("GLFER_EXACT_PIECE_MB", "GLFER_EXACT_STREAMS", "GLFER_MEANS_HPW", "GLFER_MEANS_BLOCKS", "GLFER_MEANS_PRODUCERS", "GLFER_FUSED_MIN_FRAMES")
     saved = {k: os.environ.get(k) for k in knobs}
 
     def run(**env):
@@ -176,8 +176,11 @@ def test_reference_means_piece_by_piece(lib, oracle, torch_cuda, case):
         torch.cuda.synchronize()
         return out
     try:
-        base = run(GLFER_EXACT_PIECE_MB=0, GLFER_MEANS_HPW=64)
-        for env in (dict(), dict(GLFER_EXACT_PIECE_MB=1, GLFER_EXACT_STREAMS=1, GLFER_MEANS_HPW=16),
+        base = run(GLFER_EXACT_PIECE_MB=0, GLFER_MEANS_HPW=64, GLFER_MEANS_PRODUCERS=0)
+        # ... and the fused launch (the periodogram's table form: the means produced by the launch's own first workgroups)
+        for env in (dict(), dict(GLFER_FUSED_MIN_FRAMES=64, GLFER_MEANS_PRODUCERS=8), dict(GLFER_FUSED_MIN_FRAMES=64, GLFER_MEANS_PRODUCERS=64),
+                    dict(GLFER_FUSED_MIN_FRAMES=64, GLFER_MEANS_PRODUCERS=256),
+                    dict(GLFER_EXACT_PIECE_MB=1, GLFER_EXACT_STREAMS=1, GLFER_MEANS_HPW=16),
                     dict(GLFER_EXACT_PIECE_MB=1, GLFER_EXACT_STREAMS=2, GLFER_MEANS_HPW=4, GLFER_MEANS_BLOCKS=8),
                     dict(GLFER_EXACT_PIECE_MB=1, GLFER_EXACT_STREAMS=3, GLFER_MEANS_HPW=16, GLFER_MEANS_BLOCKS=8),
                     dict(GLFER_EXACT_PIECE_MB=2, GLFER_EXACT_STREAMS=3, GLFER_MEANS_HPW=64)):
@@ -189,6 +192,10 @@ def test_reference_means_piece_by_piece(lib, oracle, torch_cuda, case):
                 os.environ.pop(k, None)
             os.environ["GLFER_EXACT_PIECE_MB"] = "1"
             part = sp.run(d, first_frame=64, nframes=frames - 101).cpu().numpy()
+            os.environ["GLFER_EXACT_PIECE_MB"] = "0"
+            os.environ["GLFER_FUSED_MIN_FRAMES"] = "64"
+            part_fused = sp.run(d, first_frame=64, nframes=frames - 101).cpu().numpy()
+            assert np.array_equal(part_fused.view(np.uint32), part.view(np.uint32))
     finally:
         for k, v in saved.items():
             if v is None:
