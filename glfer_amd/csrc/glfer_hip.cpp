@@ -1410,15 +1410,17 @@ static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroPara
   if (e != hipSuccess) return hip_fail(e, "scratch (hop means)");
   SpectroParams q = bs;
   q.means = means - hop_lo;                                                    // indexed by GLOBAL hop (= frame) index
-  // THE FUSED LAUNCH (round 4, the periodogram's table form, N <= 8192): the hop means are produced INSIDE the estimator's
-  // launch -- its first workgroups run the 64-hops-side-by-side chains of submean_seq.hip, the others transform and wait for
-  // the chunks of means their frames need (spectro16h.hip produce_hop_means).  One launch, so the two kinds of workgroup are
-  // co-resident whatever the streams' scheduling does: the means' read of the stream rides in the HBM bandwidth the
-  // periodogram kernel leaves idle (it runs at 0.52-0.58 of the peak) instead of in front of it.  A producer workgroup per CU
-  // leaves the transform two wavefronts per SIMD -- the occupancy at which it runs as fast as at three.
-  // GLFER_MEANS_PRODUCERS: producer workgroups (a multiple of 8; 0 = the separate launch).
+  // THE FUSED LAUNCH (round 4, the periodogram's table form, N <= 8192; an EXPERIMENT, off by default): the hop means are
+  // produced INSIDE the estimator's launch -- its first workgroups run the 64-hops-side-by-side chains of submean_seq.hip, the
+  // others transform and wait for the chunks of means their frames need (spectro16h.hip produce_hop_means) -- so that the two
+  // kinds of workgroup are co-resident whatever the streams' scheduling does and the means' read of the stream could ride in
+  // the HBM bandwidth the periodogram kernel leaves idle.  Measured (profiles/r04_piecewise_means.txt): correct (rows
+  // bit-identical), and NOT faster -- C1 753 M frames/s with 512 producer workgroups against 787 with the separate launch: the
+  // fused launch moves its 12.9 GB at the same 4.6 TB/s the periodogram kernel reaches alone; the chip's rate for this 2 : 1
+  // read : write mix, not idle time, is what the second read of the stream costs.
+  // GLFER_MEANS_PRODUCERS: producer workgroups (a multiple of 8; 0 = the separate launch, the default).
   {
-    const long producers = [] { const char *e = getenv("GLFER_MEANS_PRODUCERS"); return e && *e ? atol(e) : 256L; }();
+    const long producers = [] { const char *e = getenv("GLFER_MEANS_PRODUCERS"); return e && *e ? atol(e) : 0L; }();
     const bool periodogram_table = body_route(bs, p->n) == ROUTE_REAL_INPUT && bs.npairs == 1 && bs.htapers <= 1 && p->n <= 8192;
     // (short launches: the producers' lead over the first consumers is a bubble of nhops / producers' rate -- keep the two launches)
     const long min_frames = [] { const char *e = getenv("GLFER_FUSED_MIN_FRAMES"); return e && *e ? atol(e) : 65536L; }();   // (tests lower it)
