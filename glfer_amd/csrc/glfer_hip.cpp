@@ -616,7 +616,13 @@ int glfer_hip_waterfall_map_device(const glfer_hip_display *d, int avg_mode, int
                            hip_stream, d_levels, d->psd_pitch);
 }
 
-size_t glfer_hip_scratch_trim(int device, size_t keep_bytes) { return glfer::scratch_trim(device, keep_bytes); }
+size_t glfer_hip_scratch_trim(int device, size_t keep_bytes) {
+  if (keep_bytes == 0 && device >= 0 && device < 64) {       // "give everything back": the parked ingest ring too
+    DeviceGuard guard(device);
+    if (guard.error() == hipSuccess) glfer::ingest_ring_drop_spare(device);
+  }
+  return glfer::scratch_trim(device, keep_bytes);
+}
 size_t glfer_hip_scratch_held(int device) { return glfer::scratch_held(device); }
 void glfer_hip_scratch_limit(size_t bytes) { glfer::scratch_set_cap(bytes); }
 

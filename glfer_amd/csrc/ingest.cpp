@@ -32,7 +32,45 @@ using glfer::DeviceGuard;
 using glfer::hip_fail;
 
 namespace glfer {
+// ONE idle ring per device outlives its plan (round 4): the *_multi / *_workers entries make a plan per worker and per call, and a
+// ring is ~0.5 GB of pinned and device memory that takes 30-40 ms to allocate -- half of what a 1-hour WAV costs end to end.  A
+// destroyed plan parks its ring here (if the slot is empty and the ring under the cap), a new plan's first job takes it.
+// glfer_hip_scratch_trim(device, 0) frees it with the kept scratch.
+static std::mutex g_spare_mu;
+static IngestRing *g_spare_ring[64] = {nullptr};
+static size_t ring_bytes(const IngestRing *r) {
+  size_t b = 0;
+  for (int i = 0; i < 2; i++)
+    for (int k = 0; k < 8; k++) b += r->cap[i][k];
+  return b;
+}
+IngestRing *ingest_ring_take(int dev) {
+  if (dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_spare_mu);
+  IngestRing *r = g_spare_ring[dev];
+  g_spare_ring[dev] = nullptr;
+  return r;
+}
+static void ingest_ring_destroy(IngestRing *r);
+void ingest_ring_drop_spare(int dev) {            // with `dev` current
+  IngestRing *r = ingest_ring_take(dev);
+  if (r) ingest_ring_destroy(r);
+}
 void ingest_ring_free(IngestRing *r) {          // with the ring's device current (plan_destroy, run_job)
+  if (!r) return;
+  int dev = -1;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !r->busy && ring_bytes(r) <= ((size_t)2 << 30)) {
+    for (int i = 0; i < 2; i++)
+      if (r->st[i]) (void)hipStreamSynchronize(r->st[i]);
+    std::lock_guard<std::mutex> lock(g_spare_mu);
+    if (!g_spare_ring[dev]) {
+      g_spare_ring[dev] = r;
+      return;
+    }
+  }
+  ingest_ring_destroy(r);
+}
+static void ingest_ring_destroy(IngestRing *r) {
   if (!r) return;
   for (int i = 0; i < 2; i++) {
     if (r->st[i]) (void)hipStreamSynchronize(r->st[i]);
@@ -192,6 +230,7 @@ int run_job(const Job &job, size_t *frames_done) {
   bool own_ring = false;
   {
     std::lock_guard<std::mutex> lock(g_ring_mu);
+    if (!p->ring) p->ring = glfer::ingest_ring_take(p->cfg.device);      // the device's parked ring, if any (its buffers grow on demand)
     if (!p->ring) p->ring = new glfer::IngestRing();
     if (!p->ring->busy) {
       p->ring->busy = true;

@@ -67,7 +67,9 @@ struct IngestRing {
   size_t cap[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
   bool busy = false;
 };
-void ingest_ring_free(IngestRing *r);
+void ingest_ring_free(IngestRing *r);          // parks the ring as the device's spare, or frees it
+IngestRing *ingest_ring_take(int dev);         // the device's parked ring (the caller owns it), or null
+void ingest_ring_drop_spare(int dev);          // frees the parked ring (glfer_hip_scratch_trim)
 
 }  // namespace glfer
 

@@ -471,7 +471,11 @@ int glfer_hip_waterfall_wav_multi(const glfer_hip_config *cfg, unsigned device_m
  *                                         buffers in fft_close, fft.c:297-306; a GUI host calls this
  *                                         when a waterfall is closed or the block size changes.)
  *   glfer_hip_scratch_held(device)        bytes kept right now.
- * GLFER_SCRATCH_CACHE=0 in the environment disables keeping altogether. */
+ * GLFER_SCRATCH_CACHE=0 in the environment disables keeping altogether.
+ * Besides the scratch blocks, ONE idle chunk ring of the host / file entries (two pinned sample buffers, two device buffers each
+ * way; at most 2 GiB) is parked per device when its plan is destroyed and taken by the next plan that needs one -- the *_multi /
+ * *_workers entries make a plan per worker and call, and allocating a ring costs 30-40 ms; glfer_hip_scratch_trim(device, 0)
+ * frees it too. */
 size_t glfer_hip_scratch_trim(int device, size_t keep_bytes);
 size_t glfer_hip_scratch_held(int device);
 void glfer_hip_scratch_limit(size_t bytes);
