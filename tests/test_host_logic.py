@@ -135,6 +135,14 @@ def test_argument_errors(lib):
             lib.Spectrogram(lib.FftParams(**kw))
     with pytest.raises(api.GlferHipError, match="bad argument"):
         lib.Spectrogram(lib.MtmParams(n=1024, w=0.0, kmax=3))
+    # cfg.psd_pitch (round 4): at least N/2+1 floats, not negative, not with the LMP statistic
+    for pitch in (512, 1, -16):
+        with pytest.raises(api.GlferHipError, match="bad argument"):
+            lib.Spectrogram(lib.FftParams(n=1024, overlap=0.0, window_type=0, psd_pitch=pitch))
+    lp = lib.LmpParams(n=1024, overlap=0.5, avg=4)
+    lp.psd_pitch = 528
+    with pytest.raises(api.GlferHipError, match="bad argument"):
+        lib.Spectrogram(lp)
     with pytest.raises(api.GlferHipError):
         lib.make_window(12, 64)
 
