@@ -452,3 +452,21 @@ def test_per_column_stages_read_pitched_rows(lib, torch_cuda):
         assert L.glfer_hip_waterfall_device(C.byref(dpp), int(mode), 4, 10, 2000, 1, rows.data_ptr(), frames, bins, p_rgb.data_ptr(),
                                             p_lev.data_ptr(), None, st) == 0
         assert torch.equal(w_rgb, p_rgb) and torch.equal(w_lev, p_lev), mode
+
+
+@pytest.mark.parametrize("n,t,p_e", [(1024, 128, 63), (512, 8, 1), (2048, 64, 2), (1024, 100, 40), (4096, 124, 31), (1024, 66, 16)])
+def test_hparma_schedule_over_matrix_shapes(lib, oracle, torch_cuda, n, t, p_e):
+    """The static rotation schedule (hparma.hip, round 4) at the edges of its range: 64 columns (the widest it takes), 2 and 3
+    columns (one and two steps per sweep), t = 100 / 124 (partly filled row chunks), an odd column count, and t = 66 (not a
+    multiple of 4: round 3's walk takes it) -- |A(f)|^2 / N against the oracle at the HP-ARMA tolerance."""
+    h = oracle.hop(n, 0.0)
+    frames = 6
+    x = synth(frames * h, seed=n + t + p_e)
+    ref = oracle.hparma_frames(x, n, 0.0, t, p_e, sub_mean=0)
+    got = lib.Spectrogram(lib.HparmaParams(n=n, overlap=0.0, t=t, p_e=p_e)).run(torch_cuda.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
+    for f in range(frames):
+        want = ref[f][0].astype(np.float64)
+        # (two columns put a zero of A(z) at z = 1: the reciprocal at bin 0 is inf in the reference too)
+        assert np.array_equal(np.isfinite(got[f]), np.isfinite(want)), (n, t, p_e, f)
+        e = max(rel_err(1.0 / got[f, :n // 2], 1.0 / want[:n // 2]))
+        assert e < 1e-4, (n, t, p_e, f, e)
