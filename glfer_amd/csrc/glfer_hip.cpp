@@ -20,7 +20,7 @@
 #include "host_tables.h"
 #include "spectro_params.h"
 
-extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const int *rot_sched, int rot_steps, const uint16_t *lagmap,
+extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const int *rot_sched, int rot_steps, int rot_width, const uint16_t *lagmap,
                                           const float2 *unit, hipStream_t st);
 extern "C" hipError_t glfer_launch_floor(const float *psd, size_t nframes, int bins, int pitch, int m, float *stats,
                                          hipStream_t st);
@@ -897,6 +897,9 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     // which (j, k) waits for the last earlier rotation on column j and the last on column k; list scheduling by longest
     // remaining path fills steps of eight: 80 steps for 33 columns (66 would be full steps; anti-diagonal by anti-diagonal
     // it is 94).
+    // GLFER_HPARMA_WIDTH=16: sixteen rotations per step, each over 4 lanes (A/B runs; 63 steps for 33 columns -- the critical path)
+    const int width = [] { const char *e = getenv("GLFER_HPARMA_WIDTH"); return e && atoi(e) == 16 ? 16 : 8; }();
+    p->rot_width = width;
     if (ncol >= 2 && ncol <= 64) {
       std::vector<std::pair<int, int>> rots;
       for (int j = 0; j < ncol - 1; j++)
@@ -924,10 +927,10 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
       int done = 0;
       while (done < R) {
         std::sort(ready.begin(), ready.end(), [&](int a, int b) { return lp[a] != lp[b] ? lp[a] > lp[b] : a < b; });
-        const int take = std::min<int>(8, (int)ready.size());
+        const int take = std::min<int>(width, (int)ready.size());
         std::vector<int> cur(ready.begin(), ready.begin() + take);
         ready.erase(ready.begin(), ready.begin() + take);
-        for (int g = 0; g < 8; g++) rot_sched.push_back(g < take ? (rots[cur[g]].first | rots[cur[g]].second << 8) : -1);
+        for (int g = 0; g < width; g++) rot_sched.push_back(g < take ? (rots[cur[g]].first | rots[cur[g]].second << 8) : -1);
         for (int i : cur) {
           done++;
           for (int s : succ[i])
@@ -1004,7 +1007,7 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
     if (e == hipSuccess && !rot_sched.empty()) {
       e = hipMalloc((void **)&p->d_rot_sched, rot_sched.size() * sizeof(int));
       if (e == hipSuccess) e = hipMemcpy(p->d_rot_sched, rot_sched.data(), rot_sched.size() * sizeof(int), hipMemcpyHostToDevice);
-      p->rot_steps = (int)(rot_sched.size() / 8);
+      p->rot_steps = (int)(rot_sched.size() / p->rot_width);
     }
     if (e == hipSuccess) e = hipMemcpy(p->d_unit, unit.data(), unit.size() * sizeof(float), hipMemcpyHostToDevice);
   }
@@ -1636,7 +1639,7 @@ int glfer_run_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, s
     }
   } else if (rc == GLFER_OK) {
     hipError_t e = p->cfg.mode == GLFER_MODE_HPARMA
-                       ? glfer_launch_hparma(&sp, p->n, p->cfg.hparma_t, p->cfg.hparma_p_e + 1, p->d_rot_sched, p->rot_steps, p->d_lagmap, p->d_unit, st)
+                       ? glfer_launch_hparma(&sp, p->n, p->cfg.hparma_t, p->cfg.hparma_p_e + 1, p->d_rot_sched, p->rot_steps, p->rot_width, p->d_lagmap, p->d_unit, st)
                        : launch_by_n(sp, p->n, st);
     if (e != hipSuccess) rc = hip_fail(e, "estimator launch");
   }

@@ -137,6 +137,30 @@ __device__ __forceinline__ void octet_sum3(double &a, double &b, double &c) {
   level(std::integral_constant<int, 0x141>{});   // row_half_mirror: the other quad of the octet
 }
 
+// ... and over the LPR = 8 or 4 lanes a rotation is laid over (4: the two levels inside a quad)
+template <int LPR>
+__device__ __forceinline__ void group_sum3(double &a, double &b, double &c) {
+  if constexpr (LPR == 8) {
+    octet_sum3(a, b, c);
+  } else {
+    static_assert(LPR == 4, "a rotation over 8 or 4 lanes");
+    auto dpp = [](double x, auto ctrl) -> double {
+      constexpr int C = decltype(ctrl)::value;
+      const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+      const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, C, 0xf, 0xf, false);
+      const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), C, 0xf, 0xf, false);
+      return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    };
+    auto level = [&](auto ctrl) {
+      a += dpp(a, ctrl);
+      b += dpp(b, ctrl);
+      c += dpp(c, ctrl);
+    };
+    level(std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    level(std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  }
+}
+
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -149,6 +173,7 @@ struct HparmaParams {
   int ncol;                 // p_e + 1
   const int *sched;         // [nsteps][8]: the Jacobi sweep as steps of up to eight column-disjoint rotations, j | k << 8 or -1 (glfer_hip.cpp)
   int nsteps;
+  int width;                // rotations per step the schedule was built for: 8 (a rotation over 8 lanes) or 16 (over 4)
   const uint16_t *lagmap;   // [t][ncol]: which autocorrelation lag each matrix cell ends up holding
   const float2 *unit;       // [N/2+1]: exp(-2 pi i k / N)
 };
@@ -228,28 +253,31 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
     // then the butterfly), as they already differed from the reference's row-by-row order.  t a multiple of 4, <= 128.
     const bool diag = hp.sched != nullptr && hp.nsteps > 0 && t <= 128 && ncol <= 64 && (t & 3) == 0 && ncol >= 2;
     typedef float v4f32 __attribute__((ext_vector_type(4)));
-    while (diag && count > 0 && sweep <= sweepmax) {
-      const int grp = lane >> 3, l8 = lane & 7;
+    // one sweep of the schedule with a rotation over LPR lanes (64 / LPR rotations per step; hp.width = 64 / LPR is the width the host
+    // scheduled for): a lane holds 128 / LPR rows of the two columns in chunks of four (rows (4 LPR) c + 4 l .. + 3) and rows l, l + LPR ... of Q
+    auto sweep_scheduled = [&](auto lprc) {
+      constexpr int LPR = decltype(lprc)::value, NG = 64 / LPR, NCH = 32 / LPR, NQ = 64 / LPR;
+      const int grp = lane / LPR, ll = lane % LPR;
       int skipped = 0;
       int e = hp.sched[grp];
       for (int s0 = 0; s0 < hp.nsteps; s0++) {
-        const int en = hp.sched[(s0 + 1 < hp.nsteps ? s0 + 1 : s0) * 8 + grp];      // the next step's pair, requested a step ahead
+        const int en = hp.sched[(s0 + 1 < hp.nsteps ? s0 + 1 : s0) * NG + grp];     // the next step's pair, requested a step ahead
         const bool act = e >= 0;
         const int j = act ? (e & 0xff) : 0, k = act ? (e >> 8) : 1;
         float *Aj = A + j * t, *Ak = A + k * t, *Qj = Q + j * ncol, *Qk = Q + k * ncol;
         const v4f32 z4 = v4f32{0.0f, 0.0f, 0.0f, 0.0f};
-        v4f32 aj[4], ak[4];
+        v4f32 aj[NCH], ak[NCH];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const int r = 32 * c + 4 * l8;
+        for (int c = 0; c < NCH; c++) {
+          const int r = 4 * LPR * c + 4 * ll;
           aj[c] = r < t ? *reinterpret_cast<const v4f32 *>(Aj + r) : z4;
           ak[c] = r < t ? *reinterpret_cast<const v4f32 *>(Ak + r) : z4;
         }
-        float qj[8], qk[8];
+        float qj[NQ], qk[NQ];
 #pragma unroll
-        for (int m = 0; m < 8; m++) {                    // (unconditional loads of a clamped row: a branch per load would wait for each in turn)
-          if (8 * m < ncol) {                            // (uniform)
-            const int qr = l8 + 8 * m < ncol ? l8 + 8 * m : ncol - 1;
+        for (int m = 0; m < NQ; m++) {                   // (unconditional loads of a clamped row: a branch per load would wait for each in turn)
+          if (LPR * m < ncol) {                          // (uniform)
+            const int qr = ll + LPR * m < ncol ? ll + LPR * m : ncol - 1;
             qj[m] = Qj[qr];
             qk[m] = Qk[qr];
           } else {
@@ -258,7 +286,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
         }
         double pp = 0.0, qq = 0.0, rr = 0.0;            // (float products are exact in double: fma and multiply + add round alike)
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < NCH; c++) {
 #pragma unroll
           for (int i = 0; i < 4; i++) {
             const double a = aj[c][i], b = ak[c][i];
@@ -267,7 +295,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
             rr = __builtin_fma(b, b, rr);
           }
         }
-        octet_sum3(pp, qq, rr);
+        group_sum3<LPR>(pp, qq, rr);
         bool rotate = act;
         if (qq * rr < 2.22e-16) rotate = false;                                    // util.c:316-320
         else if (pp * pp < 1.0e-12 * (qq * rr)) rotate = false;                    // util.c:321-325, without the division (qq * rr > 0 here)
@@ -289,8 +317,8 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
             ok = (float)(-a * sn + b * cs);
           };
 #pragma unroll
-          for (int c = 0; c < 4; c++) {
-            const int r = 32 * c + 4 * l8;
+          for (int c = 0; c < NCH; c++) {
+            const int r = 4 * LPR * c + 4 * ll;
             if (r < t) {
               float nj[4], nk[4];
 #pragma unroll
@@ -300,13 +328,13 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
             }
           }
 #pragma unroll
-          for (int m = 0; m < 8; m++) {
-            if (8 * m < ncol) {                                                     // (uniform: slots past the last row of Q are skipped)
+          for (int m = 0; m < NQ; m++) {
+            if (LPR * m < ncol) {                                                   // (uniform: slots past the last row of Q are skipped)
               float oj, ok;
               turn(qj[m], qk[m], oj, ok);
-              if (l8 + 8 * m < ncol) {
-                Qj[l8 + 8 * m] = oj;
-                Qk[l8 + 8 * m] = ok;
+              if (ll + LPR * m < ncol) {
+                Qj[ll + LPR * m] = oj;
+                Qk[ll + LPR * m] = ok;
               }
             }
           }
@@ -314,11 +342,15 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
         wave_fence();                                    // the next step's rotations read these columns from other lanes
         e = en;
       }
-      // `count` (util.c:298, 318, 323): the sweep's pairs minus the skipped ones, over the eight octets
+      // `count` (util.c:298, 318, 323): the sweep's pairs minus the skipped ones, over the groups
       int sk = 0;
 #pragma unroll
-      for (int g = 0; g < 8; g++) sk += __builtin_amdgcn_readlane(skipped, 8 * g);
+      for (int g = 0; g < NG; g++) sk += __builtin_amdgcn_readlane(skipped, LPR * g);
       count = ncol * (ncol - 1) / 2 - sk;
+    };
+    while (diag && count > 0 && sweep <= sweepmax) {
+      if (hp.width == 16) sweep_scheduled(std::integral_constant<int, 4>{});
+      else sweep_scheduled(std::integral_constant<int, 8>{});
       sweep++;
     }
     while (!diag && count > 0 && sweep <= sweepmax) {
@@ -484,7 +516,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
 
 using namespace glfer;
 
-extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const int *rot_sched, int rot_steps,
+extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t, int ncol, const int *rot_sched, int rot_steps, int rot_width,
                                           const uint16_t *lagmap, const float2 *unit, hipStream_t st) {
   if (sp->nframes <= 0) return hipSuccess;
   HparmaParams hp;
@@ -494,6 +526,7 @@ extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t,
   hp.ncol = ncol;
   hp.sched = rot_sched;
   hp.nsteps = rot_steps;
+  hp.width = rot_width;
   hp.lagmap = lagmap;
   hp.unit = unit;
   const int big = n > t * ncol ? n : t * ncol;

@@ -103,7 +103,7 @@ struct glfer_hip_plan {
   float *d_ltaps = nullptr;         // odd taper counts, LDS-resident half tables (spectro16xl.hip)
   uint16_t *d_lagmap = nullptr;     // HP-ARMA: [t][p_e+1] lag held by each matrix cell
   int *d_rot_sched = nullptr;       // HP-ARMA: [rot_steps][8] the Jacobi sweep as steps of up to eight column-disjoint rotations (j | k << 8, -1 = none)
-  int rot_steps = 0;
+  int rot_steps = 0, rot_width = 8;
   float2 *d_unit = nullptr;         // HP-ARMA: [n/2+1] exp(-2 pi i k/n)
   // harmonic F-test (mtm.c:124-136): built on first use
   float *d_ftaps_mu_first = nullptr;   // the allocation: [hn][taper 0..ntapers-1][hn], each [2n] alone in slot 0 of the packed layout
