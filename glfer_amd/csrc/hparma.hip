@@ -185,7 +185,9 @@ __device__ __forceinline__ float hp_sample(__amdgpu_buffer_rsrc_t rsrc, unsigned
   else return ((float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsrc, voff, 0, 0) - 128.0f) / 128.0f;
 }
 
-template <int FMT>
+// LPR: lanes a scheduled rotation is laid over (8: eight rotations per step, the product; 4: sixteen -- a kernel of its own, so that
+// its registers do not cost the other form its occupancy)
+template <int FMT, int LPR = 8>
 __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SpectroParams &p = hp.s;
@@ -251,12 +253,12 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
     // and the ~80 double-precision instructions of the angle (two divisions, two square roots) are issued once for eight
     // rotations.  Every rotation's own arithmetic is what it was; the sums associate differently (sixteen rows in a lane,
     // then the butterfly), as they already differed from the reference's row-by-row order.  t a multiple of 4, <= 128.
-    const bool diag = hp.sched != nullptr && hp.nsteps > 0 && t <= 128 && ncol <= 64 && (t & 3) == 0 && ncol >= 2;
+    const bool diag = hp.sched != nullptr && hp.nsteps > 0 && hp.width == 64 / LPR && t <= 128 && ncol <= 64 && (t & 3) == 0 && ncol >= 2;
     typedef float v4f32 __attribute__((ext_vector_type(4)));
     // one sweep of the schedule with a rotation over LPR lanes (64 / LPR rotations per step; hp.width = 64 / LPR is the width the host
     // scheduled for): a lane holds 128 / LPR rows of the two columns in chunks of four (rows (4 LPR) c + 4 l .. + 3) and rows l, l + LPR ... of Q
-    auto sweep_scheduled = [&](auto lprc) {
-      constexpr int LPR = decltype(lprc)::value, NG = 64 / LPR, NCH = 32 / LPR, NQ = 64 / LPR;
+    auto sweep_scheduled = [&] {
+      constexpr int NG = 64 / LPR, NCH = 32 / LPR, NQ = 64 / LPR;
       const int grp = lane / LPR, ll = lane % LPR;
       int skipped = 0;
       int e = hp.sched[grp];
@@ -349,8 +351,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
       count = ncol * (ncol - 1) / 2 - sk;
     };
     while (diag && count > 0 && sweep <= sweepmax) {
-      if (hp.width == 16) sweep_scheduled(std::integral_constant<int, 4>{});
-      else sweep_scheduled(std::integral_constant<int, 8>{});
+      sweep_scheduled();
       sweep++;
     }
     while (!diag && count > 0 && sweep <= sweepmax) {
@@ -534,21 +535,19 @@ extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t,
   const long long resident = 256LL * (shmem ? (160 * 1024) / shmem : 8);
   const unsigned grid = (unsigned)(sp->nframes < resident ? sp->nframes : resident);
   hipError_t e = hipSuccess;
+#define GLFER_HPARMA_LAUNCH(F, L)                                                                                  \
+  do {                                                                                                              \
+    e = glfer::allow_dynamic_lds((const void *)hparma_kernel<F, L>, shmem);                                         \
+    if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<F, L>), dim3(grid), dim3(64), shmem, st, hp);            \
+  } while (0)
+  const bool wide = rot_width == 16;
   switch (sp->fmt) {
-    case GLFER_FMT_F32:
-      e = glfer::allow_dynamic_lds((const void *)hparma_kernel<GLFER_FMT_F32>, shmem);
-      if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<GLFER_FMT_F32>), dim3(grid), dim3(64), shmem, st, hp);
-      break;
-    case GLFER_FMT_S16:
-      e = glfer::allow_dynamic_lds((const void *)hparma_kernel<GLFER_FMT_S16>, shmem);
-      if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<GLFER_FMT_S16>), dim3(grid), dim3(64), shmem, st, hp);
-      break;
-    case GLFER_FMT_U8:
-      e = glfer::allow_dynamic_lds((const void *)hparma_kernel<GLFER_FMT_U8>, shmem);
-      if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<GLFER_FMT_U8>), dim3(grid), dim3(64), shmem, st, hp);
-      break;
+    case GLFER_FMT_F32: if (wide) GLFER_HPARMA_LAUNCH(GLFER_FMT_F32, 4); else GLFER_HPARMA_LAUNCH(GLFER_FMT_F32, 8); break;
+    case GLFER_FMT_S16: if (wide) GLFER_HPARMA_LAUNCH(GLFER_FMT_S16, 4); else GLFER_HPARMA_LAUNCH(GLFER_FMT_S16, 8); break;
+    case GLFER_FMT_U8: if (wide) GLFER_HPARMA_LAUNCH(GLFER_FMT_U8, 4); else GLFER_HPARMA_LAUNCH(GLFER_FMT_U8, 8); break;
     default: return hipErrorInvalidValue;
   }
+#undef GLFER_HPARMA_LAUNCH
   if (e != hipSuccess) return e;
   return hipGetLastError();
 }
