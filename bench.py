@@ -42,7 +42,7 @@ WORKLOADS = {
     # SURVEY 8(d)'s secondary row: BASELINE.json does not give C3's overlap; the reference's default (0) is the headline, C2's 75 % this one
     "mtm75": ("C3 at C2's overlap: multitaper N=4096 NW=2.5 mtm_k=4 (5 tapers), overlap 75%, 48 kHz mono f32", 4096, 0.75, 2.5, 4, 262144, 16384),
     "mtm16k": ("C4: multitaper N=16384 NW=4.5 mtm_k=8 (9 tapers), overlap 0, 48 kHz mono f32", 16384, 0.0, 4.5, 8, 65536, 1024),
-    "hparma": ("C5: HP-ARMA t=128 p_e=32 N=4096, overlap 0, 48 kHz mono f32 (compute/latency bound, not HBM)", 4096, 0.0, 0.0, 0, 16384, 4096),
+    "hparma": ("C5: HP-ARMA t=128 p_e=32 N=4096, overlap 0, 48 kHz mono f32 (compute/latency bound, not HBM)", 4096, 0.0, 0.0, 0, 65536, 4096),
 }
 METRICS = {"fft1k": "spectrogram frames/sec + achieved HBM GB/s, N=1024 periodogram",
            "mtm": "spectrogram frames/sec + achieved HBM GB/s, N=4096 MTM K=4",
@@ -348,14 +348,23 @@ def hparma_view(res):
     tested, rotated = 8 * (ncol * (ncol - 1) // 2), 2567
     flops = 2.0 * t_ * n + tested * (3 * 2 * t_) + rotated * (6 * t_ + 6 * ncol) + (n / 2 + 1) * ncol * 8
     tf = frames * flops / (kernel_ms * 1e-3) / 1e12
-    return {"model": "counted FP64 flops of hparma_do on this stream, lower bound (8 sweeps of 528 tested pairs, 2 567 rotations: tools/hparma_sweep_count.py)",
+    view = {"model": "counted FP64 flops of hparma_do on this stream, lower bound (8 sweeps of 528 tested pairs, 2 567 rotations: tools/hparma_sweep_count.py)",
             "flops_per_frame_f64": flops,
             "achieved_TFLOPs": tf, "peak_TFLOPs": 78.6, "frac": tf / 78.6,
-            "note": "bound by the double-precision vector instructions of the Jacobi rotations (4 clocks each) and, at seven wavefronts per CU "
-                    "(22 KB of LDS per frame), by the chain of ~60 dependent ones in a step's angle.  Round 4: column-disjoint rotations run side by "
-                    "side -- the sweep as a static schedule of eight rotations per step over 8-lane octets, 80 steps instead of 528 rotations; the "
-                    "reference's order among rotations that share a column, every rotation's arithmetic and the per-sweep count unchanged "
-                    "(0.526 -> 1.16 M frames/s, profiles/r04_hparma_schedule.txt)"}
+            "note": "bound by the ISSUE of double-precision vector instructions (4 clocks each on a SIMD): multiplies and adds the reference rounds "
+                    "one by one (no fma in a rotation), float <-> double conversions and an angle per step are instructions, not counted flops.  "
+                    "Round 4: column-disjoint rotations side by side (a static schedule of eight per step over 8-lane octets, 80 steps instead of 528 "
+                    "rotations), the shape as compile-time constants (straight-line steps), the autocorrelation two lags a lane and four terms "
+                    "a round: 0.526 -> 1.72 M frames/s (profiles/r04_hparma_schedule.txt)"}
+    pmc, src = pmc_summary("hparma_issue.json")
+    if pmc:
+        per_frame = pmc["SQ_INSTS_VALU_per_frame"]
+        fps = frames / (kernel_ms * 1e-3)
+        view["issue"] = {"valu_wave_instr_per_frame_measured": per_frame, "clocks_per_instr": 4,
+                         "simd_clocks_per_s": 1024 * 2.4e9, "frac": per_frame * 4 * fps / (1024 * 2.4e9),
+                         "is": "share of the chip's SIMD clocks (1024 SIMDs x 2.4 GHz nominal) this launch spent issuing vector instructions at 4 clocks each",
+                         "source": "SQ_INSTS_VALU, rocprofv3 PMC (" + src + "), not this run"}
+    return view
 
 
 def parity_vs_oracle(torch, G, workload, local, frames=64):

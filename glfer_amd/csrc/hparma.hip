@@ -15,10 +15,13 @@
 // Compiled with -ffp-contract=off: a*c + b*s must round as the reference's two multiplies + add.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "spectro_params.h"
 
 namespace glfer {
 hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);   // plan.h / glfer_hip.cpp: once per device, kernel and size class
+hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st);   // (stream-ordered scratch of the library)
+void scratch_free(void *q, hipStream_t st);
 }
 
 namespace glfer {
@@ -176,6 +179,7 @@ struct HparmaParams {
   int width;                // rotations per step the schedule was built for: 8 (a rotation over 8 lanes) or 16 (over 4)
   const uint16_t *lagmap;   // [t][ncol]: which autocorrelation lag each matrix cell ends up holding
   const float2 *unit;       // [N/2+1]: exp(-2 pi i k / N)
+  unsigned *queue;          // frames handed out beyond the first gridDim.x (null: blockIdx.x, + gridDim.x, ...)
 };
 
 template <int FMT>
@@ -187,18 +191,28 @@ __device__ __forceinline__ float hp_sample(__amdgpu_buffer_rsrc_t rsrc, unsigned
 
 // LPR: lanes a scheduled rotation is laid over (8: eight rotations per step, the product; 4: sixteen -- a kernel of its own, so that
 // its registers do not cost the other form its occupancy)
-template <int FMT, int LPR = 8>
+// TT, NC: the matrix shape as compile-time constants (BASELINE config 5: t = 128, p_e + 1 = 33), 0 = taken from the parameters.  With the
+// shape known the step is straight-line code: no row tests around the loads and stores of a column, column offsets by shifts instead
+// of v_mul_lo_u32, Q's five row slots instead of eight tested ones.
+template <int FMT, int LPR = 8, int TT = 0, int NC = 0>
 __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SpectroParams &p = hp.s;
-  const int N = hp.n, t = hp.t, ncol = hp.ncol;
+  const int N = hp.n, t = TT ? TT : hp.t, ncol = NC ? NC : hp.ncol;
   const int lane = threadIdx.x;
+  typedef float v4f32 __attribute__((ext_vector_type(4)));
   constexpr unsigned esz = FMT == GLFER_FMT_F32 ? 4 : (FMT == GLFER_FMT_S16 ? 2 : 1);
-  // LDS: [x (N floats) overlaid later by A (t*ncol floats)] [Q ncol*ncol] [r t] [S ncol] [a ncol]
-  const int big = N > t * ncol ? N : t * ncol;
+  // LDS: [x (N floats + a zero tail of 128 when t <= 128) overlaid later by A (t*ncol floats)] [Q ncol*ncol] [r t] [S ncol] [a ncol]
+  const int xlen = N + (t <= 128 ? 128 : 0);
+  const int big = xlen > t * ncol ? xlen : t * ncol;
   float *x = smem, *A = smem, *Q = smem + big, *rl = Q + ncol * ncol, *S = rl + t, *ar = S + ncol;
 
-  for (long long f = blockIdx.x; f < p.nframes; f += gridDim.x) {
+  // Frames are handed out from a queue when a launch has more of them than wavefronts in flight (hp.queue, zeroed by the launcher):
+  // seven one-wavefront workgroups share a CU's four SIMDs 2 + 2 + 2 + 1 (tools/ldsocc), the one alone on its SIMD is half as
+  // fast again as the others, and with a fixed stride it sat idle for the last third of the launch.
+  for (long long f = blockIdx.x; f < p.nframes;
+       f = hp.queue ? (long long)gridDim.x + (long long)__builtin_amdgcn_readfirstlane(lane == 0 ? (int)atomicAdd(hp.queue, 1u) : 0)
+                    : f + gridDim.x) {
     // ---- K1: the assembled frame (prepare_audio, fft.c:98-113), unwindowed (source.c:369)
     {
       const long long s0 = (p.frame0 + f) * (long long)p.H - p.R;
@@ -206,20 +220,76 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
       const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sbase * (long long)esz, 0, 0x7fffffff, 0x00020000);
       const int rel0 = (int)(s0 - sbase);
-      for (int j = lane; j < N; j += 64) {
-        const int rel = rel0 + j;
-        const bool ok = p.history_mode ? (j >= p.R) : (rel >= 0);
-        const float v = hp_sample<FMT>(xrsrc, ok ? (unsigned)rel * esz : 0x80000000u);
-        x[j] = ok ? v : 0.0f;
+      // sixteen loads in flight per lane and one wait for them (one load and its wait per iteration, as this loop used to be
+      // compiled, is 64 trips to memory a frame -- with two wavefronts on a SIMD at best, nobody covers them)
+      constexpr int UN = 16;
+      for (int j0 = lane; j0 < N; j0 += 64 * UN) {
+        float v[UN];
+        bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+          const int j = j0 + 64 * u, rel = rel0 + j;
+          ok[u] = j < N && (p.history_mode ? (j >= p.R) : (rel >= 0));
+          v[u] = hp_sample<FMT>(xrsrc, ok[u] ? (unsigned)rel * esz : 0x80000000u);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+          const int j = j0 + 64 * u;
+          if (j < N) x[j] = ok[u] ? v[u] : 0.0f;
+        }
+      }
+      if (t <= 128) {
+        x[N + lane] = 0.0f;
+        x[N + 64 + lane] = 0.0f;
       }
     }
     wave_fence();
     // ---- autocorrelation (hparma.c:89-95): float products summed in double, k ascending
-    for (int i = lane; i < t; i += 64) {
-      double s = 0.0;
-      const int len = N - i;
-      for (int k = 0; k < len; k++) s += (double)(x[k + i] * x[k]);
-      rl[i] = (float)(s / (double)len);
+    if (t <= 128) {
+      // Lags `lane` and `lane + 64` side by side, four k at a time: x[k .. k+3] is one broadcast ds_read_b128 for both, the lane's own
+      // operands x[k + i ..] two 4-byte-aligned ds_read2_b32 a lag, everything requested one round ahead.  Every lane walks all N
+      // values of k: past its own N - i the frame's zero tail gives products of (+-)0, and s + (+-)0 is s bit for bit (s starts at
+      // +0 and can never become -0), so the sum is hparma.c:91-93's.  The one-term-at-a-time loop this replaces was a quarter of the
+      // kernel's issued instructions (14 a term, each iteration waiting for its own two LDS reads).
+      const float *xa = x + lane, *xb = x + lane + 64;
+      double s0 = 0.0, s1 = 0.0;
+      v4f32 xk = *reinterpret_cast<const v4f32 *>(x);
+      float a[4], b[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        a[c] = xa[c];
+        b[c] = xb[c];
+      }
+      for (int k = 0; k < N; k += 4) {
+        const int kn = k + 4 < N ? k + 4 : k;             // (the last round asks for its own values again)
+        const v4f32 xkn = *reinterpret_cast<const v4f32 *>(x + kn);
+        float an[4], bn[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          an[c] = xa[kn + c];
+          bn[c] = xb[kn + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          s0 += (double)(a[c] * xk[c]);
+          s1 += (double)(b[c] * xk[c]);
+        }
+        xk = xkn;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          a[c] = an[c];
+          b[c] = bn[c];
+        }
+      }
+      if (lane < t) rl[lane] = (float)(s0 / (double)(N - lane));
+      if (lane + 64 < t) rl[lane + 64] = (float)(s1 / (double)(N - lane - 64));
+    } else {
+      for (int i = lane; i < t; i += 64) {
+        double s = 0.0;
+        const int len = N - i;
+        for (int k = 0; k < len; k++) s += (double)(x[k + i] * x[k]);
+        rl[i] = (float)(s / (double)len);
+      }
     }
     wave_fence();
     // ---- the t x ncol matrix, column-major A[j*t + i]; cell (i,j) holds lag lagmap[i][j]
@@ -254,12 +324,17 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
     // rotations.  Every rotation's own arithmetic is what it was; the sums associate differently (sixteen rows in a lane,
     // then the butterfly), as they already differed from the reference's row-by-row order.  t a multiple of 4, <= 128.
     const bool diag = hp.sched != nullptr && hp.nsteps > 0 && hp.width == 64 / LPR && t <= 128 && ncol <= 64 && (t & 3) == 0 && ncol >= 2;
-    typedef float v4f32 __attribute__((ext_vector_type(4)));
     // one sweep of the schedule with a rotation over LPR lanes (64 / LPR rotations per step; hp.width = 64 / LPR is the width the host
     // scheduled for): a lane holds 128 / LPR rows of the two columns in chunks of four (rows (4 LPR) c + 4 l .. + 3) and rows l, l + LPR ... of Q
     auto sweep_scheduled = [&] {
       constexpr int NG = 64 / LPR, NCH = 32 / LPR, NQ = 64 / LPR;
       const int grp = lane / LPR, ll = lane % LPR;
+      // Columns start 4 t bytes apart -- a multiple of the 256 bytes the 64 banks span for t = 64, 128 -- so the same chunk of two
+      // columns lies on the same banks, and the two groups a ds_read_b128 serves together collided on every access (rocprofv3: 38 %
+      // of the LDS array's active cycles were bank conflicts).  Odd groups therefore take their chunks in the order 1, 0, 3, 2: the
+      // neighbours' 128 bytes fall on different halves of the banks.  (A lane's sixteen rows are the same; the order it adds
+      // them in depends on its group's parity.)
+      const int swz = LPR == 8 ? (grp & 1) : 0;
       int skipped = 0;
       int e = hp.sched[grp];
       for (int s0 = 0; s0 < hp.nsteps; s0++) {
@@ -271,7 +346,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
         v4f32 aj[NCH], ak[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-          const int r = 4 * LPR * c + 4 * ll;
+          const int r = 4 * LPR * (c ^ swz) + 4 * ll;
           aj[c] = r < t ? *reinterpret_cast<const v4f32 *>(Aj + r) : z4;
           ak[c] = r < t ? *reinterpret_cast<const v4f32 *>(Ak + r) : z4;
         }
@@ -320,7 +395,7 @@ __global__ __launch_bounds__(64) void hparma_kernel(HparmaParams hp) {
           };
 #pragma unroll
           for (int c = 0; c < NCH; c++) {
-            const int r = 4 * LPR * c + 4 * ll;
+            const int r = 4 * LPR * (c ^ swz) + 4 * ll;
             if (r < t) {
               float nj[4], nk[4];
 #pragma unroll
@@ -530,23 +605,44 @@ extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t,
   hp.width = rot_width;
   hp.lagmap = lagmap;
   hp.unit = unit;
-  const int big = n > t * ncol ? n : t * ncol;
-  const size_t shmem = (size_t)(big + ncol * ncol + t + 2 * ncol) * sizeof(float);
+  const int xlen = n + (t <= 128 ? 128 : 0);            // the frame and its zero tail (the autocorrelation's two-lag walk)
+  const int big = xlen > t * ncol ? xlen : t * ncol;
+  size_t shmem = (size_t)(big + ncol * ncol + t + 2 * ncol) * sizeof(float);
+  // GLFER_HPARMA_LDS_KB (tools/hparma_occupancy.sh only): ask for more LDS than the frame needs, i.e. fewer frames in flight per CU
+  static const long lds_kb = [] { const char *e = getenv("GLFER_HPARMA_LDS_KB"); return e ? atol(e) : 0L; }();
+  if (lds_kb > 0 && (size_t)lds_kb * 1024 > shmem && lds_kb <= 64) shmem = (size_t)lds_kb * 1024;
   const long long resident = 256LL * (shmem ? (160 * 1024) / shmem : 8);
   const unsigned grid = (unsigned)(sp->nframes < resident ? sp->nframes : resident);
   hipError_t e = hipSuccess;
-#define GLFER_HPARMA_LAUNCH(F, L)                                                                                  \
-  do {                                                                                                              \
-    e = glfer::allow_dynamic_lds((const void *)hparma_kernel<F, L>, shmem);                                         \
-    if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<F, L>), dim3(grid), dim3(64), shmem, st, hp);            \
+  hp.queue = nullptr;
+  if ((long long)sp->nframes > (long long)grid) {
+    e = glfer::scratch_malloc((void **)&hp.queue, 256, st);
+    if (e == hipSuccess) e = hipMemsetAsync(hp.queue, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return e;
+  }
+#define GLFER_HPARMA_LAUNCH(F, L, TT, NC)                                                                                  \
+  do {                                                                                                                      \
+    e = glfer::allow_dynamic_lds((const void *)hparma_kernel<F, L, TT, NC>, shmem);                                         \
+    if (e == hipSuccess) hipLaunchKernelGGL((hparma_kernel<F, L, TT, NC>), dim3(grid), dim3(64), shmem, st, hp);            \
   } while (0)
   const bool wide = rot_width == 16;
+  // GLFER_HPARMA_GENERIC=1 (A/B runs and the tests): the shape from the parameters even for t = 128, p_e = 32
+  const bool generic_only = [] { const char *e = getenv("GLFER_HPARMA_GENERIC"); return e && atoi(e) != 0; }();
+  const bool c5 = !wide && !generic_only && t == 128 && ncol == 33 && rot_sched != nullptr && rot_steps > 0;
   switch (sp->fmt) {
-    case GLFER_FMT_F32: if (wide) GLFER_HPARMA_LAUNCH(GLFER_FMT_F32, 4); else GLFER_HPARMA_LAUNCH(GLFER_FMT_F32, 8); break;
-    case GLFER_FMT_S16: if (wide) GLFER_HPARMA_LAUNCH(GLFER_FMT_S16, 4); else GLFER_HPARMA_LAUNCH(GLFER_FMT_S16, 8); break;
-    case GLFER_FMT_U8: if (wide) GLFER_HPARMA_LAUNCH(GLFER_FMT_U8, 4); else GLFER_HPARMA_LAUNCH(GLFER_FMT_U8, 8); break;
-    default: return hipErrorInvalidValue;
+#define GLFER_HPARMA_FMT(F)                                    \
+    case F:                                                    \
+      if (wide) GLFER_HPARMA_LAUNCH(F, 4, 0, 0);               \
+      else if (c5) GLFER_HPARMA_LAUNCH(F, 8, 128, 33);         \
+      else GLFER_HPARMA_LAUNCH(F, 8, 0, 0);                    \
+      break;
+    GLFER_HPARMA_FMT(GLFER_FMT_F32)
+    GLFER_HPARMA_FMT(GLFER_FMT_S16)
+    GLFER_HPARMA_FMT(GLFER_FMT_U8)
+#undef GLFER_HPARMA_FMT
+    default: e = hipErrorInvalidValue;
   }
+  if (hp.queue) glfer::scratch_free(hp.queue, st);
 #undef GLFER_HPARMA_LAUNCH
   if (e != hipSuccess) return e;
   return hipGetLastError();

@@ -470,3 +470,26 @@ def test_hparma_schedule_over_matrix_shapes(lib, oracle, torch_cuda, n, t, p_e):
         assert np.array_equal(np.isfinite(got[f]), np.isfinite(want)), (n, t, p_e, f)
         e = max(rel_err(1.0 / got[f, :n // 2], 1.0 / want[:n // 2]))
         assert e < 1e-4, (n, t, p_e, f, e)
+
+
+@pytest.mark.parametrize("fmt", ["f32", "s16", "u8"])
+def test_hparma_fixed_shape_kernel_equals_the_general_one(lib, torch_cuda, monkeypatch, fmt):
+    """BASELINE config 5's shape (t = 128, p_e = 32) runs a kernel with the shape as compile-time constants (straight-line steps);
+    GLFER_HPARMA_GENERIC=1 sends it through the kernel that takes the shape from its parameters.  Same statements, same order:
+    the rows must be the same bits, for every sample format, over enough frames that every workgroup walks more than one."""
+    n, frames = 4096, 3000
+    x = synth(frames * n, seed=77)
+    if fmt == "s16":
+        dev, sf = torch_cuda.from_numpy(np.clip(np.round(x * 20000.0), -32768, 32767).astype(np.int16)).cuda(), lib.SAMPLES_S16
+    elif fmt == "u8":
+        dev, sf = torch_cuda.from_numpy(np.clip(np.round(x * 100.0 + 128.0), 0, 255).astype(np.uint8)).cuda(), lib.SAMPLES_U8
+    else:
+        dev, sf = torch_cuda.from_numpy(x).cuda(), lib.SAMPLES_F32
+    sp = lib.Spectrogram(lib.HparmaParams(n=n, overlap=0.0, t=128, p_e=32, sample_format=sf))
+    monkeypatch.delenv("GLFER_HPARMA_GENERIC", raising=False)
+    fixed = sp.run(dev).clone()
+    monkeypatch.setenv("GLFER_HPARMA_GENERIC", "1")
+    general = sp.run(dev).clone()
+    assert fixed.shape == (frames, n // 2 + 1)
+    assert torch_cuda.equal(fixed.view(torch_cuda.int32), general.view(torch_cuda.int32))
+
