@@ -355,7 +355,7 @@ def hparma_view(res):
                     "one by one (no fma in a rotation), float <-> double conversions and an angle per step are instructions, not counted flops.  "
                     "Round 4: column-disjoint rotations side by side (a static schedule of eight per step over 8-lane octets, 80 steps instead of 528 "
                     "rotations), the shape as compile-time constants (straight-line steps), the autocorrelation two lags a lane and four terms "
-                    "a round: 0.526 -> 1.72 M frames/s (profiles/r04_hparma_schedule.txt)"}
+                    "a round, frames from a queue: 0.526 -> 2.13 M frames/s (profiles/r04_hparma_schedule.txt)"}
     pmc, src = pmc_summary("hparma_issue.json")
     if pmc:
         per_frame = pmc["SQ_INSTS_VALU_per_frame"]

@@ -5,10 +5,9 @@
 //   with the reference's row-0 overflow reproduced through a host-built lag map, one-sided
 //   Jacobi SVD in the reference's cyclic column order, rank from the cumulative sigma^2, AR
 //   vector from the noise subspace, |A(f)|^2/N on N/2+1 bins and its reciprocal below Nyquist.
-// Compute bound by the vector instructions a rotation issues (~280, most of them double precision at 4 clocks each;
-// 6 336+ rotations per frame), not HBM- and -- measured in round 3 with 12 instead of 7 frames in flight per CU -- not
-// latency-bound either (tools/experiments/hparma_registers_and_mfma_sums.hip.txt): frames are independent, so the launch
-// simply keeps every SIMD busy with its own frames.
+// Compute bound by the vector instructions it issues (most of them double precision at 4 clocks each: 230 k a frame at BASELINE
+// config 5, 0.81 of the SIMD clocks -- profiles/r04_hparma_issue.json), not HBM-bound: frames are independent, seven of them are in
+// flight per CU (22 KB of LDS each) and take their successors from a queue.
 // The matrix lives in LDS column-major (a column pair is two conflict-free strided reads per
 // lane), inner products are double as in the reference, the three sums of a rotation are reduced
 // across the wave with DPP, and every lane repeats the scalar part so all branches are uniform.
