@@ -70,6 +70,9 @@
 // buffer at the offset they have inside their 64-byte granule in memory, one barrier, and a lane
 // reads 16 aligned bytes and stores them; the row's first and last few floats (the parts of a
 // 16-byte chunk it shares with its neighbours) go out as single floats.
+#ifndef GLFER16H_OPAQUE_ROW
+#define GLFER16H_OPAQUE_ROW 1    /* 0: A/B builds, the row offset left to the optimizer (tools/build_variant.sh) */
+#endif
 #ifndef GLFER16H_STAGE_ROWS
 #define GLFER16H_STAGE_ROWS 0   /* measured, C2: 320 -> 264 M frames/s (HBM writes 1.09x -> see profiles/r03_c2_staged_rows.txt): one more barrier, 8 KB more LDS
                                    writes per frame and 24 spilled VGPRs cost more than the aligned stores save; kept for A/B builds */
@@ -616,7 +619,17 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       const long long left = p.nframes - start, span = per * FPB;
       const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
           p.psd + (size_t)start * (size_t)p.pitch, 0, (unsigned)((left > span ? span : left) * (long long)ROWB), 0x00020000);
-      const unsigned row = (unsigned)rel_of(it) * ROWB;
+      // row = the slot's part + the iteration's part.  The iteration's part is kept out of the optimizer's sight (a scalar it must
+      // recompute every frame): left visible, the unrolled register-reuse loops kept `lane part + r * ROWB` of each of their copies in
+      // registers of their own -- six VGPRs spilled in the C2 kernel (three wavefronts per SIMD: 168), and their reloads, counted
+      // by vmcnt like the sample prefetches issued in front of them, made every frame wait for loads that were meant to have two
+      // frames' time.  (The row offset stays in the VECTOR offset: the descriptor's range check, which drops the stores of frame
+      // slots past the last frame, does not cover a scalar offset.)
+      unsigned urow = (unsigned)it * ROWB * (unsigned)(SHIFT > 0 ? 1 : FPB);
+#if GLFER16H_OPAQUE_ROW
+      asm volatile("" : "+s"(urow));
+#endif
+      const unsigned row = (unsigned)rel_of(0) * ROWB + urow;
       const unsigned vup = row + t * 4u, vdown = row + (unsigned)(M - 7 * T - (int)t) * 4u;
       // STAGE: the row's floats into the exchange buffer's free upper part (the mirror step uses entries
       // 0 .. M/2), at the offset s16 they have inside their 64-byte granule in memory
