@@ -490,7 +490,10 @@ static hipError_t launch16_fmt(const SpectroParams &p, hipStream_t st) {
   // persistent blocks: enough to fill every CU at the kernel's occupancy, never more than the work
   const long long work = ((long long)p.nframes + LC::FPB - 1) / LC::FPB;
   if (work == 0) return hipSuccess;
-  const long long resident = 256LL * ((GLFER16_WAVES_PER_SIMD * 256) / LC::BLOCK > 0 ? (GLFER16_WAVES_PER_SIMD * 256) / LC::BLOCK : 1);
+  // the general path (limiter, RA9MB, spectrum output) at two wavefronts per SIMD whatever the size: at three it spills 113-123 VGPRs
+  // (N = 4096) and runs at 30-36 M frames/s against 50 (N = 512: 328 against 425) -- tools/packed_rate.py, round 4
+  const int wps = (p.nonlin || p.spec) && !p.ftest && !p.mean_inkernel ? 2 : GLFER16_WAVES_PER_SIMD;
+  const long long resident = 256LL * ((wps * 256) / LC::BLOCK > 0 ? (wps * 256) / LC::BLOCK : 1);
   unsigned grid = (unsigned)(work < 4 * resident ? work : 4 * resident);
   if (grid >= 64) grid &= ~7u;                     // whole XCD slices: see xcd_block_index()
   if (p.ftest) {
@@ -510,7 +513,7 @@ static hipError_t launch16_fmt(const SpectroParams &p, hipStream_t st) {
     return hipGetLastError();
   }
   if (p.nonlin || p.spec)
-    hipLaunchKernelGGL((spectro16_kernel<L, FMT, true>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    hipLaunchKernelGGL((spectro16_kernel<L, FMT, true, 2>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   else
     hipLaunchKernelGGL((spectro16_kernel<L, FMT, false>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   return hipGetLastError();
