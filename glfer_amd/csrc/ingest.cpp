@@ -60,6 +60,7 @@ void ingest_ring_free(IngestRing *r) {          // with the ring's device curren
   if (!r) return;
   int dev = -1;
   if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !r->busy && ring_bytes(r) <= ((size_t)2 << 30)) {
+    if (r->up) (void)hipStreamSynchronize(r->up);
     for (int i = 0; i < 2; i++)
       if (r->st[i]) (void)hipStreamSynchronize(r->st[i]);
     std::lock_guard<std::mutex> lock(g_spare_mu);
@@ -72,8 +73,13 @@ void ingest_ring_free(IngestRing *r) {          // with the ring's device curren
 }
 static void ingest_ring_destroy(IngestRing *r) {
   if (!r) return;
+  if (r->up) {
+    (void)hipStreamSynchronize(r->up);
+    (void)hipStreamDestroy(r->up);
+  }
   for (int i = 0; i < 2; i++) {
     if (r->st[i]) (void)hipStreamSynchronize(r->st[i]);
+    if (r->ev_up[i]) (void)hipEventDestroy(r->ev_up[i]);
     if (r->h_in[i]) (void)hipHostFree(r->h_in[i]);
     if (r->h_out[i]) (void)hipHostFree(r->h_out[i]);
     if (r->h_lev[i]) (void)hipHostFree(r->h_lev[i]);
@@ -259,7 +265,14 @@ int run_job(const Job &job, size_t *frames_done) {
     e = kind == 0 ? hipHostMalloc(ptr, bytes, hipHostMallocDefault) : hipMalloc(ptr, bytes);
     if (e == hipSuccess) *cap = bytes;
   };
+  // Uploads have a stream of their own.  With chunk c's upload, kernels and download all on stream c % 2 -- rounds 2-3 -- the two
+  // streams ran in step: both uploading, then both downloading, the link used one way at a time (25 + 25 GB/s where this box
+  // does 57 one way and 48 + 48 both ways: tools/pcie_probe.py shows the same for a bare ring of copies).  Queued behind one another
+  // the uploads stagger the chunks by themselves: chunk c + 1 goes up while chunk c's rows come down.
+  if (!R.up) e = hipStreamCreateWithFlags(&R.up, hipStreamNonBlocking);
   for (int b = 0; b < 2 && e == hipSuccess; b++) {
+    if (!R.ev_up[b]) e = hipEventCreateWithFlags(&R.ev_up[b], hipEventDisableTiming);
+    if (e != hipSuccess) break;
     if (!st[b]) e = hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking);
     if (!job.pinned_src) ensure((void **)&h_in[b], &R.cap[b][0], in_bytes, 0);
     ensure((void **)&d_in[b], &R.cap[b][1], in_bytes, 1);
@@ -310,7 +323,9 @@ int run_job(const Job &job, size_t *frames_done) {
     if (job.pinned_src) {
       // the caller's stream is pinned: history, hops and all go up from where they lie
       const size_t up = cf - lo_hop + nf;
-      e = hipMemcpyAsync(d_in[b], job.pinned_src + lo_hop * hop * esz, up * hop * esz, hipMemcpyHostToDevice, st[b]);
+      e = hipMemcpyAsync(d_in[b], job.pinned_src + lo_hop * hop * esz, up * hop * esz, hipMemcpyHostToDevice, R.up);
+      if (e == hipSuccess) e = hipEventRecord(R.ev_up[b], R.up);
+      if (e == hipSuccess) e = hipStreamWaitEvent(st[b], R.ev_up[b], 0);
       if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
     }
     // history: from the previous chunk's pinned buffer where it has it, else from the reader
@@ -335,7 +350,9 @@ int run_job(const Job &job, size_t *frames_done) {
     const bool has_tail = job.tail_fresh >= 0 && cf + nf == frame_hi;
     const size_t up_hops = cf - lo_hop + nf;
     if (!job.pinned_src) {
-      e = hipMemcpyAsync(d_in[b], h_in[b], up_hops * hop * esz, hipMemcpyHostToDevice, st[b]);
+      e = hipMemcpyAsync(d_in[b], h_in[b], up_hops * hop * esz, hipMemcpyHostToDevice, R.up);
+      if (e == hipSuccess) e = hipEventRecord(R.ev_up[b], R.up);
+      if (e == hipSuccess) e = hipStreamWaitEvent(st[b], R.ev_up[b], 0);
       if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
     }
     const unsigned char *vbase = d_in[b] - lo_hop * hop * esz;       // virtual address of stream sample 0
@@ -375,6 +392,7 @@ int run_job(const Job &job, size_t *frames_done) {
   // the two chunks still in flight, oldest first
   if (rc == GLFER_OK) rc = drain(b);
   if (rc == GLFER_OK) rc = drain(b ^ 1);
+  if (R.up) (void)hipStreamSynchronize(R.up);
   for (int i = 0; i < 2; i++)
     if (st[i]) (void)hipStreamSynchronize(st[i]);
   if (own_ring) {

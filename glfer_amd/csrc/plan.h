@@ -64,6 +64,8 @@ struct IngestRing {
   short *h_lev[2] = {nullptr, nullptr}, *d_lev[2] = {nullptr, nullptr};
   float *d_psd[2] = {nullptr, nullptr}, *d_stats[2] = {nullptr, nullptr};
   hipStream_t st[2] = {nullptr, nullptr};
+  hipStream_t up = nullptr;                       // every chunk's upload (round 4): uploads queue behind one another, so that chunk c + 1 goes up while chunk c's rows come down
+  hipEvent_t ev_up[2] = {nullptr, nullptr};       // chunk b's upload done: its stream's kernels wait for it
   size_t cap[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
   bool busy = false;
 };
