@@ -420,7 +420,7 @@ def roofline_of(res, workload, traffic=None, traffic_src=None, kernel_ms_triplet
 
 def end_to_end(torch, G, local, frames=131072, reps=3):
     """SURVEY 8(d)'s separate row: the headline workload host memory to host memory -- a PINNED 16-bit PCM buffer (what a
-    WAV file holds, wav_fmt.c:111-114) in, pinned float rows out, through glfer_hip_spectrogram_host's two-stream ring
+    WAV file holds, wav_fmt.c:111-114) in, pinned float rows out, through glfer_hip_spectrogram_host's chunk ring (uploads on one stream, kernels and downloads on two)
     (source.c:112-171 as a batch).  PCIe-inclusive: never the headline value."""
     import numpy as np
     name, n, overlap, nw, kmax, _, _ = WORKLOADS["mtm"]
@@ -448,7 +448,7 @@ def end_to_end(torch, G, local, frames=131072, reps=3):
     return {"workload": name + ", 16-bit PCM", "path": "pinned host samples -> glfer_hip_spectrogram_host -> pinned host rows",
             "frames": frames, "value": frames / best, "unit": "frames/s", "seconds": best, "first_call_seconds": first,
             "pcie_gbs_both_directions": nbytes / best / 1e9, "bytes_in_per_frame": 2 * sp.hop, "bytes_out_per_frame": 4 * sp.bins,
-            "note": "best of %d calls after the first; PCIe Gen5 x16 is ~63 GB/s each way" % reps}
+            "note": "best of %d calls after the first; pinned copies on this pool's boxes run at 57 GB/s one way and 48 + 48 GB/s both ways (tools/pcie_probe.py, profiles/r04_ingest_pcie_inclusive.txt)" % reps}
 
 
 def c4_as_worded(torch, G, local):

@@ -223,8 +223,8 @@ int glfer_hip_mtm_ftest_device(glfer_hip_plan *plan, const void *d_stream, size_
                                void *hip_stream);
 
 /* Host-buffer entry: h_stream goes to the device in chunks through a two-deep ring (two pinned
- * sample buffers, two device buffers each way, two streams: a chunk's upload runs under the
- * previous chunk's compute and download), the PSD rows come back; blocks until done.
+ * sample buffers, two device buffers each way; uploads on one stream, kernels and downloads on two:
+ * a chunk goes up while the previous chunk's rows come down), the PSD rows come back; blocks until done.
  * h_psd in pinned memory (glfer_hip_host_alloc) receives its rows by DMA directly, and an h_stream
  * in pinned memory is uploaded from where it lies; any other memory goes through pinned staging
  * and a host copy (the slower way by 3-4x: the host copy sets the pace).
