@@ -431,6 +431,12 @@ def end_to_end(torch, G, local, frames=131072, reps=3):
     del x
     import ctypes as C
     rows = G.pinned_empty((frames, sp.bins), np.float32)       # (allocated once: pinning 1 GB takes longer than the whole job)
+    # The engine in its steady state, not the driver's housekeeping: for a few hundred milliseconds after gigabytes of device memory
+    # have gone back to the driver (the earlier rows' tensors, `x` above) copies over the link run at three quarters of their
+    # rate (tools/e2e_bisect2.py: 3.8 against 5.05 M frames/s for ~0.2 s after a 3 GiB hipFree) -- give the memory back now and wait it out.
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    time.sleep(1.0)
     best, first = 1e9, None
     for r in range(reps + 1):
         nf = C.c_size_t(0)

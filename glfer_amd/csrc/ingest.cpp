@@ -96,6 +96,43 @@ static void ingest_ring_destroy(IngestRing *r) {
 
 namespace {
 
+bool numa_bind_on() {
+  static const bool on = [] { const char *e = getenv("GLFER_NUMA_BIND"); return !(e && *e == '0'); }();
+  return on;
+}
+
+// binds the calling thread to the CPUs of `device`'s NUMA node for its lifetime (nothing if the node is unknown, the intersection
+// with the thread's own mask is empty, or GLFER_NUMA_BIND=0), and gives the thread its mask back
+struct NodeBinding {
+  cpu_set_t saved;
+  bool bound = false;
+  explicit NodeBinding(int device) {
+    cpu_set_t want;
+    if (device < 0 || !numa_bind_on() || sched_getaffinity(0, sizeof saved, &saved) != 0) return;
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    unsigned char mask[CPU_SETSIZE / 8];
+    const int node = glfer_hip_numa_node_of_bus_id(bus, nullptr);
+    if (node < 0 || glfer_hip_numa_node_cpus(node, nullptr, mask, sizeof mask) <= 0) return;
+    CPU_ZERO(&want);
+    int n = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+      if ((mask[c >> 3] >> (c & 7) & 1) && CPU_ISSET(c, &saved)) {
+        CPU_SET(c, &want);
+        n++;
+      }
+    bound = n > 0 && sched_setaffinity(0, sizeof want, &want) == 0;
+  }
+  ~NodeBinding() {
+    if (bound) (void)sched_setaffinity(0, sizeof saved, &saved);
+  }
+  NodeBinding(const NodeBinding &) = delete;
+  NodeBinding &operator=(const NodeBinding &) = delete;
+};
+
 std::mutex g_ring_mu;
 
 size_t sample_bytes(int fmt) { return fmt == GLFER_SAMPLES_F32 ? 4 : (fmt == GLFER_SAMPLES_S16 ? 2 : 1); }
@@ -213,6 +250,10 @@ int run_job(const Job &job, size_t *frames_done) {
   size_t chunk = job.chunk_frames;
   if (chunk == 0) {                                            // default: 16384 frames, at most 256 MiB of samples
     chunk = 16384;
+    if (const char *ev = getenv("GLFER_INGEST_CHUNK")) {       // (tools/chunk_probe.py)
+      const long v = atol(ev);
+      if (v > 0) chunk = (size_t)v;
+    }
     const size_t cap = ((size_t)256 << 20) / (hop * esz);
     if (chunk > cap) chunk = cap;
   }
@@ -257,11 +298,13 @@ int run_job(const Job &job, size_t *frames_done) {
   const size_t rows_cap = chunk + 1;
   hipError_t e = hipSuccess;
   // a buffer of at least `bytes`: the one the ring has, or a new one (kind: 0 pinned host, 1 device)
+  std::unique_ptr<NodeBinding> near_gpu;
   auto ensure = [&](void **ptr, size_t *cap, size_t bytes, int kind) {
     if (e != hipSuccess || (*ptr && *cap >= bytes)) return;
     if (*ptr) (void)(kind == 0 ? hipHostFree(*ptr) : hipFree(*ptr));
     *ptr = nullptr;
     *cap = 0;
+    if (kind == 0 && !near_gpu) near_gpu.reset(new NodeBinding(p->cfg.device));   // pinned staging beside the GPU (see glfer_hip_host_alloc)
     e = kind == 0 ? hipHostMalloc(ptr, bytes, hipHostMallocDefault) : hipMalloc(ptr, bytes);
     if (e == hipSuccess) *cap = bytes;
   };
@@ -287,6 +330,7 @@ int run_job(const Job &job, size_t *frames_done) {
       }
     }
   }
+  near_gpu.reset();                                // (the thread's own mask back before any work)
   int rc = (e == hipSuccess) ? GLFER_OK : hip_fail(e, "ingest: allocate");
 
   struct Pending { size_t first = 0, nf = 0; bool live = false; } pend[2];
@@ -482,15 +526,6 @@ int glfer_hip_numa_node_cpus(int node, const char *sysfs_root, unsigned char *ma
   return count;
 }
 
-void *glfer_hip_host_alloc(size_t bytes) {
-  void *p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  return p;
-}
-
 void glfer_hip_host_free(void *p) {
   if (p) (void)hipHostFree(p);
 }
@@ -671,41 +706,15 @@ int check_devices(const int *devices, int nworkers) {
 // /sys/devices/system/node/node<N>/cpulist, intersected with what this process may use (a 1-GPU box hands a job 16 of
 // the host's cores).  Nothing is bound when the node is unknown (-1: a one-node host), the intersection is empty or
 // GLFER_NUMA_BIND=0.
-bool numa_bind_on() {
-  static const bool on = [] { const char *e = getenv("GLFER_NUMA_BIND"); return !(e && *e == '0'); }();
-  return on;
-}
-
 // runs work(r) for r = 0 .. world-1, one host thread each (this thread takes worker 0); the first
 // failure's code and text are what the caller sees.  devices (may be null): worker r's GPU, for the placement above.
 int on_workers(unsigned world, const std::function<int(unsigned)> &work, const int *devices = nullptr) {
   std::vector<int> rcs(world, GLFER_OK);
   std::vector<std::string> msgs(world);
   auto run = [&](unsigned r) {
-    cpu_set_t saved, want;
-    bool bound = false;
-    if (devices && world > 1 && numa_bind_on() && sched_getaffinity(0, sizeof saved, &saved) == 0) {
-      char bus[32] = {0};
-      if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, devices[r]) == hipSuccess) {
-        unsigned char mask[CPU_SETSIZE / 8];
-        const int node = glfer_hip_numa_node_of_bus_id(bus, nullptr);
-        if (node >= 0 && glfer_hip_numa_node_cpus(node, nullptr, mask, sizeof mask) > 0) {
-          CPU_ZERO(&want);
-          int n = 0;
-          for (int c = 0; c < CPU_SETSIZE; c++)
-            if ((mask[c >> 3] >> (c & 7) & 1) && CPU_ISSET(c, &saved)) {
-              CPU_SET(c, &want);
-              n++;
-            }
-          bound = n > 0 && sched_setaffinity(0, sizeof want, &want) == 0;
-        }
-      } else {
-        (void)hipGetLastError();
-      }
-    }
+    NodeBinding here(devices && world > 1 ? devices[r] : -1);     // (worker 0 is the caller's own thread: its mask comes back)
     rcs[r] = work(r);
     if (rcs[r]) msgs[r] = glfer::error_text();
-    if (bound) (void)sched_setaffinity(0, sizeof saved, &saved);          // (worker 0 is the caller's own thread)
   };
   std::vector<std::thread> th;
   for (unsigned r = 1; r < world; r++) {
@@ -877,6 +886,25 @@ bool avg_args_ok(const AvgArgs &av, size_t bins) {
 }  // namespace
 
 extern "C" {
+
+// Pinned host memory for samples and rows.  Allocated with the calling thread on the CPUs of the current device's NUMA node (pinning
+// places the pages where the allocating thread runs; DMA to the other socket's memory crosses the sockets' link), the thread's own
+// mask restored afterwards; GLFER_NUMA_BIND=0 or an unknown node: allocated where the thread is.
+void *glfer_hip_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    dev = -1;
+  }
+  NodeBinding here(dev);
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
 
 int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *devices, int nworkers,
                                        const void *h_stream, size_t nsamples, float *h_psd, size_t *nframes_out) {
