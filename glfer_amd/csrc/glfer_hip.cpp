@@ -354,7 +354,7 @@ static size_t tap_slot(int n, int pair, int i, int which) {
 
 extern "C" {
 
-const char *glfer_hip_version(void) { return "glfer_hip 0.9 (gfx950; 16 points/lane Stockham radix-16 with LDS exchange, inter-pass twiddles folded into the butterflies: packed pairs, real-input and wavefront-private forms, shared odd taper, register reuse across overlapped frames, mean removal in the reference's summation order (cfg.sub_mean = 1) or inside the kernels; N = 8..1048576; periodogram, multitaper + F-test, HP-ARMA with column-disjoint Jacobi rotations side by side, LMP; rows at a caller's pitch; wavefront floor, fused average, display map with the average taken inside it; two-stream ingest ring, WAV files and waterfalls over several GPUs, read-ahead behind the per-hop shim, kept scratch blocks with a cap, workers bound to their GPU's NUMA node)"; }
+const char *glfer_hip_version(void) { return "glfer_hip 0.9 (gfx950; 16 points/lane Stockham radix-16 with LDS exchange, inter-pass twiddles folded into the butterflies: packed pairs, real-input and wavefront-private forms, shared odd taper, register reuse across overlapped frames, mean removal in the reference's summation order (cfg.sub_mean = 1) or inside the kernels; N = 8..1048576; periodogram, multitaper + F-test, HP-ARMA with column-disjoint Jacobi rotations side by side and frames from a queue, LMP; rows at a caller's pitch; wavefront floor, fused average, display map with the average taken inside it; chunk ring for ingest with uploads and downloads at once, WAV files and waterfalls over several GPUs, read-ahead behind the per-hop shim, kept scratch blocks with a cap, workers bound to their GPU's NUMA node)"; }
 
 int glfer_hip_palette(int palette, unsigned char colortab[768]) {
   if (!colortab) return GLFER_E_ARG;
