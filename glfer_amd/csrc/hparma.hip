@@ -627,12 +627,15 @@ extern "C" hipError_t glfer_launch_hparma(const SpectroParams *sp, int n, int t,
   const bool wide = rot_width == 16;
   // GLFER_HPARMA_GENERIC=1 (A/B runs and the tests): the shape from the parameters even for t = 128, p_e = 32
   const bool generic_only = [] { const char *e = getenv("GLFER_HPARMA_GENERIC"); return e && atoi(e) != 0; }();
-  const bool c5 = !wide && !generic_only && t == 128 && ncol == 33 && rot_sched != nullptr && rot_steps > 0;
+  const bool fixed = !wide && !generic_only && rot_sched != nullptr && rot_steps > 0;
+  const bool c5 = fixed && t == 128 && ncol == 33;                 // BASELINE config 5
+  const bool dflt = fixed && t == 96 && ncol == 17;                // glfer's own defaults (glfer.c:248-249: t = 96, p_e = 16)
   switch (sp->fmt) {
 #define GLFER_HPARMA_FMT(F)                                    \
     case F:                                                    \
       if (wide) GLFER_HPARMA_LAUNCH(F, 4, 0, 0);               \
       else if (c5) GLFER_HPARMA_LAUNCH(F, 8, 128, 33);         \
+      else if (dflt) GLFER_HPARMA_LAUNCH(F, 8, 96, 17);        \
       else GLFER_HPARMA_LAUNCH(F, 8, 0, 0);                    \
       break;
     GLFER_HPARMA_FMT(GLFER_FMT_F32)

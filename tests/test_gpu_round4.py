@@ -472,9 +472,11 @@ def test_hparma_schedule_over_matrix_shapes(lib, oracle, torch_cuda, n, t, p_e):
         assert e < 1e-4, (n, t, p_e, f, e)
 
 
+@pytest.mark.parametrize("shape", [(128, 32), (96, 16)])
 @pytest.mark.parametrize("fmt", ["f32", "s16", "u8"])
-def test_hparma_fixed_shape_kernel_equals_the_general_one(lib, torch_cuda, monkeypatch, fmt):
-    """BASELINE config 5's shape (t = 128, p_e = 32) runs a kernel with the shape as compile-time constants (straight-line steps);
+def test_hparma_fixed_shape_kernel_equals_the_general_one(lib, torch_cuda, monkeypatch, fmt, shape):
+    """BASELINE config 5's shape (t = 128, p_e = 32) and glfer's defaults (t = 96, p_e = 16, glfer.c:248-249) run a kernel with the shape as
+    compile-time constants (straight-line steps);
     GLFER_HPARMA_GENERIC=1 sends it through the kernel that takes the shape from its parameters.  Same statements, same order:
     the rows must be the same bits, for every sample format, over enough frames that every workgroup walks more than one."""
     n, frames = 4096, 3000
@@ -485,7 +487,7 @@ def test_hparma_fixed_shape_kernel_equals_the_general_one(lib, torch_cuda, monke
         dev, sf = torch_cuda.from_numpy(np.clip(np.round(x * 100.0 + 128.0), 0, 255).astype(np.uint8)).cuda(), lib.SAMPLES_U8
     else:
         dev, sf = torch_cuda.from_numpy(x).cuda(), lib.SAMPLES_F32
-    sp = lib.Spectrogram(lib.HparmaParams(n=n, overlap=0.0, t=128, p_e=32, sample_format=sf))
+    sp = lib.Spectrogram(lib.HparmaParams(n=n, overlap=0.0, t=shape[0], p_e=shape[1], sample_format=sf))
     monkeypatch.delenv("GLFER_HPARMA_GENERIC", raising=False)
     fixed = sp.run(dev).clone()
     monkeypatch.setenv("GLFER_HPARMA_GENERIC", "1")
