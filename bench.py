@@ -431,14 +431,15 @@ def end_to_end(torch, G, local, frames=131072, reps=3):
     del x
     import ctypes as C
     rows = G.pinned_empty((frames, sp.bins), np.float32)       # (allocated once: pinning 1 GB takes longer than the whole job)
-    # The engine in its steady state, not the driver's housekeeping: for a few hundred milliseconds after gigabytes of device memory
-    # have gone back to the driver (the earlier rows' tensors, `x` above) copies over the link run at three quarters of their
-    # rate (tools/e2e_bisect2.py: 3.8 against 5.05 M frames/s for ~0.2 s after a 3 GiB hipFree) -- give the memory back now and wait it out.
+    # The engine in its steady state, not the driver's housekeeping: for a while after gigabytes of device memory have gone back
+    # to the driver (the earlier rows' tensors, `x` above) copies over the link run at three quarters of their rate (tools/e2e_bisect2.py:
+    # 3.8 against 5.0 M frames/s for ~0.5 s after a 12 GiB hipFree; tools/e2e_alone.py: up to ~2 s at this point of the full run).  The
+    # call is therefore repeated for three seconds, a quarter of a second apart, and the best one is the row; every call's rate is kept.
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
-    time.sleep(1.0)
-    best, first = 1e9, None
-    for r in range(reps + 1):
+    best, first, rates = 1e9, None, []
+    t_begin = time.perf_counter()
+    while True:
         nf = C.c_size_t(0)
         t0 = time.perf_counter()
         rc = G.api.lib().glfer_hip_spectrogram_host(sp._h, pcm.ctypes.data, pcm.size, rows.ctypes.data, C.byref(nf))
@@ -448,13 +449,18 @@ def end_to_end(torch, G, local, frames=131072, reps=3):
             first = dt                                  # (the first call makes the plan's ring: pinned and device buffers)
         else:
             best = min(best, dt)
+            rates.append(round(frames / dt / 1e6, 2))
+        if len(rates) >= reps and (time.perf_counter() - t_begin >= 3.0 or len(rates) >= 40):
+            break
+        time.sleep(0.25)
     del rows
     nbytes = frames * (2 * sp.hop + 4 * sp.bins)
     sp.close()
     return {"workload": name + ", 16-bit PCM", "path": "pinned host samples -> glfer_hip_spectrogram_host -> pinned host rows",
             "frames": frames, "value": frames / best, "unit": "frames/s", "seconds": best, "first_call_seconds": first,
             "pcie_gbs_both_directions": nbytes / best / 1e9, "bytes_in_per_frame": 2 * sp.hop, "bytes_out_per_frame": 4 * sp.bins,
-            "note": "best of %d calls after the first; pinned copies on this pool's boxes run at 57 GB/s one way and 48 + 48 GB/s both ways (tools/pcie_probe.py, profiles/r04_ingest_pcie_inclusive.txt)" % reps}
+            "calls_M_frames_per_s": rates,
+            "note": "best of %d calls after the first, spread over three seconds; pinned copies on this pool's boxes run at 57 GB/s one way and 48 + 48 GB/s both ways (tools/pcie_probe.py, profiles/r04_ingest_pcie_inclusive.txt)" % len(rates)}
 
 
 def c4_as_worded(torch, G, local):

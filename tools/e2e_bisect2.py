@@ -35,3 +35,16 @@ for i in range(12):
     r = once()
     print("   t = %.2f s  %.2f M frames/s" % (time.perf_counter() - t0, r))
     time.sleep(0.15)
+
+print("---- 12 GiB freed at once, then the host path for five seconds")
+ts = [torch.empty(3 << 30, dtype=torch.uint8, device="cuda") for _ in range(4)]
+for t in ts:
+    t.zero_()
+torch.cuda.synchronize()
+del ts, t
+t0 = time.perf_counter()
+torch.cuda.empty_cache()
+while time.perf_counter() - t0 < 5.0:
+    r = once()
+    print("   t = %.2f s  %.2f M frames/s" % (time.perf_counter() - t0, r))
+    time.sleep(0.25)
