@@ -17,6 +17,7 @@
 #endif
 
 namespace glfer {
+hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);   // plan.h / glfer_hip.cpp
 
 // a / d for many a and one d, correctly rounded: with y = RN(1/d) (one true division), q0 = RN(a y),
 // r = a - d q0 (exact in an fma), RN(q0 + r y) = RN(a/d) (Markstein) -- the divisors here are the
@@ -160,6 +161,55 @@ __global__ __launch_bounds__(256) void lmp_ring_kernel(const float *__restrict__
   }
 }
 
+// The same for ANY ring size up to 64 (round 4; lmp_av is a free entry of glfer's options dialog): the thread's ring in LDS
+// ([slot][thread]: a column of its own, no barrier), the slot of a frame taken as frame mod nl at run time, the sums over the slots in
+// slot order by loops.  One row read per frame (plus nl - 1 per group of G) where lmp_kernel<0> reads 2 nl: lmp_av = 16 at N = 4096
+// ran at 16.5 M frames/s, a tenth of the rate of the periodograms under it.
+__global__ __launch_bounds__(256) void lmp_ring_any_kernel(const float *__restrict__ rows, long long row0, long long first, long long nframes,
+                                                           int bins, int nl, int G, double c_neg, double c_den, double recip_nl,
+                                                           double recip_nl1, float *__restrict__ out) {
+  extern __shared__ float ring[];                                  // [nl][256]
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const long long f0 = first + (long long)blockIdx.y * G;
+  const long long last = first + nframes, end = f0 + G < last ? f0 + G : last;
+  if (f0 >= last) return;
+  const bool live = i < bins;
+  float *w = ring + threadIdx.x;
+  const float *col = rows + (live ? (size_t)i : 0);
+  // what the ring holds when frame f0 arrives: frames f0 - nl + 1 .. f0 - 1 in their slots (zero before the stream), f0's own slot still to come
+  for (int d = 1; d < nl; d++) {
+    const long long f = f0 - d;
+    const int slot = (int)(((f % nl) + nl) % nl);
+    w[slot * 256] = (f >= 0 && live) ? col[(size_t)(f - row0) * bins] : 0.0f;
+  }
+  const SmallDivisor by_nl((double)nl, recip_nl), by_nl1((double)(nl - 1), recip_nl1);
+  int slot = (int)(f0 % nl);
+  for (long long f = f0; f < end; f++) {
+    w[slot * 256] = live ? col[(size_t)(f - row0) * bins] : 0.0f;
+    slot = slot + 1 == nl ? 0 : slot + 1;
+    if (!live) continue;
+    float *o = out + (size_t)(f - first) * bins;
+    if (i == 0) {                                                  // lmp.c:160
+      o[0] = 1e-3;
+      continue;
+    }
+    double my = 0.0, sy = 0.0;
+    for (int j = 0; j < nl; j++) my += w[j * 256];                 // lmp.c:134-140
+    my = by_nl(my);
+    for (int j = 0; j < nl; j++) {                                 // lmp.c:143-149
+      const double t = w[j * 256] - my;
+      sy += t * t;
+    }
+    sy = by_nl1(sy);
+    double v_hat = my * my - sy;                                   // lmp.c:153-159
+    if (v_hat < 0.0) v_hat = 0.0;
+    v_hat = 0.5 * (my - sqrt(v_hat));
+    float q = c_neg + (nl * my) / (c_den * v_hat);
+    if (q <= 1.0e-3) q = 1e-3;
+    o[i] = q;
+  }
+}
+
 // One thread per (frame, bin).  spec: [ntap + 1][nframes][n] halfcomplex spectra (fft_radix2.c
 // layout) of the frame under taper j, the last one under hn (mu); mu_live = 0: mu is all zeros (the
 // reference build without FFTW never writes it, mtm.c:173).
@@ -268,6 +318,16 @@ extern "C" hipError_t glfer_launch_lmp(const float *rows, long long row0, long l
     }
     nframes = head;                                               // what is left for the frame-by-frame kernel
     if (nframes == 0) return hipSuccess;
+  }
+  if (nl > 1 && nl <= 64 && nframes >= 64 && GLFER_LMP_RING) {     // any other ring size: the ring in LDS (lmp_ring_any_kernel)
+    size_t G = 64;
+    while ((nframes + G - 1) / G > 65535) G *= 2;
+    const size_t lds = (size_t)nl * 256 * sizeof(float);
+    hipError_t e = glfer::allow_dynamic_lds((const void *)lmp_ring_any_kernel, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lmp_ring_any_kernel, dim3((unsigned)((bins + 255) / 256), (unsigned)((nframes + G - 1) / G)), dim3(256), lds, st, rows, row0,
+                       first, (long long)nframes, bins, nl, (int)G, c_neg, c_den, recip_nl, recip_nl1, out);
+    return hipGetLastError();
   }
   // blockIdx.y carries the frame: at most 65535 per launch
   for (size_t done = 0; done < nframes; done += 65535) {

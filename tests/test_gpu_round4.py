@@ -495,3 +495,37 @@ def test_hparma_fixed_shape_kernel_equals_the_general_one(lib, torch_cuda, monke
     assert fixed.shape == (frames, n // 2 + 1)
     assert torch_cuda.equal(fixed.view(torch_cuda.int32), general.view(torch_cuda.int32))
 
+
+
+@pytest.mark.parametrize("n,ovl,nl", [(1024, 0.5, 5), (512, 0.0, 7), (2048, 0.75, 16), (256, 0.0, 33), (1024, 0.0, 64), (4096, 0.0, 10)])
+def test_lmp_ring_of_any_size(lib, torch_cuda, n, ovl, nl):
+    """lmp_av other than 2, 3, 4, 8 (a free entry of glfer's options): launches of >= 64 frames keep a thread's ring in LDS and read a
+    row once (lmp_ring_any_kernel); shorter ones go frame by frame (lmp_kernel<0>, 2 nl row reads each).  Same sums in the same slot
+    order: a long launch must equal the short launches that tile it bit for bit, wherever they start in the stream -- and the
+    reference's formula evaluated in numpy on the device's own periodograms."""
+    hop = int(n * (1.0 - ovl))
+    frames = 300
+    x = synth(frames * hop, fs=8000.0, seed=n + nl)
+    dx = torch_cuda.from_numpy(x).cuda()
+    sp = lib.Spectrogram(lib.LmpParams(n=n, overlap=ovl, avg=nl))
+    full = sp.run(dx)
+    assert full.shape == (frames, n // 2 + 1)
+    for first, count in ((0, 40), (40, 63), (103, 50), (153, 17), (170, 63), (233, 63), (296, 4)):
+        piece = sp.run(dx, first_frame=first, nframes=count)
+        assert torch_cuda.equal(piece.view(torch_cuda.int32), full[first:first + count].view(torch_cuda.int32)), (first, count)
+    late = sp.run(dx, first_frame=37, nframes=frames - 37)          # a long launch that starts inside the stream, off the ring's period
+    assert torch_cuda.equal(late.view(torch_cuda.int32), full[37:].view(torch_cuda.int32))
+    per = lib.Spectrogram(lib.FftParams(n=n, window_type=lib.WINDOWS["rectangular"], overlap=ovl))
+    P = per.run(dx).cpu().numpy().astype(np.float64)
+    ring = np.zeros((nl, P.shape[1]))
+    got = full.cpu().numpy()
+    for f in range(frames):
+        ring[f % nl] = P[f]
+        my = ring.sum(axis=0) / nl
+        sy = ((ring - my) ** 2).sum(axis=0) / (nl - 1)
+        v = 0.5 * (my - np.sqrt(np.maximum(my * my - sy, 0.0)))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            o = -np.sqrt(nl / 2.0) + (nl * my) / (2.0 * np.sqrt(2.0 * nl) * v)
+        o = np.where(o <= 1e-3, 1e-3, o)
+        o[0] = 1e-3
+        assert np.allclose(got[f], o, rtol=3e-6, atol=0), (f, np.abs(got[f] / o - 1).max())
