@@ -494,6 +494,12 @@ def test_hparma_fixed_shape_kernel_equals_the_general_one(lib, torch_cuda, monke
     general = sp.run(dev).clone()
     assert fixed.shape == (frames, n // 2 + 1)
     assert torch_cuda.equal(fixed.view(torch_cuda.int32), general.view(torch_cuda.int32))
+    # frames handed out from the queue (a launch of more frames than wavefronts in flight: 1 792) against launches short enough to
+    # take the fixed assignment: a row does not depend on which wavefront computed it
+    monkeypatch.delenv("GLFER_HPARMA_GENERIC", raising=False)
+    for first, count in ((0, 1000), (1000, 1792), (2792, 208)):
+        piece = sp.run(dev, first_frame=first, nframes=count)
+        assert torch_cuda.equal(piece.view(torch_cuda.int32), fixed[first:first + count].view(torch_cuda.int32)), (first, count)
 
 
 
