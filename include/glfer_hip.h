@@ -233,6 +233,8 @@ int glfer_hip_spectrogram_host(glfer_hip_plan *plan, const void *h_stream, size_
                                float *h_psd, size_t *nframes_out);
 
 /* Pinned host memory for the ring's ends (source.c / wav_fmt.c side buffers). */
+/* (pinned with the calling thread on the CPUs of the current device's NUMA node, its affinity restored afterwards;
+ * GLFER_NUMA_BIND=0 turns the placement off) */
 void *glfer_hip_host_alloc(size_t bytes);
 void glfer_hip_host_free(void *p);
 
