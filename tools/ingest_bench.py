@@ -35,6 +35,10 @@ for name, params in (("C2 periodogram n=4096 overlap 0.75", dict(kind="fft", n=4
     t0 = time.perf_counter(); out = sp.run_host(raw); dt = time.perf_counter() - t0
     print("%s, s16 host buffer -> host PSD rows: %.2f M frames/s, %.1f GB/s over PCIe both ways"
           % (name, out.shape[0] / dt / 1e6, (ns * 2 + out.nbytes) / dt / 1e9), flush=True)
+    # (that call also grew the plan's ring to the job's chunk size: pinned staging of 2 x 256 MiB; the same call again:)
+    t0 = time.perf_counter(); out = sp.run_host(raw); dt = time.perf_counter() - t0
+    print("%s, s16 host buffer -> host PSD rows, ring at size: %.2f M frames/s, %.1f GB/s over PCIe both ways"
+          % (name, out.shape[0] / dt / 1e6, (ns * 2 + out.nbytes) / dt / 1e9), flush=True)
     del out
     # rows into pinned memory (glfer_hip_host_alloc): DMA straight into the caller's array, no staging copy
     import ctypes as C
