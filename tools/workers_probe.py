@@ -1,6 +1,9 @@
 """glfer_hip_spectrogram_host_workers with 1, 2, 4, 8 workers sharing ONE GPU (the host side of the multi-GPU entry: a thread, a plan
 and a chunk ring per worker; the GPU and its link are shared here, so the rate should hold, not scale), pinned ends; rows compared
-with the one-worker run.   python tools/workers_probe.py"""
+with the one-worker run.   python tools/workers_probe.py
+Measured (round 4, one box): 5.15 / 4.31 / 3.62 / 3.09 M frames/s with 1 / 2 / 4 / 8 workers.  The fall is this rehearsal's own: a device parks ONE
+chunk ring between calls (ingest_ring_take), so all but one of the workers that share the GPU allocate 2 x 256 MiB of pinned and device buffers
+inside every call; with a worker per GPU -- what the entry is for -- each device has its parked ring."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
