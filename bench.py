@@ -367,6 +367,63 @@ def hparma_view(res):
     return view
 
 
+def stats_rows(torch, G, local, steps=5, warmup=3):
+    """SURVEY 8(f-4)'s two per-bin statistics as rows of the line (device-resident, timed like the secondary rows, with events on the
+    launch stream): LMP (lmp.c:101-181) at the reference's defaults (lmp_av = 4, glfer.c:252; N = 1024, overlap 0) and the harmonic
+    F-test (mtm.c:165-233) on the headline's estimator (N = 4096, 5 tapers)."""
+    dev = torch.device("cuda", local)
+    rows = []
+
+    def timed(fn, frames):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return frames * steps / dt, dt / steps * 1e3, sum(a.elapsed_time(b) for a, b in ev) / steps
+
+    sp = G.Spectrogram(G.LmpParams(n=1024, overlap=0.0, avg=4), device=local)
+    frames = 1 << 20
+    x = synth_on_device(torch, frames * sp.hop, dev, seed=3, fs=8000.0)
+    out = torch.empty((frames, sp.bins), dtype=torch.float32, device=dev)
+    fps, ms, kms = timed(lambda: sp.run(x, out=out), frames)
+    b_alg = 4 * sp.hop + 4 * sp.bins
+    rows.append({"workload": "f-4: LMP detection statistic N=1024 lmp_av=4, overlap 0 (rectangular periodogram + lmp_ring_kernel)", "key": "lmp",
+                 "value": fps, "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": ms, "kernel_ms": kms, "frames_per_step": frames,
+                 "roofline": {"bound": "hbm", "achieved": frames * b_alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": frames * b_alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": b_alg,
+                              "note": "algorithmic bytes: the hop in, the statistic's row out; the launches also write the periodogram rows and read them back once (three row passes)"}})
+    sp.close()
+    del x, out
+    sp = G.Spectrogram(G.MtmParams(n=4096, overlap=0.0, w=2.5, kmax=4), device=local)
+    frames = 1 << 17
+    x = synth_on_device(torch, frames * sp.hop, dev, seed=4)
+    fout = torch.empty((frames, sp.bins), dtype=torch.float32, device=dev)
+    import ctypes as C
+    stq = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def ftest_once():
+        rc = G.api.lib().glfer_hip_mtm_ftest_device(sp._h, x.data_ptr(), x.numel(), 0, frames, fout.data_ptr(), 1, stq)
+        assert rc == 0, rc
+
+    fps, ms, kms = timed(ftest_once, frames)
+    rows.append({"workload": "f-4: harmonic F-test N=4096 NW=2.5 mtm_k=4, overlap 0 (six one-taper transforms per frame, fused)", "key": "ftest",
+                 "value": fps, "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": ms, "kernel_ms": kms, "frames_per_step": frames,
+                 "roofline": {"bound": "valu", "achieved": frames * (4 * sp.hop + 4 * sp.bins) / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": frames * (4 * sp.hop + 4 * sp.bins) / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "not HBM-bound: hn and the five tapers are six full N-point transforms of one real frame each (the statistic needs every taper's own spectrum), 2.4 x the headline's transform work"}})
+    sp.close()
+    del x, fout
+    torch.cuda.empty_cache()
+    return rows
+
+
 def parity_vs_oracle(torch, G, workload, local, frames=64):
     """max|d|/max and L2 error of the HIP rows against the CPU oracle on the first
     `frames` frames of the workload's synthetic stream (seed 0) -- the checker beside the number, not
@@ -633,6 +690,7 @@ def main():
                                   "frac": r["frames"] * (4 * r["hop"] + 4 * r["bins"] + 12 * r["bins"]) / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_frame": 4 * r["hop"] + 4 * r["bins"] + 12 * r["bins"],
                                   "note": "both launches: the hop in, the PSD row out, the row in again and 8 B per bin of averages out"}})
+        rows.extend(stats_rows(torch, G, local))
         line["secondary"] = rows
         line["parity"] = parity_vs_oracle(torch, G, args.workload, local)
         line["end_to_end"] = end_to_end(torch, G, local)
