@@ -163,7 +163,8 @@ def test_hparma_do_hop_by_hop(compat, oracle):
         hop = x[f * h:(f + 1) * h].copy()
         compat.hparma_do(_fp(hop), _fp(psd), None, C.byref(p))
         _set(compat, "glfer_compat_first_buffer", 0)
-        assert max(rel_err(1.0 / psd[:n // 2].astype(np.float64), 1.0 / want[f, :n // 2].astype(np.float64))) < 1e-4
+        # BASELINE config 5's matrix shape (t = 128, p_e = 32, N = 4096): the usual 1e-5 on |A(f)|^2 / N (tests/_spread.py)
+        assert max(rel_err(1.0 / psd[:n // 2].astype(np.float64), 1.0 / want[f, :n // 2].astype(np.float64))) < 1e-5
     compat.hparma_close(C.byref(p))
 
 
@@ -211,13 +212,22 @@ def test_lmp_do_hop_by_hop(compat, oracle):
     p.fft.n, p.fft.window_type, p.fft.overlap, p.fft.a, p.fft.limiter, p.avg = n, 5, ovl, 0.0, 0, nl
     compat.lmp_init(C.byref(p))
     want = oracle.spectrogram_lmp(x, n, ovl, nl, sub_mean=1)
+    # the bound of tests/test_gpu_round2.py::test_lmp_vs_oracle: 3 x the largest movement the oracle's own statistic makes in some
+    # frame of this stream when its input moves by one float ulp (the statistic divides by a per-bin variance), never below 1e-5
+    from _spread import ulp_perturbations
+    spread = 0.0
+    for xp in ulp_perturbations(x, 6, seed=n):
+        wp = oracle.spectrogram_lmp(xp, n, ovl, nl, sub_mean=1)
+        spread = max(spread, float((np.abs(wp.astype(np.float64) - want).max(axis=1) / want.max(axis=1)).max()))
+    bound = max(1e-5, 3.0 * spread)
+    print("lmp_do: oracle 1-ulp spread %.2e, bound %.2e" % (spread, bound))
     psd = np.empty(n // 2 + 1, np.float32)
     for f in range(frames):
         hop = x[f * h:(f + 1) * h].copy()
         compat.lmp_do(_fp(hop), _fp(psd), None, C.byref(p))
         _set(compat, "glfer_compat_first_buffer", 0)
         assert psd[0] == np.float32(1e-3)
-        assert np.abs(psd.astype(np.float64) - want[f]).max() <= 2e-4 * want[f].max(), f
+        assert np.abs(psd.astype(np.float64) - want[f]).max() <= bound * want[f].max(), (f, np.abs(psd.astype(np.float64) - want[f]).max() / want[f].max(), bound)
     compat.lmp_close(C.byref(p))
 
 

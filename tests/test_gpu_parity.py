@@ -16,7 +16,7 @@ from _signals import CONFIGS, rel_err, synth
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
-HPARMA_TOL = 1e-4      # see test_hparma_parity: the estimator itself is only conditioned to ~1e-5
+HPARMA_TOL = 1e-5      # BASELINE config 5's shape; other shapes: max(1e-5, 1.1 x the oracle's own 1-ulp spread), tests/_spread.py
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -56,12 +56,9 @@ def test_golden_vectors(lib, torch_cuda, path):
         return
     sp, got = _run(lib, torch_cuda, _params(lib, g), g["x"])
     assert got.shape == g["psd"].shape
-    tol = TOL
-    if int(g["limiter"]) if "limiter" in g else 0:
-        tol = 2e-4     # |y|^0.1 through float exp/log on the device vs double libm: 1e-7*|log y| per sample
-    for f in range(got.shape[0]):
+    for f in range(got.shape[0]):                          # (the limiter fixture too: fft.c:151-156 runs in double on the device since round 4)
         emax, el2 = rel_err(got[f], g["psd"][f])
-        assert emax < tol and el2 < tol, (f, emax, el2)
+        assert emax < TOL and el2 < TOL, (f, emax, el2)
 
 
 @pytest.mark.parametrize("cfg", list(CONFIGS), ids=list(CONFIGS))
@@ -560,10 +557,10 @@ def test_wav_file_ingest(lib, oracle, torch_cuda, tmp_path, bits):
 def test_hparma_parity(lib, oracle, torch_cuda, n, overlap, t, p_e, sub_mean):
     """BASELINE config 5 (hparma.c:74-157 + util.c:261-386), incl. the reference's row-0 overflow.
     The estimator's output is 1/(|A(f)|^2/N) below Nyquist.  Parity is stated on |A(f)|^2/N,
-    peak-normalised, at 1e-4: the AR vector comes from the noise subspace of an ill-conditioned
-    matrix, and the reference's own result moves by up to ~1e-5 in this norm when its input
-    samples are perturbed by one float ulp (tests/test_oracle_pinning.py::
-    test_hparma_is_conditioned_at_1e5), so 1e-5 is not a meaningful bound for this estimator.  The reciprocal amplifies every absolute
+    peak-normalised: 1e-5 at BASELINE config 5's shape (N = 4096, t = 128, p_e = 32; measured <= 4.5e-6), and
+    max(1e-5, 1.1 x s) at the other shapes, s = the largest movement of the ORACLE's own result over this stream when its
+    input samples are perturbed by one float ulp (tests/_spread.py, computed here: the AR vector comes from the noise
+    subspace of an ill-conditioned matrix, and at t = 96, p_e = 16 the reference itself moves by 1.4e-5).  The reciprocal amplifies every absolute
     error by max|A|^2/|A_k|^2 at the spectral peaks, where the reference's own float32 FFT is
     ~1e-3 away from exact arithmetic; so the final spectrum is additionally checked against a
     float64 evaluation of the ORACLE's AR vector: per-bin relative error <= 1e-2 even at the peaks
@@ -571,17 +568,22 @@ def test_hparma_parity(lib, oracle, torch_cuda, n, overlap, t, p_e, sub_mean):
     frames = 10
     h = oracle.hop(n, overlap)
     x = synth(frames * h, seed=n + t)
+    from _spread import hparma_bound
     ref = oracle.hparma_frames(x, n, overlap, t, p_e, sub_mean=sub_mean)
+    bound, spread, _ = hparma_bound(oracle, x, n, overlap, t, p_e, sub_mean, seed=t)
     sp = lib.Spectrogram(lib.HparmaParams(n=n, overlap=overlap, t=t, p_e=p_e, sub_mean=sub_mean))
     got = sp.run(torch_cuda.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
     assert got.shape == (frames, n // 2 + 1) and np.isfinite(got).all()
     k = np.arange(n // 2 + 1)
+    worst = 0.0
     for f, (psd, a, rank) in enumerate(ref):
         want = psd.astype(np.float64)
         inv_g, inv_w = 1.0 / got[f, :n // 2], 1.0 / want[:n // 2]
-        assert max(rel_err(inv_g, inv_w)) < HPARMA_TOL, (f, rel_err(inv_g, inv_w))
-        assert abs(got[f, n // 2] / want[n // 2] - 1) < 1e-4                      # Nyquist bin is not inverted (hparma.c:154)
+        worst = max(worst, max(rel_err(inv_g, inv_w)))
+        assert max(rel_err(inv_g, inv_w)) <= bound, (f, rel_err(inv_g, inv_w), bound, spread)
+        assert abs(got[f, n // 2] / want[n // 2] - 1) < 1e-5                      # Nyquist bin is not inverted (hparma.c:154)
         A = np.polyval(a[::-1].astype(np.float64), np.exp(-2j * np.pi * k / n))   # sum_m a[m] z^m
         exact = np.abs(A) ** 2 / n
         exact[:n // 2] = 1.0 / exact[:n // 2]
         assert np.abs(got[f] / exact - 1).max() < 1e-2, (f, rank, np.abs(got[f] / exact - 1).max())
+    print("hparma N=%d t=%d p_e=%d: worst %.2e, bound %.2e (oracle 1-ulp spread %.2e)" % (n, t, p_e, worst, bound, spread))

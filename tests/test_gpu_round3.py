@@ -689,15 +689,17 @@ def test_random_big_blocks_and_exact_means(lib, oracle, torch_cuda, case):
 def test_hparma_over_many_streams(lib, oracle, torch_cuda, n, overlap, t, p_e, sub_mean):
     """hparma.hip's wave_sum3: every lane must take a rotation's skip / swap decisions on the SAME bits -- a first form that let
     each quad use its own (differently associated) totals was wrong in one frame in six at t = 96 and right at t = 128 and 64.
-    Eight streams per shape, |A(f)|^2/N peak-normalised within 1e-4 of the oracle (the bound of test_hparma_parity; the device
-    sits at 2e-6 median / 2e-5 worst, where the oracle itself moves when its input moves by one float ulp:
-    tools/hparma_err_spread.py)."""
+    Eight streams per shape, |A(f)|^2/N peak-normalised against the oracle within test_hparma_parity's bound: 1e-5 at BASELINE
+    config 5's shape, max(1e-5, 1.1 x the oracle's own movement under 1-ulp input noise on that stream) elsewhere
+    (tests/_spread.py; the device sits at 2e-6 median where the oracle itself moves by 1.4e-5 at t = 96)."""
+    from _spread import hparma_bound
     h = oracle.hop(n, overlap)
     frames = 8
     worst = 0.0
     for seed in range(8):
         x = synth(frames * h, seed=5000 + 100 * seed + t)
         ref = oracle.hparma_frames(x, n, overlap, t, p_e, sub_mean=sub_mean)
+        bound, spread, _ = hparma_bound(oracle, x, n, overlap, t, p_e, sub_mean, draws=8, seed=seed)
         sp = lib.Spectrogram(lib.HparmaParams(n=n, overlap=overlap, t=t, p_e=p_e, sub_mean=sub_mean))
         got = sp.run(torch_cuda.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
         assert np.isfinite(got).all()
@@ -705,5 +707,5 @@ def test_hparma_over_many_streams(lib, oracle, torch_cuda, n, overlap, t, p_e, s
             want = ref[f][0].astype(np.float64)
             e = max(rel_err(1.0 / got[f, :n // 2], 1.0 / want[:n // 2]))
             worst = max(worst, e)
-            assert e < 1e-4, (seed, f, e)
+            assert e <= bound, (seed, f, e, bound, spread)
     print("HP-ARMA N=%d t=%d p_e=%d: worst %.1e over 64 frames" % (n, t, p_e, worst))

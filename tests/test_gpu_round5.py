@@ -1,0 +1,102 @@
+"""Round 5 (-m gpu): what VERDICT r4 asked to see in the driver's own record.
+
+* 64-bit addressing: streams of 16 GiB (f32) and 8 GiB (s16), rows past the 2^32-byte marks, probed at the start, the
+  middle and the LAST frames against the oracle (was tests/big_stream_check.py, a script).
+* the bench-scale launches themselves (bench.py's 2^30-sample streams: C3 262 144 frames, C2 1 048 576 frames, C1
+  2 097 152 frames), with and without the reference's mean removal: their first, middle and LAST frames against the
+  oracle -- the workgroup that walks the end of the range, the clamped frame slots, the last rows' stores.
+"""
+import numpy as np
+import pytest
+
+from _signals import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _oracle_row(oracle, params, lib, seg, n, overlap):
+    """The LAST row of the oracle run over `seg` (whole hops, true overlap)."""
+    if params.mode == lib.MODE_MTM:
+        return oracle.spectrogram_mtm(seg, n, overlap, params.w, params.kmax, sub_mean=1 if params.sub_mean else 0)[-1]
+    return oracle.spectrogram_fft(seg, n, overlap, params.window_type, 0.0, 0, 1 if params.sub_mean else 0, 0)[-1]
+
+
+def _probe(lib, oracle, torch, params, x, probes, to_float=lambda a: a, out=None):
+    """Run the whole stream through the C-ABI, then compare the probed frames with the oracle.  A probed frame f is
+    recomputed by the oracle from the hops [f - 2 * back, f]: by the last of those frames the zero history of the
+    segment's start has left the frame (and every hop the frame touches carries its own mean), so the last row is the
+    frame as the reference would compute it in the middle of the stream."""
+    sp = lib.Spectrogram(params)
+    rows = sp.run(x, out=out)
+    torch.cuda.synchronize()
+    n, h = sp.n, sp.hop
+    assert rows.shape[0] == x.numel() // h
+    back = (n - h + h - 1) // h
+    worst = 0.0
+    for f in probes:
+        f0 = max(f - 2 * back, 0)
+        seg = np.ascontiguousarray(to_float(x[f0 * h:(f + 1) * h].cpu().numpy()))
+        want = _oracle_row(oracle, params, lib, seg, n, params.overlap)
+        got = rows[f].cpu().numpy()
+        e = max(rel_err(got, want))
+        assert e < TOL, (f, e)
+        worst = max(worst, e)
+    total = rows.shape[0]
+    sp.close()
+    return worst, total
+
+
+def test_streams_past_4_gib_are_addressed_with_64_bits(lib, oracle, torch_cuda):
+    """16 GiB of f32 samples (2^20 frames of N = 4096, multitaper, overlap 0: 8.6 GB of rows) and 8 GiB of s16 samples at
+    75 % overlap (2^22 hops: 34 GB of rows), with and without mean removal: frames either side of every 2^32-byte mark
+    that matters and the last ones."""
+    torch = torch_cuda
+    frames = 1 << 20
+    x = torch.empty(frames * 4096, dtype=torch.float32, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    for s in range(0, x.numel(), 1 << 28):
+        e = min(x.numel(), s + (1 << 28))
+        x[s:e] = torch.sin(torch.arange(s, e, device="cuda", dtype=torch.float64) * 0.013).float() * 0.4
+        x[s:e] += 0.05 * torch.randn(e - s, device="cuda", generator=g)
+    worst, total = _probe(lib, oracle, torch, lib.MtmParams(n=4096, overlap=0.0, w=2.5, kmax=4), x,
+                          [0, 1, 262143, 262144, 524287, 524288, frames - 2, frames - 1])
+    print("multitaper N=4096 f32, %d frames, 16 GiB stream: worst probed frame %.2e" % (total, worst))
+    del x
+    torch.cuda.empty_cache()
+    hops = 1 << 22
+    x = torch.empty(hops * 1024, dtype=torch.int16, device="cuda")
+    for s in range(0, x.numel(), 1 << 28):
+        e = min(x.numel(), s + (1 << 28))
+        x[s:e] = (torch.randn(e - s, device="cuda", generator=g) * 3000 + 700).clamp_(-32768, 32767).to(torch.int16)
+    out = torch.empty((hops, 2049), dtype=torch.float32, device="cuda")
+    for sub_mean in (0, 1):
+        worst, total = _probe(lib, oracle, torch, lib.FftParams(n=4096, window_type=0, overlap=0.75, sample_format=lib.SAMPLES_S16, sub_mean=sub_mean), x,
+                              [0, 2, 3, 4, 40, 524287, 524288, 2097151, 2097152, hops - 2, hops - 1], to_float=oracle.pcm_s16_to_float, out=out)
+        print("periodogram N=4096 s16 75%%, sub_mean %d, %d frames, 8 GiB stream: worst probed frame %.2e" % (sub_mean, total, worst))
+
+
+@pytest.mark.parametrize("workload,sub_mean", [("mtm", 0), ("mtm", 1), ("fft", 0), ("fft", 1), ("fft1k", 0), ("fft1k", 1), ("mtm75", 0), ("mtm16k", 0)])
+def test_last_frames_of_the_bench_scale_launch(lib, oracle, torch_cuda, workload, sub_mean):
+    """bench.py's own launches -- the same stream generator, seed, length and parameters -- probed at their first, middle and
+    last frames (frame 262 143 of the 2^30-sample C3 launch, 1 048 575 of C2's, 2 097 151 of C1's)."""
+    import bench
+    torch = torch_cuda
+    name, n, overlap, nw, kmax, frames, _ = bench.WORKLOADS[workload]
+    params = bench.make_params(lib, workload, **(dict(sub_mean=lib.SUBMEAN_EXACT) if sub_mean else {}))
+    h = oracle.hop(n, overlap)
+    x = bench.synth_on_device(torch, frames * h, torch.device("cuda", 0), seed=0, fs=8000.0 if workload == "fft1k" else 48000.0)
+    if sub_mean:
+        x += 0.1                                     # (the "+mean" rows of the line run on a stream with a DC level)
+    mid = frames // 2
+    worst, total = _probe(lib, oracle, torch, params, x, [0, 1, 5, mid - 1, mid, frames - 65, frames - 3, frames - 2, frames - 1])
+    assert total == frames
+    print("%s sub_mean %d: %d frames, worst probed frame %.2e" % (workload, sub_mean, frames, worst))
