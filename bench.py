@@ -204,13 +204,35 @@ def dry_run(args, world, rank):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    per_rank = [float(rank + 1)]
+    host_phase = None
     if world > 1:
         dist.barrier()
+        per_rank = gather_per_rank(torch, dist, t, world)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # the host-side phase of the real run: rank 0 works (here: sleeps), the others wait on the CPU
+        host_phase = host_side_phase(dist, rank, None, lambda: {"slept_s": time.sleep(0.2) or 0.2})
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": t.item(), "steps": args.steps,
-                          "warmup": args.warmup, "workload": args.workload}))
+                          "warmup": args.warmup, "workload": args.workload, "per_rank": per_rank, "host_phase": host_phase}))
+
+
+def gather_per_rank(torch, dist, t, world):
+    """Every rank's own value of the one-element tensor t, in rank order (the MAX over them is what the contract reports)."""
+    lst = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(lst, t)
+    return [x.item() for x in lst]
+
+
+def host_side_phase(dist, rank, cpu_group, work):
+    """"scaling risk is host-side only" -- so after the device-resident timing ONE process (rank 0) drives every GPU of
+    the job through the host entries (one worker thread, plan and pinned ring per GPU: glfer_hip_spectrogram_host_multi,
+    glfer_hip_spectrogram_wav_multi) while the other ranks wait at a barrier on the CPU (a gloo group: an RCCL barrier would
+    keep their GPUs spinning under rank 0's workers).  Returns work()'s result on rank 0, None elsewhere."""
+    out = work() if rank == 0 else None
+    dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
+    return out
 
 
 def cpu_model():
@@ -246,7 +268,7 @@ def pmc_summary(pmc_name):
     return None, None
 
 
-def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local, rehearse, params_kw=None, avg_depth=0, dc=0.0):
+def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local, rehearse, params_kw=None, avg_depth=0, dc=0.0, avg_form="two"):
     """W untimed + K timed passes of one workload over this rank's frame range; the timed region is
     bracketed by barrier + synchronize on both sides and the MAX over ranks is taken.  Returns a dict
     (every rank; only rank 0 uses it)."""
@@ -272,6 +294,15 @@ def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local,
     import ctypes as C
 
     def step():
+        if avg_depth and avg_form != "two":
+            # fft_do + fft_psd + update_avg_plain in ONE launch (glfer_hip_spectrogram_avg_device: the average taken on the |X|^2
+            # values in registers); "fused": the PSD rows are never stored, "fused+rows": they are
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = G.api.lib().glfer_hip_spectrogram_avg_device(
+                sp._h, C.c_void_p(shard.data_ptr() - begin * shard.element_size()), begin + shard.numel(), first, count, G.AVG_PLAIN, avg_depth, 0, bins, 0,
+                bins, C.c_void_p(psd.data_ptr() if avg_form == "fused+rows" else None), C.c_void_p(avg_out[0].data_ptr()), C.c_void_p(avg_out[1].data_ptr()), st)
+            assert rc == 0, rc
+            return
         run_shard(sp, shard, begin, first, count, out=psd)
         if avg_depth:
             st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -296,15 +327,20 @@ def measure(torch, G, dist, workload, frames, steps, warmup, world, rank, local,
         a.record()
         step()
         b.record()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                 # this rank's own K steps, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     each = [a.elapsed_time(b) for a, b in ev]
     kernel_ms = sum(each) / steps
     tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
+    per_rank_ms = [dt_own / steps * 1e3]
     if world > 1:
+        per_rank_ms = [v / steps * 1e3 for v in gather_per_rank(torch, dist, torch.tensor([dt_own], dtype=torch.float64, device="cpu" if rehearse else dev), world)]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
-    res = {"workload": workload, "name": name, "n": n, "overlap": overlap, "hop": hop, "bins": bins, "frames": frames,
+    dt_local = dt
+    res = {"workload": workload, "name": name, "n": n, "overlap": overlap, "hop": hop, "bins": bins, "frames": frames, "dt_local": dt_local, "per_rank_ms": per_rank_ms,
            "ntapers": sp.ntapers, "dt": dt, "kernel_ms": kernel_ms, "fps": frames * world * steps / dt,
            "ms_per_step": dt / steps * 1e3, "b_alg": 4 * hop + 4 * bins,
            "kernel_ms_first": each[0], "kernel_ms_min": min(each), "kernel_ms_max": max(each)}
@@ -520,7 +556,44 @@ def end_to_end(torch, G, local, frames=131072, reps=3):
             "note": "best of %d calls after the first, spread over three seconds; pinned copies on this pool's boxes run at 57 GB/s one way and 48 + 48 GB/s both ways (tools/pcie_probe.py, profiles/r04_ingest_pcie_inclusive.txt)" % len(rates)}
 
 
-def c4_as_worded(torch, G, local):
+def end_to_end_multi(torch, G, local, devices, frames_per_gpu=32768, reps=3):
+    """The N > 1 line's host-side row: the headline workload from ONE process over every GPU of the job -- pinned 16-bit PCM in
+    host memory in, pinned rows out, through glfer_hip_spectrogram_host_workers (one worker thread + plan + pinned ring per
+    entry of `devices`; frame ranges, no collective).  Where scaling can be lost (PCIe, NUMA placement, thread wake-ups: SURVEY
+    8(e)) and the device-resident value cannot show it."""
+    import ctypes as C
+    import numpy as np
+    name, n, overlap, nw, kmax, _, _ = WORKLOADS["mtm"]
+    params = G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sample_format=G.SAMPLES_S16)
+    cfg = G.make_config(params, devices[0])
+    frames = frames_per_gpu * len(devices)
+    hop, bins = n, n // 2 + 1
+    pcm = G.pinned_empty((frames * hop,), np.int16)
+    piece = 1 << 26
+    for s0 in range(0, frames * hop, piece):                        # (the stream is made on this rank's GPU, a piece at a time)
+        e0 = min(frames * hop, s0 + piece)
+        x = synth_on_device(torch, e0 - s0, torch.device("cuda", local), seed=7 + s0 // piece)
+        pcm[s0:e0] = (x * 32767.0).round().to(torch.int16).cpu().numpy()
+        del x
+    rows = G.pinned_empty((frames, bins), np.float32)
+    devs = (C.c_int * len(devices))(*devices)
+    times = []
+    for _ in range(reps + 1):
+        nf = C.c_size_t(0)
+        t0 = time.perf_counter()
+        rc = G.api.lib().glfer_hip_spectrogram_host_workers(C.byref(cfg), devs, len(devices), pcm.ctypes.data, pcm.size, rows.ctypes.data, C.byref(nf))
+        times.append(time.perf_counter() - t0)
+        assert rc == 0 and nf.value == frames, (rc, nf.value)
+    del rows, pcm
+    best = min(times[1:])
+    nbytes = frames * (2 * hop + 4 * bins)
+    return {"workload": name + ", 16-bit PCM, one process driving %d GPUs" % len(devices), "devices": list(devices),
+            "path": "pinned host samples -> glfer_hip_spectrogram_host_workers (one worker per GPU) -> pinned host rows",
+            "frames": frames, "frames_per_gpu": frames_per_gpu, "value": frames / best, "unit": "frames/s", "seconds": best,
+            "first_call_seconds": times[0], "calls_seconds": times, "pcie_gbs_both_directions_aggregate": nbytes / best / 1e9}
+
+
+def c4_as_worded(torch, G, local, devices=None):
     """BASELINE config 4 as worded: a 1-hour 48 kHz mono 16-bit WAV (346 MB, written to /dev/shm here) through
     glfer_hip_spectrogram_wav_multi on every visible GPU -- multitaper N = 16384, 9 tapers -- wall seconds, file to rows
     in host memory (source.c:193, wav_fmt.c:45-121 as a batch)."""
@@ -541,27 +614,26 @@ def c4_as_worded(torch, G, local):
         del pcm
         import ctypes as C
         import numpy as np
-        devices = list(range(torch.cuda.device_count()))
+        if devices is None:
+            devices = list(range(torch.cuda.device_count()))
         params = G.MtmParams(n=n, overlap=overlap, w=nw, kmax=kmax, sample_format=G.SAMPLES_S16)
-        cfg = G.make_config(params, 0)
+        cfg = G.make_config(params, devices[0])
         frames = nsamples // n
         rows = G.pinned_empty((frames, n // 2 + 1), np.float32)     # the application's row buffer, made once (pinned: rows arrive by DMA)
-        mask = 0
-        for dv in devices:
-            mask |= 1 << dv
+        devs = (C.c_int * len(devices))(*devices)             # (one worker per entry; an ordinal may repeat: the one-GPU rehearsal)
         times = []
-        for _ in range(3):
+        for _ in range(4):
             nf = C.c_size_t(0)
             t0 = time.perf_counter()
-            rc = G.api.lib().glfer_hip_spectrogram_wav_multi(C.byref(cfg), mask, os.fsencode(path), rows.ctypes.data, frames, C.byref(nf), 0)
+            rc = G.api.lib().glfer_hip_spectrogram_wav_workers(C.byref(cfg), devs, len(devices), os.fsencode(path), rows.ctypes.data, frames, C.byref(nf), 0)
             times.append(time.perf_counter() - t0)
             assert rc == 0 and nf.value == frames, (rc, nf.value)
         del rows
         return {"workload": "C4 as worded: multitaper N=16384 NW=4.5 mtm_k=8 over a 1-hour 48 kHz 16-bit mono WAV", "file_bytes": 44 + 2 * nsamples,
-                "gpus": len(devices), "frames": frames, "wall_seconds": min(times), "first_call_seconds": times[0],
+                "gpus": len(set(devices)), "workers": len(devices), "frames": frames, "wall_seconds": min(times), "first_call_seconds": times[0], "calls_seconds": times,
                 "value": frames / min(times), "unit": "frames/s",
-                "path": "glfer_hip_spectrogram_wav_multi: every worker opens the file and reads its own part, rows by DMA into a pinned host buffer",
-                "note": "file in %s (page cache); best of 3 calls, each making its own plans and rings (per-call set-up is inside the time); "
+                "path": "glfer_hip_spectrogram_wav_workers: every worker opens the file and reads its own part, rows by DMA into a pinned host buffer",
+                "note": "file in %s (page cache); best of 4 calls (the workers, their plans and rings are kept between calls: the first call makes them); "
                         "the kernel alone runs this file's 10 546 frames in ~1.2 ms" % d}
     finally:
         try:
@@ -680,22 +752,38 @@ def main():
         rows.append({"workload": r["name"] + ", rows at a pitch of 2112 floats (cfg.psd_pitch)", "key": "fft+pitch2112", "value": r["fps"],
                      "unit": "frames/s", "steps": 5, "warmup": SECONDARY_WARMUP, "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"],
                      "frames_per_step": r["frames"], "roofline": roofline_of(r, "fft")})
-        # SURVEY 8(d)'s avg-on row: C2 followed by update_avg_plain, depth 4, over the whole band (avg.c:108-159; one fused kernel)
-        r = measure(torch, G, dist, "fft", 262144, 5, SECONDARY_WARMUP, world, rank, local, rehearse, avg_depth=4)
-        rows.append({"workload": r["name"] + " + update_avg_plain depth 4 (avg_fused_kernel, 8 B out per bin)", "key": "fft+avg", "value": r["fps"],
-                     "unit": "frames/s", "steps": 5, "warmup": SECONDARY_WARMUP, "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"],
-                     "frames_per_step": r["frames"],
-                     "roofline": {"bound": "hbm", "achieved": r["frames"] * (4 * r["hop"] + 4 * r["bins"] + 12 * r["bins"]) / (r["kernel_ms"] * 1e-3) / 1e9,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": r["frames"] * (4 * r["hop"] + 4 * r["bins"] + 12 * r["bins"]) / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "algorithmic_bytes_per_frame": 4 * r["hop"] + 4 * r["bins"] + 12 * r["bins"],
-                                  "note": "both launches: the hop in, the PSD row out, the row in again and 8 B per bin of averages out"}})
+        # SURVEY 8(d)'s avg-on row: C2 with update_avg_plain, depth 4, over the whole band (avg.c:108-159).  "fft+avg": the average
+        # taken inside the periodogram launch, PSD rows never stored (north_star: |X|^2 + block-average fused in-register);
+        # "fft+avg+rows": the same launch storing the rows too; "fft+avg two launches": rows, then avg_fused_kernel over them (round 4's row)
+        for form, key, what, extra in (("fused", "fft+avg", "one launch, the average taken in registers, PSD rows not stored", 0),
+                                       ("fused+rows", "fft+avg+rows", "one launch, the average taken in registers, PSD rows stored as well", 4),
+                                       ("two", "fft+avg two launches", "rows, then avg_fused_kernel over them: the row in again, 8 B per bin out", 8)):
+            r = measure(torch, G, dist, "fft", 262144, 5, SECONDARY_WARMUP, world, rank, local, rehearse, avg_depth=4, avg_form=form)
+            b = 4 * r["hop"] + 8 * r["bins"] + 32 + extra * r["bins"]
+            rows.append({"workload": r["name"] + " + update_avg_plain depth 4 (%s)" % what, "key": key, "value": r["fps"],
+                         "unit": "frames/s", "steps": 5, "warmup": SECONDARY_WARMUP, "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"],
+                         "frames_per_step": r["frames"],
+                         "roofline": {"bound": "hbm", "achieved": r["frames"] * b / (r["kernel_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": r["frames"] * b / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": b,
+                                      "note": "bytes this form moves by construction: the hop in, 8 B per bin of averages + 32 B of return values out"
+                                              + (", 4 B per bin of PSD row out" if extra == 4 else (", the PSD row out and in again" if extra == 8 else ""))}})
         rows.extend(stats_rows(torch, G, local))
         line["secondary"] = rows
         line["parity"] = parity_vs_oracle(torch, G, args.workload, local)
         line["end_to_end"] = end_to_end(torch, G, local)
         line["c4_as_worded"] = c4_as_worded(torch, G, local)
+    # ---- N > 1: the host-side rows (rank 0 drives every GPU of the job from one process; the other ranks wait on the CPU)
+    if world > 1 and not args.no_secondary and args.workload == "mtm":
+        cpu_group = None if rehearse else dist.new_group(backend="gloo")
+        devs = [0] * world if rehearse else list(range(world))
+        host = host_side_phase(dist, rank, cpu_group, lambda: {"end_to_end": end_to_end_multi(torch, G, local, devs),
+                                                               "c4_as_worded": c4_as_worded(torch, G, local, devs)})
+        if rank == 0:
+            line["host_side"] = host
+            line["host_side"]["note"] = ("one process (rank 0) over all %d GPUs while the other ranks wait at a CPU barrier: the path on which "
+                                         "multi-GPU scaling can be lost (SURVEY 8(e)); never part of `value`" % world)
     if rank == 0:
+        line["per_rank_ms_per_step"] = res["per_rank_ms"]
         if world == 1 and not args.no_cpu_baseline:
             _, n, overlap, nw, kmax, _, cpu_frames = WORKLOADS[args.workload]
             line["cpu_baseline"] = cpu_baseline(args.workload, n, overlap, nw, kmax, cpu_frames)

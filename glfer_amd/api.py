@@ -47,6 +47,8 @@ EXPORTS = [
     "glfer_hip_waterfall_wav_multi", "glfer_hip_submean_exact_device",
     # round 4
     "glfer_hip_numa_node_of_bus_id", "glfer_hip_numa_node_cpus", "glfer_hip_floor_device_pitched",
+    # round 5
+    "glfer_hip_abi_version", "glfer_hip_spectrogram_avg_device",
 ]
 
 
@@ -171,6 +173,8 @@ def lib():
     for f in ("glfer_hip_strerror", "glfer_hip_last_hip_error", "glfer_hip_version"):
         getattr(L, f).restype = C.c_char_p
     L.glfer_hip_strerror.argtypes = [C.c_int]
+    L.glfer_hip_abi_version.argtypes = []
+    L.glfer_hip_spectrogram_avg_device.argtypes = [vp, vp, sz, sz, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -334,6 +338,26 @@ class Spectrogram:
                                                   first_frame, nframes, out.data_ptr(), st),
                "glfer_hip_spectrogram_device")
         return out                                       # (with cfg.psd_pitch: [nframes][pitch], a row's first `bins` floats are its bins)
+
+    def run_avg(self, stream, avg_mode, depth, minbin, maxbin, max0=0, n_out=None, want_psd=False, want_ret=True,
+                first_frame=0, nframes=None):
+        """fft_do + fft_psd + update_avg_* in one call (glfer_hip_spectrogram_avg_device): returns (avg [nframes][n_out] float64,
+        ret [nframes][4] float64 or None, psd [nframes][bins] float32 or None)."""
+        torch = _torch()
+        assert stream.is_cuda and stream.dim() == 1 and stream.is_contiguous() and stream.dtype == self._sample_dtype()
+        if nframes is None:
+            nframes = self.num_frames(stream.numel()) - first_frame
+        n_out = n_out or self.bins
+        avg = torch.empty((nframes, n_out), dtype=torch.float64, device=stream.device)
+        ret = torch.empty((nframes, 4), dtype=torch.float64, device=stream.device) if want_ret else None
+        psd = torch.empty((nframes, self.bins), dtype=torch.float32, device=stream.device) if want_psd else None
+        st = C.c_void_p(torch.cuda.current_stream(stream.device).cuda_stream)
+        _check(lib().glfer_hip_spectrogram_avg_device(self._h, C.c_void_p(stream.data_ptr()), stream.numel(), first_frame, nframes,
+                                                      int(avg_mode), int(depth), int(minbin), int(maxbin), int(max0), int(n_out),
+                                                      C.c_void_p(psd.data_ptr() if want_psd else None), C.c_void_p(avg.data_ptr()),
+                                                      C.c_void_p(ret.data_ptr() if want_ret else None), st),
+               "glfer_hip_spectrogram_avg_device")
+        return avg, ret, psd
 
     def run_wav(self, path, chunk_frames=0, max_frames=None, partial_tail=False):
         """Whole WAV file -> numpy psd [frames][bins], streamed through pinned buffers.

@@ -4,6 +4,7 @@
 // HBM-bound streaming/reduction kernels over PSD rows; no LDS tiling beyond the row itself.
 #include <hip/hip_runtime.h>
 #include "display_map.hpp"
+#include "div_exact.hpp"
 #include <stdint.h>
 #include <type_traits>
 
@@ -527,9 +528,6 @@ __global__ __launch_bounds__(256) void avg_norm_kernel(const float *__restrict__
 #ifndef GLFER_AVG_AHEAD
 #define GLFER_AVG_AHEAD 1    /* frames requested ahead of the one being reduced: 1 or 2 (measured: no difference, see the kernel) */
 #endif
-#ifndef GLFER_AVG_ABL
-#define GLFER_AVG_ABL 0    /* timing ablations (results wrong): 1 no row stores, 2 no wavefront reduction, 4 no barrier, 8 no quotients */
-#endif
 #if GLFER_AVG_ABL & 1
 #define GLFER_AVG_STORE(dst, val) do { const double v_ = (val); if (v_ == 1.2345e-300) (dst) = v_; } while (0)
 #else
@@ -539,74 +537,8 @@ __global__ __launch_bounds__(256) void avg_norm_kernel(const float *__restrict__
 #define GLFER_AVG_STORE(dst, val) (dst) = (val)
 #endif
 #endif
-// ---- double-precision wavefront reductions by DPP: row_shr 1,2,4,8 leave a row's result in its lane
-// 15, row_bcast 15 / 31 carry it to lane 63, readlane broadcasts it.  A lane without a source takes
-// `ZERO ? 0 : itself` -- the identity of a sum / of a maximum or minimum.  (Six ds_bpermute rounds
-// per value, as __shfl_xor does it, cost an LDS round trip each.)
-template <int CTRL, int ROWMASK, bool ZERO>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
-  const unsigned rl = (unsigned)__builtin_amdgcn_update_dpp(ZERO ? 0 : lo, lo, CTRL, ROWMASK, 0xf, false);
-  const unsigned rh = (unsigned)__builtin_amdgcn_update_dpp(ZERO ? 0 : hi, hi, CTRL, ROWMASK, 0xf, false);
-  return __longlong_as_double((long long)(((unsigned long long)rh << 32) | rl));
-}
-__device__ __forceinline__ double lane63_f64(double v) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-// over the wavefront: the sum of s, the maximum of mx with the LOWEST index mi among equals, the minimum of mn
-// (INDEX = false: the index is not wanted -- a column that is only mapped has no peak bin to return)
-template <bool INDEX = true>
-__device__ __forceinline__ void wave_sum_max_min(double &s, double &mx, int &mi, double &mn) {
-  auto step = [&](auto ctrl, auto rowmask) {
-    constexpr int CT = decltype(ctrl)::value, RM = decltype(rowmask)::value;
-    const double os = dpp_f64<CT, RM, true>(s), om = dpp_f64<CT, RM, false>(mx), on = dpp_f64<CT, RM, false>(mn);
-    s += os;
-    if constexpr (INDEX) {
-      const int oi = __builtin_amdgcn_update_dpp(mi, mi, CT, RM, 0xf, false);
-      if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
-    } else {
-      mx = om > mx ? om : mx;
-    }
-    mn = on < mn ? on : mn;
-  };
-  step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
-  step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
-  step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
-  step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
-  step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
-  step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
-  s = lane63_f64(s);
-  mx = lane63_f64(mx);
-  mn = lane63_f64(mn);
-  if constexpr (INDEX) mi = __builtin_amdgcn_readlane(mi, 63);
-}
-
-// a / d for many a and one d, correctly rounded: with y = RN(1/d) (one true division),
-// q0 = RN(a y), r = a - d q0 (exact in an fma), q = RN(q0 + r y) is RN(a/d) (Markstein) as long as
-// nothing over- or underflows on the way -- so only for 1e-100 < |d| < 1e100 (the operands here
-// are sums of float32 bins: below 1e40, and a quotient of 1e-45/1e100 is still a normal double);
-// any other divisor (0, inf, NaN, denormal) takes the division itself.
-struct Divisor {
-  double d, y;
-  bool fast;
-  __device__ __forceinline__ explicit Divisor(double dd) : d(dd), y(1.0 / dd) {
-    const double a = dd < 0 ? -dd : dd;
-    fast = __builtin_amdgcn_readfirstlane((a > 1e-100 && a < 1e100) ? 1 : 0) != 0;   // d is the same in every lane
-  }
-  __device__ __forceinline__ double operator()(double a) const {
-#if GLFER_AVG_ABL & 8
-    return a + y;
-#endif
-    if (!fast) return a / d;
-    const double q0 = a * y;
-    const double r = __builtin_fma(-d, q0, a);
-    return __builtin_fma(r, y, q0);
-  }
-};
+// (the double-precision wavefront reductions by DPP -- dpp_f64, lane63_f64, wave_sum_max_min -- live in div_exact.hpp too)
+// (Divisor -- a / d for many a and one d, correctly rounded -- lives in div_exact.hpp: the periodogram kernel's own average uses it too)
 
 // RING: the last `depth` rows of the block's bins are kept in LDS (hist[f mod depth][j][tid], every
 // thread its own words: no synchronisation), so the row that leaves the sliding sum is not read from
@@ -766,19 +698,41 @@ __global__ __launch_bounds__(NT) void avg_fused_kernel(const float *__restrict__
     const double init = (double)psd[(size_t)f * bins + minbin];
     double s = 0.0, mx = -1.0e300, mn = 1.0e300;
     int mi = 0x7fffffff;
+    // Windows of up to four rows (the reference's default depth, glfer.c:295-296) with the ring: the sum is taken DIRECTLY,
+    // ((p[f-3] + p[f-2]) + p[f-1]) + p[f] in double, oldest row first -- the additions, in the order, that the periodogram
+    // kernel's own average makes (spectro16h.hip AVG: it keeps those rows in registers), so that the two agree double for double
+    // even where a bin spans more than 2^26 within the window and the additions round (round 5; the running sum below and this
+    // one differ there in the last bits, and neither is the reference's own rounding history).
+    const bool direct = RING && depth <= 4;                      // (the same in every thread)
     if constexpr (RING) {                                      // row f - depth leaves the sum, row f takes its slot
       float *h = hist + ((size_t)(f % depth) * BPT) * NT + tid;
+      if (direct) {
+        const float *h1 = hist + ((size_t)((f + depth - 1) % depth) * BPT) * NT + tid;   // row f - 1
+        const float *h2 = hist + ((size_t)((f + 2 * depth - 2) % depth) * BPT) * NT + tid;   // row f - 2
+        const float *h3 = hist + ((size_t)((f + 3 * depth - 3) % depth) * BPT) * NT + tid;   // row f - 3
+        const bool k1 = depth >= 2 && f >= 1, k2 = depth >= 3 && f >= 2, k3 = depth >= 4 && f >= 3;
 #pragma unroll
-      for (int j = 0; j < BPT; j++)
-        if (b0 + NT * j < maxbin) {
-          old[CUR][j] = h[NT * j];
-          h[NT * j] = v[CUR][j];
-        }
+        for (int j = 0; j < BPT; j++)
+          if (b0 + NT * j < maxbin) {
+            double c = (k3 ? (double)h3[NT * j] : 0.0) + (k2 ? (double)h2[NT * j] : 0.0);   // (adding +0.0 to a sum of non-negative bins is exact)
+            c += k1 ? (double)h1[NT * j] : 0.0;
+            cum[j] = c + (double)v[CUR][j];
+            h[NT * j] = v[CUR][j];
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < BPT; j++)
+          if (b0 + NT * j < maxbin) {
+            old[CUR][j] = h[NT * j];
+            h[NT * j] = v[CUR][j];
+          }
+      }
     }
 #pragma unroll
     for (int j = 0; j < BPT; j++) {
       if (b0 + NT * j < maxbin) {
-        if (f < depth) cum[j] += (double)v[CUR][j];
+        if (direct) {
+        } else if (f < depth) cum[j] += (double)v[CUR][j];
         else cum[j] += (double)v[CUR][j] - (double)old[CUR][j];
         const double c = cum[j];
         s += c;

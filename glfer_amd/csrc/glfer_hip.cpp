@@ -143,6 +143,12 @@ bool scratch_cache_on() {
 }
 }  // namespace
 
+bool scratch_keeping() { return scratch_cache_on(); }
+size_t scratch_cap() {
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  return g_scratch_cap;
+}
+
 hipError_t scratch_malloc(void **p, size_t bytes, hipStream_t st) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipMallocAsync(p, bytes, st);
@@ -355,6 +361,8 @@ static size_t tap_slot(int n, int pair, int i, int which) {
 extern "C" {
 
 const char *glfer_hip_version(void) { return "glfer_hip 0.9 (gfx950; 16 points/lane Stockham radix-16 with LDS exchange, inter-pass twiddles folded into the butterflies: packed pairs, real-input and wavefront-private forms, shared odd taper, register reuse across overlapped frames, mean removal in the reference's summation order (cfg.sub_mean = 1) or inside the kernels; N = 8..1048576; periodogram, multitaper + F-test, HP-ARMA with column-disjoint Jacobi rotations side by side and frames from a queue, LMP; rows at a caller's pitch; wavefront floor, fused average, display map with the average taken inside it; chunk ring for ingest with uploads and downloads at once, WAV files and waterfalls over several GPUs, read-ahead behind the per-hop shim, kept scratch blocks with a cap, workers bound to their GPU's NUMA node)"; }
+
+int glfer_hip_abi_version(void) { return GLFER_HIP_ABI; }
 
 int glfer_hip_palette(int palette, unsigned char colortab[768]) {
   if (!colortab) return GLFER_E_ARG;
@@ -617,14 +625,28 @@ int glfer_hip_waterfall_map_device(const glfer_hip_display *d, int avg_mode, int
 }
 
 size_t glfer_hip_scratch_trim(int device, size_t keep_bytes) {
+  size_t ring = 0;
   if (keep_bytes == 0 && device >= 0 && device < 64) {       // "give everything back": the parked ingest ring too
     DeviceGuard guard(device);
-    if (guard.error() == hipSuccess) glfer::ingest_ring_drop_spare(device);
+    if (guard.error() == hipSuccess) {
+      ring = glfer::ingest_ring_spare_bytes(device);
+      glfer::ingest_ring_drop_spare(device);
+    }
   }
-  return glfer::scratch_trim(device, keep_bytes);
+  return ring + glfer::scratch_trim(device, keep_bytes);      // (what glfer_hip_scratch_held counted and is gone)
 }
-size_t glfer_hip_scratch_held(int device) { return glfer::scratch_held(device); }
-void glfer_hip_scratch_limit(size_t bytes) { glfer::scratch_set_cap(bytes); }
+size_t glfer_hip_scratch_held(int device) { return glfer::scratch_held(device) + glfer::ingest_ring_spare_bytes(device); }
+void glfer_hip_scratch_limit(size_t bytes) {
+  glfer::scratch_set_cap(bytes);
+  // a parked chunk ring larger than the new cap goes back too (it is pinned host + device memory the host did not ask to keep)
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+  for (int dev = 0; dev < 64; dev++)
+    if (glfer::ingest_ring_spare_bytes(dev) > bytes) {
+      DeviceGuard guard(dev);
+      if (guard.error() == hipSuccess) glfer::ingest_ring_drop_spare(dev);
+    }
+}
 
 const char *glfer_hip_strerror(int code) {
   switch (code) {
@@ -1401,7 +1423,11 @@ static hipError_t launch_reference_means(const glfer_hip_plan *p, const SpectroP
 // estimator launch) are the knobs tools/exact_mean_time.py sweeps.
 static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroParams &bs, size_t b0, size_t b1, hipStream_t st) {
   const long piece_mb = [] { const char *e = getenv("GLFER_EXACT_PIECE_MB"); return e && *e ? atol(e) : 0L; }();   // (read per call: the sweep sets them between calls)
-  const int nstreams_env = [] { const char *e = getenv("GLFER_EXACT_STREAMS"); return e && *e ? atoi(e) : 2; }();
+  const int nstreams_env = [] {                                                  // 1..3: the plan has two side streams (aux[2]) and the join below knows three
+    const char *e = getenv("GLFER_EXACT_STREAMS");
+    const int v = e && *e ? atoi(e) : 2;
+    return v < 1 ? 1 : (v > 3 ? 3 : v);
+  }();
   const unsigned means_blocks = [] { const char *e = getenv("GLFER_MEANS_BLOCKS"); return e && *e ? (unsigned)atol(e) : 0u; }();
   const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop);
   const size_t hop_lo = b0 - hops_back, nhops = b1 - hop_lo;                  // (b0 >= first_inside >= hops_back)
@@ -1844,6 +1870,81 @@ int glfer_hip_avg_device(int avg_mode, const float *d_psd, size_t nframes, int b
   HIP_TRY(glfer_launch_avg(avg_mode, d_psd, nframes, bins, n_out, depth, minbin, maxbin, max0 ? 1 : 0, d_avg,
                            d_ret, (hipStream_t)hip_stream));
   return GLFER_OK;
+}
+
+// fft_do + fft_psd + update_avg_* for a batch of frames in ONE call (source.c:141-158 followed by g_main.c:1153-1183).  Where the
+// periodogram's real-input kernel applies -- FFT mode, N = 512 .. 4096, no RA9MB / limiter, no mean removal, history from the
+// stream, dense rows -- and the average is the plain one over a window of at most four frames (glfer.c:295-296: the default
+// depth is 4), the average is taken INSIDE the estimator launch on the PSD values in registers (spectro16h.hip AVG): no PSD row
+// goes to memory unless d_psd asks for it.  The frames up to the first one with a full window behind it inside the stream (at
+// most ceil((N-H)/H) + depth - 1 of them) and every other configuration take the two launches (rows, then avg_fused_kernel).
+int glfer_hip_spectrogram_avg_device(glfer_hip_plan *p, const void *d_stream, size_t nsamples, size_t first, size_t nframes,
+                                     int avg_mode, int depth, int minbin, int maxbin, int max0, int n_out, float *d_psd,
+                                     double *d_avg, double *d_ret, void *hip_stream) {
+  if (!p || !d_stream || (!d_avg && nframes)) return GLFER_E_ARG;
+  if (p->cfg.mode == GLFER_MODE_HPARMA || p->pitch != p->bins) return GLFER_E_ARG;       // (HP-ARMA rows are not averaged by the reference's callers; rows dense)
+  if (avg_mode < GLFER_AVG_SUMAVG || avg_mode > GLFER_AVG_SUMEXTREME) return GLFER_E_ARG;
+  if (depth < 1 || minbin < 0 || maxbin <= minbin || maxbin > p->bins || n_out < p->bins) return GLFER_E_ARG;
+  if (nframes == 0) return GLFER_OK;
+  if ((first + nframes) > nsamples / (size_t)p->hop || nframes > 0x7fffffffu) return GLFER_E_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  DeviceGuard guard(p->cfg.device);
+  HIP_TRY(guard.error());
+  const size_t bins = (size_t)p->bins;
+  int rc = GLFER_OK;
+  // frames [from, to): the rows (to d_psd, or scratch), then update_avg over them with the state empty at `from`
+  auto two_launches = [&](size_t from, size_t to) {
+    if (rc != GLFER_OK || from >= to) return;
+    const size_t nf = to - from;
+    float *rows = d_psd ? d_psd + (from - first) * bins : nullptr;
+    double *ret = d_ret ? d_ret + (from - first) * 4 : nullptr;
+    hipError_t e = hipSuccess;
+    if (!d_psd) e = glfer::scratch_malloc((void **)&rows, nf * bins * sizeof(float), st);
+    if (e == hipSuccess && !d_ret) e = glfer::scratch_malloc((void **)&ret, nf * 4 * sizeof(double), st);
+    if (e != hipSuccess) rc = hip_fail(e, "scratch (rows to average)");
+    if (rc == GLFER_OK) rc = glfer_run_device(p, d_stream, nsamples, from, nf, rows, nullptr, st);
+    if (rc == GLFER_OK) {
+      e = glfer_launch_avg(avg_mode, rows, nf, (int)bins, n_out, depth, minbin, maxbin, max0 ? 1 : 0, d_avg + (from - first) * (size_t)n_out, ret, st);
+      if (e != hipSuccess) rc = hip_fail(e, "update_avg launch");
+    }
+    if (!d_psd && rows) glfer::scratch_free(rows, st);
+    if (!d_ret && ret) glfer::scratch_free(ret, st);
+  };
+  SpectroParams sp;
+  fill_params(p, sp);
+  sp.stream = d_stream;
+  sp.frame0 = (long long)first;
+  sp.nframes = (int)nframes;
+  static const bool fused_off = [] { const char *e = getenv("GLFER_AVG_FUSED"); return e && *e == '0'; }();   // (A/B runs and the tests that compare the two)
+  const bool fused = !fused_off && avg_mode == GLFER_AVG_PLAIN && depth <= 4 && p->cfg.mode == GLFER_MODE_FFT && !p->nonlin && !p->cfg.sub_mean &&
+                     !p->cfg.history_mode && p->n >= 512 && p->n <= 4096 && n_out <= 2 * p->n && body_route(sp, p->n) == ROUTE_REAL_INPUT;
+  // the first frame every one of whose depth-1 predecessors lies inside the stream AND inside this call's averaging state
+  const size_t first_inside = (size_t)((p->keep + p->hop - 1) / p->hop), end = first + nframes;
+  const size_t b0 = std::max(first, first_inside) + (size_t)(depth - 1);
+  if (!fused || b0 + 256 > end) {                         // (short calls: the lead frames of every slot would outweigh the rest)
+    two_launches(first, end);
+    return rc;
+  }
+  // The head's state starts empty at `first`, like the whole call's.  Its rows are also what the body's first slots would need
+  // in front of them -- they recompute them instead (frames >= b0 - (depth-1) >= first_inside are all computable).
+  two_launches(first, b0);
+  const size_t piece = (size_t)1 << 24;                     // frames per launch: keeps a workgroup's rows under the 4 GiB of a buffer descriptor
+  for (size_t f0 = b0; rc == GLFER_OK && f0 < end; f0 += piece) {
+    const size_t nf = std::min(piece, end - f0);
+    SpectroParams q = sp;
+    q.frame0 = (long long)f0;
+    q.nframes = (int)nf;
+    q.psd = d_psd ? d_psd + (f0 - first) * bins : nullptr;
+    q.avg = d_avg + (f0 - first) * (size_t)n_out;
+    q.avg_ret = d_ret ? d_ret + (f0 - first) * 4 : nullptr;
+    q.avg_depth = depth;
+    q.avg_minbin = minbin;
+    q.avg_maxbin = maxbin;
+    q.avg_nout = n_out;
+    hipError_t e = launch_real_input(q, p->n, st);
+    if (e != hipSuccess) rc = hip_fail(e, "estimator launch (average inside the kernel)");
+  }
+  return rc;
 }
 
 // the sliding sums alone (avgdata->cum after each frame, avg.c:114-127); bins outside

@@ -56,10 +56,18 @@ void ingest_ring_drop_spare(int dev) {            // with `dev` current
   IngestRing *r = ingest_ring_take(dev);
   if (r) ingest_ring_destroy(r);
 }
+size_t ingest_ring_spare_bytes(int dev) {
+  if (dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lock(g_spare_mu);
+  return g_spare_ring[dev] ? ring_bytes(g_spare_ring[dev]) : 0;
+}
 void ingest_ring_free(IngestRing *r) {          // with the ring's device current (plan_destroy, run_job)
   if (!r) return;
   int dev = -1;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !r->busy && ring_bytes(r) <= ((size_t)2 << 30)) {
+  // parked only if the host lets the library keep memory at all (GLFER_SCRATCH_CACHE, glfer_hip_scratch_limit: a parked ring is
+  // unswappable pinned memory plus device memory) and the ring is under both caps
+  if (scratch_keeping() && ring_bytes(r) <= scratch_cap() &&
+      hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !r->busy && ring_bytes(r) <= ((size_t)2 << 30)) {
     if (r->up) (void)hipStreamSynchronize(r->up);
     for (int i = 0; i < 2; i++)
       if (r->st[i]) (void)hipStreamSynchronize(r->st[i]);

@@ -50,6 +50,8 @@ void scratch_free(void *p, hipStream_t st);
 size_t scratch_trim(int dev, size_t keep_bytes);
 size_t scratch_held(int dev);
 void scratch_set_cap(size_t bytes);
+bool scratch_keeping();                        // false with GLFER_SCRATCH_CACHE=0: the library keeps nothing between calls
+size_t scratch_cap();                          // glfer_hip_scratch_limit / GLFER_SCRATCH_CAP_MB
 
 // Allow `bytes` of dynamic LDS for `kernel` on the current device (hipFuncSetAttribute, once per
 // device, kernel and size class).
@@ -71,7 +73,8 @@ struct IngestRing {
 };
 void ingest_ring_free(IngestRing *r);          // parks the ring as the device's spare, or frees it
 IngestRing *ingest_ring_take(int dev);         // the device's parked ring (the caller owns it), or null
-void ingest_ring_drop_spare(int dev);          // frees the parked ring (glfer_hip_scratch_trim)
+void ingest_ring_drop_spare(int dev);          // frees the parked ring (glfer_hip_scratch_trim, glfer_hip_scratch_limit)
+size_t ingest_ring_spare_bytes(int dev);       // pinned host + device bytes of the parked ring (counted by glfer_hip_scratch_held)
 
 }  // namespace glfer
 

@@ -19,7 +19,10 @@
 // over the frame in turn and sums the spectra: the multitaper path for N >= 8192.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "stockham16.hpp"
+#include "div_exact.hpp"
 
 // Build variant per block size, chosen so that nothing spills (tools/hbench, -Rpass-analysis):
 // window in LDS up to N = 4096 (165 VGPRs, 3 waves/SIMD, 53 KB LDS per block); re-read per frame
@@ -54,6 +57,15 @@
 #endif
 #ifndef GLFER16H_SHIFT_BUILDS
 #define GLFER16H_SHIFT_BUILDS 1    /* build the register-reuse forms for 75 % and 50 % overlap */
+#endif
+#ifndef GLFER16H_AVG_BUILDS
+#define GLFER16H_AVG_BUILDS (GLFER_LOGN_OR(12) <= 12)   /* the average taken inside the kernel (AVG = 1): N = 512 .. 4096 */
+#endif
+#ifndef GLFER16H_AVG_STORE_AUX
+#define GLFER16H_AVG_STORE_AUX 0   /* cache policy of the averaged rows' stores (2 = non-temporal) */
+#endif
+#ifndef GLFER16H_AVG_TW1R
+#define GLFER16H_AVG_TW1R 1        /* AVG forms: the lane's pass-1 twiddles in registers (0: read from LDS per transform, 32 VGPRs less) */
 #endif
 #ifndef GLFER16H_STORE_AUX
 #define GLFER16H_STORE_AUX 0   /* default cache policy at every size.  Rounds 1-2 stored rows non-temporally from N = 4096 up (+3 % then,
@@ -176,8 +188,19 @@ __device__ __forceinline__ void produce_hop_means(const SpectroParams &p, float 
 // x - mu is formed once, IN PLACE, when a hop's pairs are first used (`absorb`: integer pairs become floats
 // there) -- what fft.c:93-95 does to the caller's buffer -- and the frames that share the pair afterwards
 // read the corrected value: no second copy of the frame in registers.
-template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0, int SHIFT = 0, int MEAN = 0, int MTAB = 0>
+// AVG = 1 (round 5): update_avg_plain (avg.c:108-159) taken HERE, on the PSD values while they are in registers -- north_star's
+// "|X|^2 + block-average fused in-register".  A slot walks consecutive frames (whatever the overlap) and keeps the PSD of its
+// 17 bins for the last three frames (51 VGPRs); per frame and bin the window's sum is formed in double, oldest row first
+// (float terms in a double: exact unless a bin spans more than ~2^26 within the window -- then it is the restarted sum of
+// avg_cum_kernel, not the reference's running one, like every chunk start of the stand-alone kernels), divided by depth + 1
+// with the same correctly rounded quotient (div_exact.hpp) and stored as 8-byte words; the band mean and the peak bin
+// (update_avg_plain's return value and *peakbin) come from a reduction over the slot's lanes.  The slot recomputes the depth-1
+// frames in front of its range (recompute, do not exchange): `lead` iterations without stores.  The PSD rows
+// themselves are stored only if p.psd is given.  Two wavefronts per SIMD (the rings and the double sums do not fit 168 VGPRs).
+template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0, int SHIFT = 0, int MEAN = 0, int MTAB = 0, int AVG = 0>
 __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(SpectroParams p) {
+  static_assert(AVG == 0 || (MT == 0 && HIST == 0 && MEAN == 0 && MTAB == 0), "the average inside the kernel: the plain periodogram, history from the stream");
+  constexpr bool CONSEC = SHIFT > 0 || AVG != 0;         // every frame slot walks consecutive frames
   static_assert(MTAB == 0 || (MEAN == 1 && MT == 0), "given means: the periodogram's mean form");
   static_assert(SHIFT == 0 || (MT == 0 && HIST == 0), "register reuse: periodogram, history from the stream");
   static_assert(MEAN == 0 || ((MT == 0 || SHIFT == 0) && HIST == 0 && GLFER16_BARRIER_AFTER_READS != 0),
@@ -200,6 +223,10 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   __shared__ __attribute__((aligned(16))) v2f32 lds[L::LDS_WORDS + (VAR == 2 ? M : 0)];
   constexpr int WPF = T > 64 ? T / 64 : 1;               // wavefronts per frame
   __shared__ float mred[MEAN && !MTAB ? FPB * WPF * NH : 1];      // MEAN: the frame's wavefronts' partial sums
+  // AVG: the slot's wavefronts' band partials, by frame parity (written before a frame's barrier, read after it; the next
+  // frame writes the other set: no second barrier), and the new row's psd[minbin] (the running maximum starts there, avg.c:111)
+  __shared__ double a_sum[AVG ? 2 * FPB * WPF : 1], a_max[AVG ? 2 * FPB * WPF : 1], a_init[AVG ? 2 * FPB : 1];
+  __shared__ int a_idx[AVG ? 2 * FPB * WPF : 1];
 
   const unsigned tid = threadIdx.x;
   // the fused launch (MTAB, p.nprod > 0): the first nprod workgroups produce the hop means, the others are the launch as it was
@@ -266,7 +293,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   const v2f32 *tw1row = tw1 + (t & 15) * 17;
   // (integer samples at 75 % overlap: the registers push the three-wavefront form over its 168 and the 2-4 spilled dwords cost
   // 4-6 %: the LDS row there -- profiles/r03_h_tw1_regs.txt)
-  constexpr bool TW1R = GLFER16H_TW1_REGS != 0 && !(FMT != GLFER_FMT_F32 && SHIFT == 4 && MTAB == 0);
+  constexpr bool TW1R = GLFER16H_TW1_REGS != 0 && !(FMT != GLFER_FMT_F32 && SHIFT == 4 && MTAB == 0) && (AVG == 0 || GLFER16H_AVG_TW1R != 0);
   v2f32 tw1reg[16];
   if constexpr (TW1R) {
 #pragma unroll
@@ -290,9 +317,11 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     constexpr int FROM = decltype(fromc)::value;         // pairs FROM..15 are loaded
     constexpr int ROT = decltype(rotc)::value;
     constexpr int DEST = decltype(destc)::value;         // 0: px (rotated); 1, 2: landing set DEST - 1
-    const long long last_rel = (long long)p.nframes - 1 - start;
-    const unsigned relc = (unsigned)(rel < last_rel ? rel : last_rel);
-    const long long sblk = (p.frame0 + start) * (long long)p.H - p.R;
+    // AVG: a slot starts `lead` frames in front of its range (rel >= -lead): indices and base shifted so that they stay unsigned
+    const long long lead_l = AVG != 0 ? (long long)(p.avg_depth - 1) : 0;
+    const long long last_rel = (long long)p.nframes - 1 - start + lead_l;
+    const unsigned relc = (unsigned)(rel + lead_l < last_rel ? rel + lead_l : last_rel);
+    const long long sblk = (p.frame0 + start - lead_l) * (long long)p.H - p.R;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + sblk * (long long)esz, 0, 0x7fffffff, 0x00020000);
     const unsigned lrel = relc * (unsigned)p.H + 2u * t;
@@ -341,7 +370,8 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   };
   constexpr std::integral_constant<int, 0> kToPx{};
   // the next frame of this slot: with SHIFT its first 16-SHIFT pairs are already here
-  constexpr bool UNROLL = SHIFT == 4 || SHIFT == 8;      // 16/SHIFT copies of the frame loop's body
+  constexpr bool UNROLL = (SHIFT == 4 || SHIFT == 8) && AVG == 0;   // 16/SHIFT copies of the frame loop's body (AVG: one copy, the pairs are moved --
+                                                                    // four copies of the averaging block spill 120 VGPRs at two wavefronts per SIMD)
   auto prefetch_next = [&](long long rel, auto rotc) {
     constexpr int ROT = decltype(rotc)::value;             // the rotation of the frame in flight
     if constexpr (UNROLL) {
@@ -425,9 +455,10 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       __syncthreads();
     }
   }
-  auto rel_of = [&](long long i) { return SHIFT > 0 ? (long long)fl * per + i : i * FPB + (long long)fl; };
-  long long it = 0;                                        // frames done by every slot
-  prefetch_x(rel_of(0));
+  auto rel_of = [&](long long i) { return CONSEC ? (long long)fl * per + i : i * FPB + (long long)fl; };
+  const int lead = AVG != 0 ? p.avg_depth - 1 : 0;       // AVG: frames recomputed in front of a slot's range (never stored)
+  long long it = -(long long)lead;                         // frames done by every slot
+  prefetch_x(rel_of(it));
   if constexpr (PF2) {                                     // frame 1's new pairs: landing set 1
     load_pairs(rel_of(1), std::integral_constant<int, 16 - SHIFT>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
   }
@@ -522,6 +553,18 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   auto rho_of = [](int m) constexpr { return (m % BL) + BL * brev(m / BL, RL); };
 
   const int ntap = MT ? p.htapers : 1;
+  // AVG: the PSD of this lane's 17 bins in the last three frames (ao1 = the previous frame), and the window's divisor
+  struct NoDivisor {
+    __device__ __forceinline__ explicit NoDivisor(double) {}
+    __device__ __forceinline__ double operator()(double a) const { return a; }
+  };
+  using WindowDivisor = std::conditional_t<AVG != 0, Divisor, NoDivisor>;
+  const WindowDivisor by_depth(AVG != 0 ? (double)(p.avg_depth + 1) : 1.0);          // avg.c:138-139,155 with the window full
+  float ao1[AVG ? 17 : 1], ao2[AVG ? 17 : 1], ao3[AVG ? 17 : 1];
+  if constexpr (AVG != 0) {
+#pragma unroll
+    for (int i = 0; i < 17; i++) ao1[i] = ao2[i] = ao3[i] = 0.0f;
+  }
   auto frame_body = [&](auto rotc) -> bool {
     const bool has_next = it + 1 < per;
     float mu_next = 0.0f;
@@ -625,7 +668,9 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       // by vmcnt like the sample prefetches issued in front of them, made every frame wait for loads that were meant to have two
       // frames' time.  (The row offset stays in the VECTOR offset: the descriptor's range check, which drops the stores of frame
       // slots past the last frame, does not cover a scalar offset.)
-      unsigned urow = (unsigned)it * ROWB * (unsigned)(SHIFT > 0 ? 1 : FPB);
+      unsigned urow = (unsigned)it * ROWB * (unsigned)(CONSEC ? 1 : FPB);
+      const bool store_psd = AVG == 0 || (it >= 0 && p.psd != nullptr);     // AVG: the rows themselves only if asked, never the lead frames'
+      float pv[AVG ? 17 : 1];                                              // AVG: the frame's PSD at this lane's bins: t + T m, M - (t + T m), M/2
 #if GLFER16H_OPAQUE_ROW
       asm volatile("" : "+s"(urow));
 #endif
@@ -640,6 +685,9 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       const unsigned s16 = (unsigned)gfl & 15u;          // (uniform over the frame's wavefronts)
       float *sup = stg + (s16 + t), *sdown = stg + (s16 + (unsigned)(M - 7 * T - (int)t));   // the staged bins t and M - 7T - t
       auto put = [&](float v, unsigned voff, unsigned soff) {
+        if constexpr (AVG != 0) {
+          if (!store_psd) return;
+        }
         if constexpr (GLFER_H_ABL & 1) {               // timing ablation: arithmetic kept live, no store traffic
           if (v == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, voff, soff, GLFER16H_STORE_AUX);
         } else if constexpr (STAGE) {
@@ -698,8 +746,13 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
             put(acc[8 + m], vdown, (unsigned)(T * (7 - m)) * 4u);
           }
         } else {
-          put(__builtin_fmaf(x1r, x1r, x1i * x1i), vup, (unsigned)(T * m) * 4u);              // bin k
-          put(__builtin_fmaf(x2r, x2r, x2i * x2i), vdown, (unsigned)(T * (7 - m)) * 4u);     // bin M - k
+          const float q1 = __builtin_fmaf(x1r, x1r, x1i * x1i), q2 = __builtin_fmaf(x2r, x2r, x2i * x2i);
+          if constexpr (AVG != 0) {
+            pv[m] = q1;
+            pv[8 + m] = q2;
+          }
+          put(q1, vup, (unsigned)(T * m) * 4u);              // bin k
+          put(q2, vdown, (unsigned)(T * (7 - m)) * 4u);     // bin M - k
         }
       });
       {                                                // k = M/2 pairs with itself: X = conj(Z) (lane 0's value is the bin)
@@ -709,10 +762,117 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
           acc[16] += nyq;
           if (t == 0 && last) put(acc[16], vup, (unsigned)(M / 2) * 4u);
         } else {
+          if constexpr (AVG != 0) pv[16] = nyq;
           if (t == 0) put(nyq, vup, (unsigned)(M / 2) * 4u);
         }
       }
       if (MT == 0 || last) flush_row();
+      if constexpr (AVG != 0) {
+        // ---- update_avg_plain (avg.c:108-159) on the values just formed.  Bin of value i: see pv.  One value at a time -- sum, quotient,
+        // store, band statistics -- so that nothing but the rings lives across the block (the plain average of a bin needs no band
+        // statistic: only the return values do).  The window's sum is ((p[f-3] + p[f-2]) + p[f-1]) + p[f] in double, oldest row
+        // first, the rows outside a shorter window left out: the same additions in the same order as avg_fused_kernel's ring form
+        // (aux_kernels.hip) makes for depth <= 4, so the two give the same doubles whether or not the additions are exact.
+        const int minbin = p.avg_minbin, maxbin = p.avg_maxbin, n_out = p.avg_nout;
+        const bool out_now = it >= 0;                                                  // (the same in every lane of the workgroup)
+        const bool stats = out_now && p.avg_ret != nullptr;
+        const int par = (int)(it & 1);
+        typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+        const unsigned AROWB = (unsigned)n_out * 8u;
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.avg + (size_t)start * (size_t)n_out, 0, out_now ? (unsigned)((left > span ? span : left) * (long long)AROWB) : 0u, 0x00020000);
+        unsigned uarow = (unsigned)it * AROWB;                                         // (the iteration's part, a scalar kept out of the optimizer's sight: see urow)
+#if GLFER16H_OPAQUE_ROW
+        asm volatile("" : "+s"(uarow));
+#endif
+        const unsigned arow = (unsigned)rel_of(0) * AROWB + uarow;
+        const unsigned aup = arow + t * 8u, adown = arow + (unsigned)(M - 7 * T - (int)t) * 8u;
+        double sm = 0.0, mx = -1.0e300;
+        int mi = 0x7fffffff;
+        // (one copy of the block for every window length -- a copy per length, or the frame loop's four copies, spill ~120 VGPRs
+        // at two wavefronts per SIMD --: a ring slot beyond the window is kept at +0.0, and adding +0.0 is exact)
+        const bool d2 = p.avg_depth >= 2, d3 = p.avg_depth >= 3, d4 = p.avg_depth >= 4;
+        auto one = [&](auto ic, int b, bool mine, unsigned voff, unsigned soff) {
+          constexpr int i = decltype(ic)::value;
+          const double c = (((double)ao3[i] + (double)ao2[i]) + (double)ao1[i]) + (double)pv[i];   // avgdata->cum[index], avg.c:116-127
+          ao3[i] = d4 ? ao2[i] : 0.0f;
+          ao2[i] = d3 ? ao1[i] : 0.0f;
+          ao1[i] = d2 ? pv[i] : 0.0f;
+          const bool in = b >= minbin && b < maxbin;
+          if (out_now && mine) {
+            const double val = in ? by_depth(c) : 1e-15;                              // avg.c:150-155 (a lead frame's stores fall outside the empty descriptor)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, val), arsrc, voff, soff, GLFER16H_AVG_STORE_AUX);
+          }
+          if (stats && mine) {
+            // the band's sum and its maximum with the LOWEST bin among equals (avg.c:129-135 walks the bins upwards with a strict >):
+            // a lane takes its own bins in ascending order, so a strict > keeps the lowest
+            if (in) {
+              sm += c;
+              if (c > mx) { mx = c; mi = b; }
+            }
+            if (b == minbin) a_init[par * FPB + (int)fl] = (double)pv[i];             // the running maximum starts at psd[minbin], avg.c:111
+          }
+        };
+        static_for<0, 8>([&](auto mc) {                                               // bins t + T m, upwards
+          constexpr int m = decltype(mc)::value;
+          one(std::integral_constant<int, m>{}, (int)t + T * m, true, aup, (unsigned)(T * m) * 8u);
+        });
+        one(std::integral_constant<int, 16>{}, M / 2, t == 0, aup, (unsigned)(M / 2) * 8u);   // bin M/2 is lane 0's
+        static_for<0, 8>([&](auto mc) {                                               // bins M - (t + T m), m = 7 .. 0: upwards too
+          constexpr int m = 7 - decltype(mc)::value;
+          one(std::integral_constant<int, 8 + m>{}, M - ((int)t + T * m), true, adown, (unsigned)(T * (7 - m)) * 8u);
+        });
+        if (out_now)
+          for (int b = M + 1 + (int)t; b < n_out; b += T)                               // avgdata->avg is N wide (source.c:312): the columns past the last bin
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, 1e-15), arsrc, arow + (unsigned)b * 8u, 0, GLFER16H_AVG_STORE_AUX);
+        if (stats) {
+          if constexpr (T >= 64) {
+            wave_sum_max(sm, mx, mi);                                                  // DPP: no LDS round trips
+          } else {
+#pragma unroll
+            for (int o = 1; o < T; o <<= 1) {
+              const double os = __shfl_xor(sm, o), om = __shfl_xor(mx, o);
+              const int oi = __shfl_xor(mi, o);
+              sm += os;
+              if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+            }
+          }
+          if constexpr (WPF > 1) {
+            if ((t & 63u) == 0) {
+              const int slot = (par * FPB + (int)fl) * WPF + (int)(t >> 6);
+              a_sum[slot] = sm;
+              a_max[slot] = mx;
+              a_idx[slot] = mi;
+            }
+          }
+          frame_sync<T>();
+          if (t == 0) {
+            if constexpr (WPF > 1) {
+              const int base = (par * FPB + (int)fl) * WPF;
+              sm = a_sum[base];
+              mx = a_max[base];
+              mi = a_idx[base];
+#pragma unroll
+              for (int w = 1; w < WPF; w++) {
+                sm += a_sum[base + w];
+                if (a_max[base + w] > mx || (a_max[base + w] == mx && a_idx[base + w] < mi)) { mx = a_max[base + w]; mi = a_idx[base + w]; }
+              }
+            }
+            const long long frel = start + rel_of(it);
+            if (frel < p.nframes) {
+              const double init = a_init[par * FPB + (int)fl];
+              double top = init;
+              int peak = -1;
+              if (mx > init) { top = mx; peak = mi; }
+              double *o = p.avg_ret + (size_t)frel * 4;
+              o[0] = (sm - top) / ((double)(maxbin - minbin - 1) * (double)(p.avg_depth + 1));   // avg.c:147 (effdepth = depth: the window is full)
+              o[1] = (double)peak;
+              o[2] = 0.0;
+              o[3] = (double)p.avg_depth;
+            }
+          }
+        }
+      }
     }
     float next_part = 0.0f;
     if constexpr (MEAN != 0) {
@@ -741,10 +901,10 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     it++;
     return has_next;
   };
-  if constexpr (SHIFT == 4) {
+  if constexpr (SHIFT == 4 && UNROLL) {
     while (frame_body(std::integral_constant<int, 0>{}) && frame_body(std::integral_constant<int, 4>{}) &&
            frame_body(std::integral_constant<int, 8>{}) && frame_body(std::integral_constant<int, 12>{})) {}
-  } else if constexpr (SHIFT == 8) {
+  } else if constexpr (SHIFT == 8 && UNROLL) {
     while (frame_body(std::integral_constant<int, 0>{}) && frame_body(std::integral_constant<int, 8>{})) {}
   } else {
     while (frame_body(std::integral_constant<int, 0>{})) {}
@@ -791,6 +951,29 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
   }
 #endif
   if (p.htapers > 1) return hipErrorInvalidValue;      // the multitaper form is built for N >= 8192 only
+  if (p.avg) {
+#if GLFER16H_AVG_BUILDS
+    // update_avg_plain inside the kernel: two wavefronts per SIMD, every slot walks consecutive frames and recomputes the
+    // depth-1 frames in front of its range -- so a slot gets >= 32 frames where the launch is long enough (3 lead frames: < 10 %)
+    if (p.history_mode || p.mean_inkernel || p.avg_depth < 1 || p.avg_depth > 4 || p.avg_nout < (1 << (L - 1)) + 1) return hipErrorInvalidValue;
+    const long long per_cu2 = (2 * 256) / LC::BLOCK > 0 ? (2 * 256) / LC::BLOCK : 1;
+    static const long long mult = [] { const char *e = getenv("GLFER_AVG_GRID_MULT"); const long v = e && *e ? atol(e) : 4; return (long long)(v < 1 ? 1 : v); }();
+    const long long cap = mult * 256LL * per_cu2, want = work / 32 > 0 ? work / 32 : 1;
+    unsigned ga = (unsigned)(want < cap ? want : cap);
+    if (ga >= 64) ga &= ~7u;
+    const int k16 = (16 * p.H) % (1 << L) == 0 ? (16 * p.H) >> L : 0;
+    if (k16 == 2) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 2, 0, 0, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);
+    else if (k16 == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 4, 0, 0, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);
+    else if (k16 == 8) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 8, 0, 0, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 0, 0, 0, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);   // any other hop: every frame loaded whole
+    return hipGetLastError();
+#else
+    return hipErrorInvalidValue;
+#endif
+  }
+#ifdef GLFER16H_AVG_ONLY
+  return hipErrorInvalidValue;                         // (experiment builds, tools/build_variant.sh: only the AVG forms are compiled)
+#else
   if (p.history_mode) {
     if (p.mean_inkernel) return hipErrorInvalidValue;
     hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
@@ -856,6 +1039,7 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
 #endif
   hipLaunchKernelGGL((spectro16h_kernel<L, FMT, GLFER16H_WAVES_PER_SIMD, GLFER16H_VAR, 0, 0>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
   return hipGetLastError();
+#endif
 }
 
 // the real-input form of the single-taper path; needs p->htaps/htw/hrot (glfer_hip.cpp builds them)

@@ -60,6 +60,15 @@ struct SpectroParams {
   unsigned *means_ready;   /* device: [ceil(prod_nhops / prod_chunk)] hop groups of the chunk that are written (zeroed before the launch) */
   long long prod_hop0;     /* the hops to produce: [prod_hop0, prod_hop0 + prod_nhops) of the whole stream             */
   long long prod_nhops;
+  /* update_avg_plain (avg.c:108-159) INSIDE spectro16h.hip's periodogram kernel (round 5): avg != NULL.  A frame slot walks
+     consecutive frames and keeps the last depth-1 PSD rows of its bins in registers; the window's sum is taken in double per
+     bin and divided by depth+1 as the reference does once its window is full (avg.c:138-139,155).  EVERY frame of the launch
+     has its full window: the launcher hands over frames whose depth-1 predecessors are computable (>= the first frame
+     that lies inside the stream) and belong to the same averaging state; a slot recomputes them in front of its range. */
+  double *avg;             /* device: [nframes][avg_nout] doubles, row i = frame frame0 + i; columns outside the band 1e-15 */
+  double *avg_ret;         /* device, optional: [nframes][4] = {band mean (avg.c:147), peak bin or -1, 0, effdepth}        */
+  int avg_depth;           /* 1..4                                                                                           */
+  int avg_minbin, avg_maxbin, avg_nout;
 };
 
 #ifdef __cplusplus

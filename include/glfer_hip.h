@@ -129,6 +129,12 @@ typedef struct glfer_hip_config {
  *                        periodogram, 7e-5 multitaper, N = 4096, 50 % overlap; tests/test_gpu_round3.py).
  * Any other non-zero value is taken as GLFER_SUBMEAN_EXACT.  The per-hop shims (glfer_compat.h) take the reference's order. */
 enum { GLFER_SUBMEAN_OFF = 0, GLFER_SUBMEAN_EXACT = 1, GLFER_SUBMEAN_FAST = 2 };
+/* ABI BREAK (library 0.8 -> 0.9, round 4): the two non-zero values were swapped -- 0.8 had 1 = the in-kernel sums and 2 = the
+ * reference's order.  A caller built against the 0.8 header that passes 2 now gets GLFER_SUBMEAN_FAST.  GLFER_HIP_ABI counts such
+ * breaks; glfer_hip_abi_version() returns the number the LIBRARY was built with, so a host can refuse a mismatch at start-up:
+ *     if (glfer_hip_abi_version() != GLFER_HIP_ABI) ...                                   ("ABI version") */
+#define GLFER_HIP_ABI 5
+int glfer_hip_abi_version(void);
 
 /* Cutting a stream into launches, chunks or shards.
  * (1) Cut at frame indices that are multiples of GLFER_FRAME_ALIGN and every frame's PSD is
@@ -347,6 +353,22 @@ int glfer_hip_floor_device_pitched(const float *d_psd, size_t nframes, int bins,
 int glfer_hip_avg_device(int avg_mode, const float *d_psd, size_t nframes, int bins, int n_out,
                          int depth, int minbin, int maxbin, int max0, double *d_avg,
                          double *d_ret, void *hip_stream);
+/* Estimator AND moving average in one call: frames [first_frame, first_frame + nframes) of the stream as
+ * glfer_hip_spectrogram_device computes them, followed by update_avg_* over those rows with the averaging state empty at
+ * first_frame -- what source.c:141-158 and g_main.c:1153-1183 do per hop.  d_avg [nframes][n_out] and d_ret [nframes][4] as
+ * glfer_hip_avg_device writes them (d_ret may be NULL); d_psd [nframes][N/2+1] receives the PSD rows themselves, or NULL: they
+ * are then never stored.  n_out >= N/2+1 (the reference's avgdata is N wide, source.c:312).
+ * The plain average (GLFER_AVG_PLAIN) over a window of up to four frames (the reference's default depth, glfer.c:295-296) of
+ * a periodogram plan (FFT mode, N = 512..4096, no RA9MB / limiter / mean removal, history from the stream) is taken INSIDE the
+ * estimator launch, on the |X|^2 values while they are in registers: per frame 4 H bytes in and 8 n_out bytes out, no PSD row
+ * in memory.  Every other case runs the two launches.  d_avg is identical, double for double, to glfer_hip_avg_device over
+ * the rows (a window's sum of float bins is exact in a double unless a bin spans more than ~2^26 within the window); the band
+ * mean in d_ret [.][0] is the same sum taken over the lanes in another order (equal to ~1e-15 relative), the peak bin equal.
+ * GLFER_AVG_FUSED=0 in the environment forces the two launches (A/B runs). */
+int glfer_hip_spectrogram_avg_device(glfer_hip_plan *plan, const void *d_stream, size_t nsamples, size_t first_frame,
+                                     size_t nframes, int avg_mode, int depth, int minbin, int maxbin, int max0, int n_out,
+                                     float *d_psd, double *d_avg, double *d_ret, void *hip_stream);
+
 /* The sliding sums alone: d_cum [nframes][n_out] = avgdata->cum after each frame (avg.c:114-127);
  * columns outside [minbin, maxbin) are left untouched. */
 int glfer_hip_avg_cum_device(const float *d_psd, size_t nframes, int bins, int n_out, int depth,
@@ -477,7 +499,8 @@ int glfer_hip_waterfall_wav_multi(const glfer_hip_config *cfg, unsigned device_m
  * Besides the scratch blocks, ONE idle chunk ring of the host / file entries (two pinned sample buffers, two device buffers each
  * way; at most 2 GiB) is parked per device when its plan is destroyed and taken by the next plan that needs one -- the *_multi /
  * *_workers entries make a plan per worker and call, and allocating a ring costs 30-40 ms; glfer_hip_scratch_trim(device, 0)
- * frees it too. */
+ * frees it too.  The parked ring obeys the same switches as the blocks: nothing is parked with GLFER_SCRATCH_CACHE=0 or when the
+ * ring is larger than the cap, glfer_hip_scratch_limit() below its size frees it, glfer_hip_scratch_held() counts it. */
 size_t glfer_hip_scratch_trim(int device, size_t keep_bytes);
 size_t glfer_hip_scratch_held(int device);
 void glfer_hip_scratch_limit(size_t bytes);

@@ -61,6 +61,20 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert line["n_gpus"] == 2 and line["max_over_ranks"] == 2.0 and line["steps"] == 3 and line["warmup"] == 1
 
 
+def test_bench_gpus_8_dry_run():
+    """The launch the driver makes for the scaling curve's last point, dry: eight ranks rendezvous on 127.0.0.1, the line carries
+    every rank's own value beside the maximum, and the host-side phase runs on rank 0 alone while the other seven wait at a
+    CPU barrier (bench.py host_side_phase) -- the shape of the N > 1 line's host rows."""
+    r = _run_bench("--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run")
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["max_over_ranks"] == 8.0
+    assert line["per_rank"] == [float(i + 1) for i in range(8)]
+    assert line["host_phase"] == {"slept_s": 0.2}
+
+
 def test_bench_under_a_launcher_is_one_rank():
     """Under torch.distributed.run the environment carries WORLD_SIZE: no self-launch, and a
     --gpus that disagrees with it is refused instead of asserting half-way."""

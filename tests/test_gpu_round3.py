@@ -690,7 +690,7 @@ def test_hparma_over_many_streams(lib, oracle, torch_cuda, n, overlap, t, p_e, s
     """hparma.hip's wave_sum3: every lane must take a rotation's skip / swap decisions on the SAME bits -- a first form that let
     each quad use its own (differently associated) totals was wrong in one frame in six at t = 96 and right at t = 128 and 64.
     Eight streams per shape, |A(f)|^2/N peak-normalised against the oracle within test_hparma_parity's bound: 1e-5 at BASELINE
-    config 5's shape, max(1e-5, 1.1 x the oracle's own movement under 1-ulp input noise on that stream) elsewhere
+    config 5's shape, max(1e-5, 3 x the oracle's own sampled movement under 1-ulp input noise on that stream) elsewhere
     (tests/_spread.py; the device sits at 2e-6 median where the oracle itself moves by 1.4e-5 at t = 96)."""
     from _spread import hparma_bound
     h = oracle.hop(n, overlap)

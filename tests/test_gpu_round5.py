@@ -9,7 +9,7 @@
 import numpy as np
 import pytest
 
-from _signals import rel_err
+from _signals import rel_err, synth as synth_stream
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -100,3 +100,84 @@ def test_last_frames_of_the_bench_scale_launch(lib, oracle, torch_cuda, workload
     worst, total = _probe(lib, oracle, torch, params, x, [0, 1, 5, mid - 1, mid, frames - 65, frames - 3, frames - 2, frames - 1])
     assert total == frames
     print("%s sub_mean %d: %d frames, worst probed frame %.2e" % (workload, sub_mean, frames, worst))
+
+
+# ---- north_star: "|X|^2 + block-average fused in-register"  ------------------------------------------
+def _pcm(x, fmt, lib, oracle):
+    if fmt == "s16":
+        raw = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16)
+        return raw, oracle.pcm_s16_to_float(raw), lib.SAMPLES_S16
+    if fmt == "u8":
+        raw = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8)
+        return raw, oracle.pcm_u8_to_float(raw), lib.SAMPLES_U8
+    return x, x, lib.SAMPLES_F32
+
+
+@pytest.mark.parametrize("n,overlap,fmt,depth,band,wide", [
+    (4096, 0.75, "f32", 4, (0, 2049), False),          # the bench row (C2 + update_avg_plain, depth 4)
+    (4096, 0.75, "f32", 4, (34, 103), True),           # the reference's default band (glfer.c:278-279: 400-1200 Hz at 48 kHz), avgdata N wide
+    (4096, 0.75, "s16", 3, (1, 2048), False),
+    (1024, 0.5, "f32", 4, (0, 513), False),
+    (2048, 0.0, "u8", 2, (10, 1000), False),
+    (512, 0.875, "f32", 4, (3, 250), True),
+    (4096, 0.6, "f32", 4, (0, 2049), False),           # a hop that is no whole number of register groups: every frame loaded whole
+    (2048, 0.5, "s16", 1, (0, 1025), False),           # depth 1: the "average" of one row (divisor 2, avg.c:138-139)
+])
+def test_average_inside_the_estimator_launch(lib, oracle, torch_cuda, monkeypatch, n, overlap, fmt, depth, band, wide):
+    """glfer_hip_spectrogram_avg_device with the plain average taken inside the periodogram kernel (spectro16h.hip AVG): the
+    averaged rows must be the doubles glfer_hip_avg_device makes of the PSD rows, the PSD rows (when asked for) the bits of
+    glfer_hip_spectrogram_device, the peak bin equal and the band mean equal to 1e-12 (a sum over lanes in another order);
+    with and without the rows stored, from the start of the stream and from its middle; and against the oracle's averager."""
+    torch = torch_cuda
+    h = oracle.hop(n, overlap)
+    frames = 1700
+    x = synth_stream(frames * h, seed=n + depth)
+    raw, xf, sf = _pcm(x, fmt, lib, oracle)
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=lib.WINDOWS["hanning"], overlap=overlap, sample_format=sf))
+    d = torch.from_numpy(raw).cuda()
+    minbin, maxbin = band
+    n_out = n if wide else sp.bins
+    rows = sp.run(d)
+    want_avg, want_ret = lib.update_avg(lib.AVG_PLAIN, rows, depth, minbin, maxbin, n_out=n_out)
+    avg, ret, psd = sp.run_avg(d, lib.AVG_PLAIN, depth, minbin, maxbin, n_out=n_out, want_psd=True)
+    torch.cuda.synchronize()
+    assert torch.equal(psd, rows)
+    assert torch.equal(avg, want_avg)
+    assert torch.equal(ret[:, 1], want_ret[:, 1]) and torch.equal(ret[:, 3], want_ret[:, 3]) and torch.equal(ret[:, 2], want_ret[:, 2])
+    assert torch.allclose(ret[:, 0], want_ret[:, 0], rtol=1e-12, atol=0)
+    # rows not stored, return values not wanted: the same averages
+    avg2, none_ret, none_psd = sp.run_avg(d, lib.AVG_PLAIN, depth, minbin, maxbin, n_out=n_out, want_psd=False, want_ret=False)
+    assert none_ret is None and none_psd is None and torch.equal(avg2, want_avg)
+    # a call that starts in the middle of the stream: the averaging state is empty at ITS first frame
+    f0, nf = 37, frames - 50
+    w_avg, w_ret = lib.update_avg(lib.AVG_PLAIN, rows[f0:f0 + nf].contiguous(), depth, minbin, maxbin, n_out=n_out)
+    avg3, ret3, _ = sp.run_avg(d, lib.AVG_PLAIN, depth, minbin, maxbin, n_out=n_out, first_frame=f0, nframes=nf)
+    assert torch.equal(avg3, w_avg) and torch.equal(ret3[:, 1], w_ret[:, 1]) and torch.allclose(ret3[:, 0], w_ret[:, 0], rtol=1e-12, atol=0)
+    # the two launches (GLFER_AVG_FUSED=0 is read once per process: compare through the other modes, which always take them)
+    a_s, r_s, _ = sp.run_avg(d, lib.AVG_SUMEXTREME, depth, minbin, maxbin, n_out=n_out)
+    w_s, wr_s = lib.update_avg(lib.AVG_SUMEXTREME, rows, depth, minbin, maxbin, n_out=n_out)
+    assert torch.equal(a_s, w_s) and torch.equal(r_s, wr_s)
+    # the oracle's row-by-row averager (avg.c:108-159) over the oracle's own PSD rows' device twins
+    a = oracle.Averager(n_out, depth)
+    rows_h, avg_h, ret_h = rows.cpu().numpy(), avg.cpu().numpy(), ret.cpu().numpy()
+    for f in range(40):
+        r, want, peak, _ = a.update("plain", rows_h[f], minbin, maxbin, n=n_out)
+        assert np.array_equal(avg_h[f], want), f
+        assert ret_h[f, 1] == peak and np.isclose(ret_h[f, 0], r, rtol=1e-12), f
+    sp.close()
+
+
+def test_average_inside_the_launch_at_bench_scale(lib, torch_cuda):
+    """The bench row's own launch (C2, 262 144 frames, update_avg_plain depth 4 over the whole band): every averaged row equal to
+    the two-launch path's, first to last."""
+    import bench
+    torch = torch_cuda
+    frames = 262144
+    sp = lib.Spectrogram(bench.make_params(lib, "fft"))
+    x = bench.synth_on_device(torch, frames * sp.hop, torch.device("cuda", 0), seed=0)
+    rows = sp.run(x)
+    want_avg, want_ret = lib.update_avg(lib.AVG_PLAIN, rows, 4, 0, sp.bins)
+    avg, ret, _ = sp.run_avg(x, lib.AVG_PLAIN, 4, 0, sp.bins)
+    assert torch.equal(avg, want_avg) and torch.equal(ret[:, 1], want_ret[:, 1])
+    assert torch.allclose(ret[:, 0], want_ret[:, 0], rtol=1e-12, atol=0)
+    sp.close()

@@ -1,13 +1,15 @@
 # usage (GPU box): [GLFER_LIB_PATH=...] bash tools/mem_pass.sh <workload> <tag>
 # Vector-memory path counters (TA / TCP / UTCL1 / TCC) of one bench workload's estimator kernel, in small groups, one
 # rocprofv3 --pmc pass each (the program itself right after `--`).  Output: gpurun_out/mem_<tag>.txt
-# (A group with the TCP_UTCL1_* counters, TCP_PENDING_STALL_CYCLES and TCP_TCP_LATENCY aborted inside rocprofv3 (signal 6) and left
-# the run hanging until the box's silence limit: round 3, 17 GPU-minutes.  Cause, as far as the kept records go: all of them ARE
-# listed for gfx950 by `rocprofv3 --list-avail` (gpurun_out/counters_avail.txt:3107-3517), so "unsupported" is not it; that group
-# asked for SIX counters of the TCP block in one pass where every group below asks for at most four of one block -- more than the
-# block has counter registers, and this rocprofv3 aborts instead of splitting the request.  Not reproduced (the pass's own logs were
-# removed by this script's clean-up, and an abort that hangs a box is not worth a second try): the rule kept here is <= 4 counters
-# of one hardware block per pass, every pass under `timeout`, and the per-pass logs stay if a pass fails.)
+# (Round 3: a group made of the TCP_UTCL1_* counters, TCP_PENDING_STALL_CYCLES and TCP_TCP_LATENCY aborted inside rocprofv3 (signal 6)
+# and left the run hanging until the box's silence limit: 17 GPU-minutes.  The CAUSE IS NOT ESTABLISHED by the kept records: all of
+# those counters are listed for gfx950 by `rocprofv3 --list-avail` (gpurun_out/counters_avail.txt), so "unsupported" is not it, and a
+# per-block register limit is not it either -- groups 3 and 4 below ask for six and five TCC_* counters in one pass and run (an
+# earlier version of this comment claimed "<= 4 counters of one block per pass"; the script's own groups contradict that).  What
+# the aborting group had that no group below has is those seven counter NAMES; the pass's logs were removed by the clean-up this
+# script then had, so nothing more can be said.  What is kept: none of those counters is requested here, every pass runs under
+# `timeout -k`, the program comes directly after `--`, and a failed pass keeps its logs.  The aborting group has not been run again:
+# an abort that hangs a box costs more than those counters are worth.)
 W=$1; TAG=$2; R=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $R
 D=gpurun_out/mem_$TAG; rm -rf $D; mkdir -p $D
