@@ -1929,6 +1929,12 @@ int glfer_hip_spectrogram_avg_device(glfer_hip_plan *p, const void *d_stream, si
   // in front of them -- they recompute them instead (frames >= b0 - (depth-1) >= first_inside are all computable).
   two_launches(first, b0);
   const size_t piece = (size_t)1 << 24;                     // frames per launch: keeps a workgroup's rows under the 4 GiB of a buffer descriptor
+  // (the kernel always forms the return values -- one code path, no branch per bin: without d_ret they land in scratch)
+  double *ret_scratch = nullptr;
+  if (!d_ret) {
+    hipError_t e = glfer::scratch_malloc((void **)&ret_scratch, std::min(piece, end - b0) * 4 * sizeof(double), st);
+    if (e != hipSuccess) return hip_fail(e, "scratch (return values)");
+  }
   for (size_t f0 = b0; rc == GLFER_OK && f0 < end; f0 += piece) {
     const size_t nf = std::min(piece, end - f0);
     SpectroParams q = sp;
@@ -1936,7 +1942,7 @@ int glfer_hip_spectrogram_avg_device(glfer_hip_plan *p, const void *d_stream, si
     q.nframes = (int)nf;
     q.psd = d_psd ? d_psd + (f0 - first) * bins : nullptr;
     q.avg = d_avg + (f0 - first) * (size_t)n_out;
-    q.avg_ret = d_ret ? d_ret + (f0 - first) * 4 : nullptr;
+    q.avg_ret = d_ret ? d_ret + (f0 - first) * 4 : ret_scratch;
     q.avg_depth = depth;
     q.avg_minbin = minbin;
     q.avg_maxbin = maxbin;
@@ -1944,6 +1950,7 @@ int glfer_hip_spectrogram_avg_device(glfer_hip_plan *p, const void *d_stream, si
     hipError_t e = launch_real_input(q, p->n, st);
     if (e != hipSuccess) rc = hip_fail(e, "estimator launch (average inside the kernel)");
   }
+  if (ret_scratch) glfer::scratch_free(ret_scratch, st);
   return rc;
 }
 

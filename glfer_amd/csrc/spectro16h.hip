@@ -64,6 +64,9 @@
 #ifndef GLFER16H_AVG_STORE_AUX
 #define GLFER16H_AVG_STORE_AUX 0   /* cache policy of the averaged rows' stores (2 = non-temporal) */
 #endif
+#ifndef GLFER16H_AVG_ABL
+#define GLFER16H_AVG_ABL 0         /* timing ablations of the AVG forms (results wrong): 1 averaged rows not stored, 2 no window sum / quotient, 4 no band statistics */
+#endif
 #ifndef GLFER16H_AVG_TW1R
 #define GLFER16H_AVG_TW1R 1        /* AVG forms: the lane's pass-1 twiddles in registers (0: read from LDS per transform, 32 VGPRs less) */
 #endif
@@ -220,7 +223,10 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   // load would wait for it: no prefetch), and their power-of-two scale (wav_fmt.c:104-117) rides in
   // the window -- (x/32768)*w and x*(w/32768) are the same float
   constexpr float kSampleScale = FMT == GLFER_FMT_F32 ? 1.0f : (FMT == GLFER_FMT_S16 ? 1.0f / 32768.0f : 1.0f / 128.0f);
-  __shared__ __attribute__((aligned(16))) v2f32 lds[L::LDS_WORDS + (VAR == 2 ? M : 0)];
+#ifndef GLFER16H_LDS_PAD
+#define GLFER16H_LDS_PAD 0       /* experiment builds: extra 8-byte words of LDS per workgroup (3400 at N = 4096: two workgroups per CU instead of three) */
+#endif
+  __shared__ __attribute__((aligned(16))) v2f32 lds[L::LDS_WORDS + (VAR == 2 ? M : 0) + GLFER16H_LDS_PAD];
   constexpr int WPF = T > 64 ? T / 64 : 1;               // wavefronts per frame
   __shared__ float mred[MEAN && !MTAB ? FPB * WPF * NH : 1];      // MEAN: the frame's wavefronts' partial sums
   // AVG: the slot's wavefronts' band partials, by frame parity (written before a frame's barrier, read after it; the next
@@ -370,7 +376,13 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   };
   constexpr std::integral_constant<int, 0> kToPx{};
   // the next frame of this slot: with SHIFT its first 16-SHIFT pairs are already here
-  constexpr bool UNROLL = (SHIFT == 4 || SHIFT == 8) && AVG == 0;   // 16/SHIFT copies of the frame loop's body (AVG: one copy, the pairs are moved --
+#ifndef GLFER16H_NO_UNROLL
+#define GLFER16H_NO_UNROLL 0     /* experiment builds: 1 = no form unrolls its frame loop over the register rotations */
+#endif
+#ifndef GLFER16H_AVG_UNROLL
+#define GLFER16H_AVG_UNROLL 0    /* experiment builds: 1 = the AVG forms unroll like the others */
+#endif
+  constexpr bool UNROLL = (SHIFT == 4 || SHIFT == 8) && (AVG == 0 || GLFER16H_AVG_UNROLL != 0) && GLFER16H_NO_UNROLL == 0;   // 16/SHIFT copies of the frame loop's body (AVG: one copy, the pairs are moved --
                                                                     // four copies of the averaging block spill 120 VGPRs at two wavefronts per SIMD)
   auto prefetch_next = [&](long long rel, auto rotc) {
     constexpr int ROT = decltype(rotc)::value;             // the rotation of the frame in flight
@@ -561,9 +573,12 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   using WindowDivisor = std::conditional_t<AVG != 0, Divisor, NoDivisor>;
   const WindowDivisor by_depth(AVG != 0 ? (double)(p.avg_depth + 1) : 1.0);          // avg.c:138-139,155 with the window full
   float ao1[AVG ? 17 : 1], ao2[AVG ? 17 : 1], ao3[AVG ? 17 : 1];
+  bool holds_minbin = false;                             // AVG: one of this lane's bins is the band's first (psd[minbin] starts the running maximum)
   if constexpr (AVG != 0) {
 #pragma unroll
     for (int i = 0; i < 17; i++) ao1[i] = ao2[i] = ao3[i] = 0.0f;
+    const int mb = p.avg_minbin;
+    holds_minbin = mb < M / 2 ? (mb % T) == (int)t : (mb == M / 2 ? t == 0 : ((M - mb) % T) == (int)t);
   }
   auto frame_body = [&](auto rotc) -> bool {
     const bool has_next = it + 1 < per;
@@ -660,8 +675,11 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       // a descriptor over the workgroup's rows: rows past the launch's last frame fall outside
       // num_records and their stores are dropped
       const long long left = p.nframes - start, span = per * FPB;
+      const bool store_psd = AVG == 0 || (it >= 0 && p.psd != nullptr);     // AVG: the rows themselves only if asked, never the lead frames'
+      // (AVG: rows not asked for, and the lead frames', are dropped the same way -- an empty descriptor -- not by a branch per store:
+      // a branch in front of every put cut the mirror step into seventeen basic blocks whose LDS reads could not be issued together)
       const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-          p.psd + (size_t)start * (size_t)p.pitch, 0, (unsigned)((left > span ? span : left) * (long long)ROWB), 0x00020000);
+          p.psd + (size_t)start * (size_t)p.pitch, 0, store_psd ? (unsigned)((left > span ? span : left) * (long long)ROWB) : 0u, 0x00020000);
       // row = the slot's part + the iteration's part.  The iteration's part is kept out of the optimizer's sight (a scalar it must
       // recompute every frame): left visible, the unrolled register-reuse loops kept `lane part + r * ROWB` of each of their copies in
       // registers of their own -- six VGPRs spilled in the C2 kernel (three wavefronts per SIMD: 168), and their reloads, counted
@@ -669,7 +687,6 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       // frames' time.  (The row offset stays in the VECTOR offset: the descriptor's range check, which drops the stores of frame
       // slots past the last frame, does not cover a scalar offset.)
       unsigned urow = (unsigned)it * ROWB * (unsigned)(CONSEC ? 1 : FPB);
-      const bool store_psd = AVG == 0 || (it >= 0 && p.psd != nullptr);     // AVG: the rows themselves only if asked, never the lead frames'
       float pv[AVG ? 17 : 1];                                              // AVG: the frame's PSD at this lane's bins: t + T m, M - (t + T m), M/2
 #if GLFER16H_OPAQUE_ROW
       asm volatile("" : "+s"(urow));
@@ -685,9 +702,6 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       const unsigned s16 = (unsigned)gfl & 15u;          // (uniform over the frame's wavefronts)
       float *sup = stg + (s16 + t), *sdown = stg + (s16 + (unsigned)(M - 7 * T - (int)t));   // the staged bins t and M - 7T - t
       auto put = [&](float v, unsigned voff, unsigned soff) {
-        if constexpr (AVG != 0) {
-          if (!store_psd) return;
-        }
         if constexpr (GLFER_H_ABL & 1) {               // timing ablation: arithmetic kept live, no store traffic
           if (v == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, voff, soff, GLFER16H_STORE_AUX);
         } else if constexpr (STAGE) {
@@ -769,13 +783,16 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       if (MT == 0 || last) flush_row();
       if constexpr (AVG != 0) {
         // ---- update_avg_plain (avg.c:108-159) on the values just formed.  Bin of value i: see pv.  One value at a time -- sum, quotient,
-        // store, band statistics -- so that nothing but the rings lives across the block (the plain average of a bin needs no band
-        // statistic: only the return values do).  The window's sum is ((p[f-3] + p[f-2]) + p[f-1]) + p[f] in double, oldest row
-        // first, the rows outside a shorter window left out: the same additions in the same order as avg_fused_kernel's ring form
-        // (aux_kernels.hip) makes for depth <= 4, so the two give the same doubles whether or not the additions are exact.
+        // store, band statistics -- so that nothing but the rings lives across the block, and WITHOUT A BRANCH per value (a first
+        // form tested `frame to be stored?` / `return values wanted?` per value: seventeen basic blocks whose double-precision
+        // chains could not overlap, 330 scalar instructions a frame): a lead frame's stores fall outside its empty descriptor, lane
+        // != 0's copy of bin M/2 goes to an out-of-range offset, the band statistics are selects.
+        // The window's sum is ((p[f-3] + p[f-2]) + p[f-1]) + p[f] in double, oldest row first -- the same additions in the same order
+        // as avg_fused_kernel's ring form (aux_kernels.hip) makes for depth <= 4, so the two give the same doubles whether or not
+        // the additions are exact.  A ring slot beyond the window is kept at +0.0 (adding +0.0 is exact): one copy of the block for
+        // every window length -- a copy per length, or the frame loop's four copies, spill ~120 VGPRs at two wavefronts per SIMD.
         const int minbin = p.avg_minbin, maxbin = p.avg_maxbin, n_out = p.avg_nout;
         const bool out_now = it >= 0;                                                  // (the same in every lane of the workgroup)
-        const bool stats = out_now && p.avg_ret != nullptr;
         const int par = (int)(it & 1);
         typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
         const unsigned AROWB = (unsigned)n_out * 8u;
@@ -787,45 +804,60 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
 #endif
         const unsigned arow = (unsigned)rel_of(0) * AROWB + uarow;
         const unsigned aup = arow + t * 8u, adown = arow + (unsigned)(M - 7 * T - (int)t) * 8u;
-        double sm = 0.0, mx = -1.0e300;
-        int mi = 0x7fffffff;
-        // (one copy of the block for every window length -- a copy per length, or the frame loop's four copies, spill ~120 VGPRs
-        // at two wavefronts per SIMD --: a ring slot beyond the window is kept at +0.0, and adding +0.0 is exact)
+        const unsigned amid = t == 0 ? arow : 0x80000000u;                              // bin M/2 is lane 0's
         const bool d2 = p.avg_depth >= 2, d3 = p.avg_depth >= 3, d4 = p.avg_depth >= 4;
+        const double dv = (double)(p.avg_depth + 1), dy = by_depth.y;                  // avg.c:138-139,155: the divisor with the window full, and RN(1 / it)
+        double sm = 0.0, mx = -1.0e300;
+        float initv = 0.0f;
+        int mi = 0x7fffffff;
         auto one = [&](auto ic, int b, bool mine, unsigned voff, unsigned soff) {
           constexpr int i = decltype(ic)::value;
+#if GLFER16H_AVG_ABL & 2
+          const double c = (double)(pv[i] + ao1[i]);
+          ao1[i] = pv[i] + ao2[i];
+          const bool in = (b >= minbin) & (b < maxbin) & mine;
+          const double q = c;
+#else
           const double c = (((double)ao3[i] + (double)ao2[i]) + (double)ao1[i]) + (double)pv[i];   // avgdata->cum[index], avg.c:116-127
           ao3[i] = d4 ? ao2[i] : 0.0f;
           ao2[i] = d3 ? ao1[i] : 0.0f;
           ao1[i] = d2 ? pv[i] : 0.0f;
-          const bool in = b >= minbin && b < maxbin;
-          if (out_now && mine) {
-            const double val = in ? by_depth(c) : 1e-15;                              // avg.c:150-155 (a lead frame's stores fall outside the empty descriptor)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, val), arsrc, voff, soff, GLFER16H_AVG_STORE_AUX);
-          }
-          if (stats && mine) {
-            // the band's sum and its maximum with the LOWEST bin among equals (avg.c:129-135 walks the bins upwards with a strict >):
-            // a lane takes its own bins in ascending order, so a strict > keeps the lowest
-            if (in) {
-              sm += c;
-              if (c > mx) { mx = c; mi = b; }
-            }
-            if (b == minbin) a_init[par * FPB + (int)fl] = (double)pv[i];             // the running maximum starts at psd[minbin], avg.c:111
-          }
+          const bool in = (b >= minbin) & (b < maxbin) & mine;
+          // c / (depth + 1), correctly rounded (div_exact.hpp; the divisor is 2 .. 5: never the slow path)
+          const double q0 = c * dy;
+          const double q = __builtin_fma(__builtin_fma(-dv, q0, c), dy, q0);
+#endif
+          const double val = in ? q : 1e-15;                                          // avg.c:150-155
+#if GLFER16H_AVG_ABL & 1
+          if (val == 1.2345e-300) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, val), arsrc, voff, soff, GLFER16H_AVG_STORE_AUX);
+#else
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, val), arsrc, voff, soff, GLFER16H_AVG_STORE_AUX);
+#endif
+#if GLFER16H_AVG_ABL & 4
+          initv += (float)val;
+          return;
+#endif
+          // the band's sum and its maximum with the LOWEST bin among equals (avg.c:129-135 walks the bins upwards with a strict >):
+          // a lane takes its own bins in ascending order, so a strict > keeps the lowest
+          sm += in ? c : 0.0;
+          const bool gt = in & (c > mx);
+          mx = gt ? c : mx;
+          mi = gt ? b : mi;
+          initv = ((b == minbin) & mine) ? pv[i] : initv;                             // the running maximum starts at psd[minbin], avg.c:111
         };
         static_for<0, 8>([&](auto mc) {                                               // bins t + T m, upwards
           constexpr int m = decltype(mc)::value;
           one(std::integral_constant<int, m>{}, (int)t + T * m, true, aup, (unsigned)(T * m) * 8u);
         });
-        one(std::integral_constant<int, 16>{}, M / 2, t == 0, aup, (unsigned)(M / 2) * 8u);   // bin M/2 is lane 0's
+        one(std::integral_constant<int, 16>{}, M / 2, t == 0, amid, (unsigned)(M / 2) * 8u);
         static_for<0, 8>([&](auto mc) {                                               // bins M - (t + T m), m = 7 .. 0: upwards too
           constexpr int m = 7 - decltype(mc)::value;
           one(std::integral_constant<int, 8 + m>{}, M - ((int)t + T * m), true, adown, (unsigned)(T * (7 - m)) * 8u);
         });
-        if (out_now)
+        if (out_now) {
           for (int b = M + 1 + (int)t; b < n_out; b += T)                               // avgdata->avg is N wide (source.c:312): the columns past the last bin
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, 1e-15), arsrc, arow + (unsigned)b * 8u, 0, GLFER16H_AVG_STORE_AUX);
-        if (stats) {
+          if (holds_minbin) a_init[par * FPB + (int)fl] = (double)initv;
           if constexpr (T >= 64) {
             wave_sum_max(sm, mx, mi);                                                  // DPP: no LDS round trips
           } else {
@@ -865,7 +897,7 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
               int peak = -1;
               if (mx > init) { top = mx; peak = mi; }
               double *o = p.avg_ret + (size_t)frel * 4;
-              o[0] = (sm - top) / ((double)(maxbin - minbin - 1) * (double)(p.avg_depth + 1));   // avg.c:147 (effdepth = depth: the window is full)
+              o[0] = (sm - top) / ((double)(maxbin - minbin - 1) * dv);               // avg.c:147 (effdepth = depth: the window is full)
               o[1] = (double)peak;
               o[2] = 0.0;
               o[3] = (double)p.avg_depth;

@@ -3,6 +3,7 @@
 # Builds tools/bin/variants/<name>/libglfer_hip.so: the product library with the listed kernel
 # sources (default: spectro16w) recompiled with the extra flags.  For same-box A/B runs:
 #   GLFER_LIB_PATH=tools/bin/variants/<name>/libglfer_hip.so python3 bench.py ...
+# ONLY_LOGN=<n> in the environment: of the per-block-size sources only that size is recompiled (minutes saved per variant).
 set -e
 cd "$(dirname "$0")/../glfer_amd/csrc"
 NAME=$1; FLAGS=$2; shift 2 || true
@@ -16,8 +17,9 @@ for o in build/*.o; do
   b=$(basename $o .o); stem=${b%_n*}
   rebuilt=0
   for s in $STEMS; do
+    logn=${b##*_n}
+    if [ -n "$ONLY_LOGN" ] && [ "$logn" != "$b" ] && [ "$logn" != "$ONLY_LOGN" ]; then continue; fi   # ONLY_LOGN=12: the other block sizes keep the product's objects
     if [ "$stem" = "$s" ]; then
-      logn=${b##*_n}
       if [ "$logn" != "$b" ]; then D="-DGLFER_LOGN=$logn"; else D=""; fi
       $HIPCC $BASE $D $FLAGS -c $s.hip -o $OUT/obj/$b.o &
       OBJS="$OBJS $OUT/obj/$b.o"; rebuilt=1
