@@ -48,7 +48,8 @@ EXPORTS = [
     # round 4
     "glfer_hip_numa_node_of_bus_id", "glfer_hip_numa_node_cpus", "glfer_hip_floor_device_pitched",
     # round 5
-    "glfer_hip_abi_version", "glfer_hip_spectrogram_avg_device",
+    "glfer_hip_abi_version", "glfer_hip_spectrogram_avg_device", "glfer_hip_workers_create", "glfer_hip_workers_destroy",
+    "glfer_hip_workers_spectrogram_wav", "glfer_hip_workers_spectrogram_host",
 ]
 
 
@@ -81,6 +82,15 @@ class Display(C.Structure):
 
 SCALE_LIN, SCALE_LIN_MAX0, SCALE_LOG, SCALE_LOG_MAX0 = range(4)          # glfer.h:43
 PALETTES = {"hsv": 0, "thresh": 1, "cool": 2, "hot": 3, "bw": 4, "bone": 5, "copper": 6, "otd": 7}
+
+
+class Phases(C.Structure):
+    """glfer_hip_phases: where a call through a workers handle spent its time (seconds; the largest value over the workers)."""
+    _fields_ = [("setup_s", C.c_double), ("read_s", C.c_double), ("h2d_s", C.c_double), ("kernel_s", C.c_double),
+                ("d2h_s", C.c_double), ("wall_s", C.c_double), ("chunks", C.c_uint)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class WavInfo(C.Structure):
@@ -174,6 +184,11 @@ def lib():
         getattr(L, f).restype = C.c_char_p
     L.glfer_hip_strerror.argtypes = [C.c_int]
     L.glfer_hip_abi_version.argtypes = []
+    L.glfer_hip_workers_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), C.c_int, sz, C.POINTER(vp)]
+    L.glfer_hip_workers_destroy.argtypes = [vp]
+    L.glfer_hip_workers_destroy.restype = None
+    L.glfer_hip_workers_spectrogram_wav.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz), C.c_uint, C.POINTER(Phases)]
+    L.glfer_hip_workers_spectrogram_host.argtypes = [vp, vp, sz, vp, C.POINTER(sz), C.POINTER(Phases)]
     L.glfer_hip_spectrogram_avg_device.argtypes = [vp, vp, sz, sz, sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     _lib = L
     return L
@@ -518,6 +533,41 @@ def waterfall_workers(params, disp, devices, samples=None, path=None, avg_mode=0
                                                      C.byref(nf), WAV_PARTIAL_TAIL if partial_tail else 0),
                "glfer_hip_waterfall_wav_workers")
     return rgb[:nf.value], (lev[:nf.value] if want_lev else None)
+
+
+class Workers:
+    """glfer_hip_workers: a kept set of workers (one plan + chunk ring per entry of `devices`) for the file / host-buffer entries."""
+
+    def __init__(self, params, devices, hint_frames=0):
+        cfg = make_config(params, devices[0])
+        devs = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        self._destroy = lib().glfer_hip_workers_destroy
+        _check(lib().glfer_hip_workers_create(C.byref(cfg), devs, len(devices), hint_frames, C.byref(self._h)), "glfer_hip_workers_create")
+        self.params, self.devices = params, list(devices)
+        self.bins = params.n // 2 + 1
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._destroy(self._h)
+            self._h.value = None
+
+    __del__ = close
+
+    def run_wav(self, path, out, partial_tail=False, phases=True):
+        """rows into `out` (a numpy array [frames][bins], ideally pinned); returns (frames, phases dict or None).  phases=False: no
+        timing events are recorded (they cost a few per cent with one worker and more with several sharing a GPU)."""
+        nf, ph = C.c_size_t(0), Phases()
+        _check(lib().glfer_hip_workers_spectrogram_wav(self._h, os.fsencode(path), out.ctypes.data, out.shape[0], C.byref(nf),
+                                                       WAV_PARTIAL_TAIL if partial_tail else 0, C.byref(ph) if phases else None),
+               "glfer_hip_workers_spectrogram_wav")
+        return nf.value, (ph.as_dict() if phases else None)
+
+    def run_host(self, samples, out, phases=True):
+        nf, ph = C.c_size_t(0), Phases()
+        _check(lib().glfer_hip_workers_spectrogram_host(self._h, samples.ctypes.data, samples.size, out.ctypes.data, C.byref(nf),
+                                                        C.byref(ph) if phases else None), "glfer_hip_workers_spectrogram_host")
+        return nf.value, (ph.as_dict() if phases else None)
 
 
 class PinnedArray:

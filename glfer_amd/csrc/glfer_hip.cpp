@@ -629,15 +629,18 @@ size_t glfer_hip_scratch_trim(int device, size_t keep_bytes) {
   if (keep_bytes == 0 && device >= 0 && device < 64) {       // "give everything back": the parked ingest ring too
     DeviceGuard guard(device);
     if (guard.error() == hipSuccess) {
-      ring = glfer::ingest_ring_spare_bytes(device);
+      ring = glfer::workers_kept_bytes(device);
+      glfer::workers_drop_kept();                              // (their plans park one ring per device on the way out: dropped next)
+      ring += glfer::ingest_ring_spare_bytes(device);
       glfer::ingest_ring_drop_spare(device);
     }
   }
   return ring + glfer::scratch_trim(device, keep_bytes);      // (what glfer_hip_scratch_held counted and is gone)
 }
-size_t glfer_hip_scratch_held(int device) { return glfer::scratch_held(device) + glfer::ingest_ring_spare_bytes(device); }
+size_t glfer_hip_scratch_held(int device) { return glfer::scratch_held(device) + glfer::ingest_ring_spare_bytes(device) + glfer::workers_kept_bytes(device); }
 void glfer_hip_scratch_limit(size_t bytes) {
   glfer::scratch_set_cap(bytes);
+  if (bytes == 0) glfer::workers_drop_kept();
   // a parked chunk ring larger than the new cap goes back too (it is pinned host + device memory the host did not ask to keep)
   int cur = -1;
   if (hipGetDevice(&cur) != hipSuccess) cur = -1;
@@ -1048,6 +1051,7 @@ void glfer_hip_plan_destroy(glfer_hip_plan *p) {
   if (p->d_taps) (void)hipFree(p->d_taps);
   if (p->d_window) (void)hipFree(p->d_window);
   if (p->d_ftaps_mu_first) (void)hipFree(p->d_ftaps_mu_first);
+  if (p->d_ftaps2) (void)hipFree(p->d_ftaps2);
   if (p->d_U0) (void)hipFree(p->d_U0);
   if (p->d_tw) (void)hipFree(p->d_tw);
   if (p->d_htaps) (void)hipFree(p->d_htaps);
@@ -1754,6 +1758,31 @@ int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t n
     p->d_ftaps_mu_first = d;
     p->d_ftaps = d + (size_t)2 * n;
     p->d_U0 = du;
+    // the paired form's tables: two real sequences per N-point transform (re / im), each halved (X_a = (Z[k] + conj Z[N-k]) / 2)
+    const int r_mu = (T + 2) / 2, r_nomu = (T + 1) / 2;
+    std::vector<float> pt((size_t)(r_mu + r_nomu) * 2 * n, 0.0f);
+    auto seq = [&](int s_, int i, bool with_mu) -> float {          // sequence s_ of the call: hn first when mu is live, then the tapers
+      const int j = with_mu ? s_ - 1 : s_;
+      if (j >= T) return 0.0f;
+      return 0.5f * (j < 0 ? p->hn[i] : (float)p->tapers[(size_t)j * n + i]);
+    };
+    for (int r = 0; r < r_mu + r_nomu; r++) {
+      const bool with_mu = r < r_mu;
+      const int rr = with_mu ? r : r - r_mu;
+      for (int i = 0; i < n; i++) {
+        pt[(size_t)r * 2 * n + tap_slot(n, 0, i, 0)] = seq(2 * rr, i, with_mu);
+        pt[(size_t)r * 2 * n + tap_slot(n, 0, i, 1)] = seq(2 * rr + 1, i, with_mu);
+      }
+    }
+    float *d2 = nullptr;
+    hipError_t e2 = hipMalloc((void **)&d2, pt.size() * sizeof(float));
+    if (e2 == hipSuccess) e2 = hipMemcpy(d2, pt.data(), pt.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e2 != hipSuccess) {
+      (void)hipFree(d2);
+      return hip_fail(e2, "ftest tables (paired)");
+    }
+    p->d_ftaps2 = d2;
+    p->d_ftaps2_nomu = d2 + (size_t)r_mu * 2 * n;
   }
   SpectroParams sp;
   fill_params(p, sp);
@@ -1784,6 +1813,15 @@ int glfer_hip_mtm_ftest_device(glfer_hip_plan *p, const void *d_stream, size_t n
     q.ft_mu_live = mu_live ? 1 : 0;
     q.npairs = mu_live ? T + 1 : T;                    // rounds: hn first (mu), then the tapers
     q.taps = mu_live ? p->d_ftaps_mu_first : p->d_ftaps;
+    // round 5: two sequences per transform, separated through the mirror bins (GLFER_FTEST_PAIRED=0: one per transform, for A/B runs and tests)
+    // Measured (gpurun_out/r5/ftest_rate.txt): N = 4096, 5 tapers 39.2 against 33.5 M frames/s; N = 1024, 8 tapers 94.3 against 105.9 -- the
+    // mirror exchange (two barriers, 16 LDS writes, 9 reads a round) costs a short transform more than it saves: paired from N = 2048.
+    const char *pe = getenv("GLFER_FTEST_PAIRED");
+    if (pe && *pe ? *pe != '0' : n >= 2048) {
+      q.ft_nseq = mu_live ? T + 1 : T;
+      q.npairs = (q.ft_nseq + 1) / 2;
+      q.taps = mu_live ? p->d_ftaps2 : p->d_ftaps2_nomu;
+    }
     hipError_t e = launch_packed(q, n, st);
     if (e != hipSuccess) rc = hip_fail(e, "ftest launch");
     if (scratch) glfer::scratch_free(scratch, st);

@@ -18,6 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <chrono>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -88,6 +91,8 @@ static void ingest_ring_destroy(IngestRing *r) {
   for (int i = 0; i < 2; i++) {
     if (r->st[i]) (void)hipStreamSynchronize(r->st[i]);
     if (r->ev_up[i]) (void)hipEventDestroy(r->ev_up[i]);
+    for (hipEvent_t ev : r->ev_t[i])
+      if (ev) (void)hipEventDestroy(ev);
     if (r->h_in[i]) (void)hipHostFree(r->h_in[i]);
     if (r->h_out[i]) (void)hipHostFree(r->h_out[i]);
     if (r->h_lev[i]) (void)hipHostFree(r->h_lev[i]);
@@ -147,6 +152,96 @@ size_t sample_bytes(int fmt) { return fmt == GLFER_SAMPLES_F32 ? 4 : (fmt == GLF
 
 // memcpy spread over a few threads: the destination is usually fresh pageable memory, where the
 // page faults, not the copy, set the pace
+// A worker's own reader threads, kept by its glfer_hip_workers handle (round 5).  read_wide used to start its threads per chunk: sixteen
+// chunks x up to sixteen threads a call, each with a fresh stack on a process's first call -- 31 ms of a 1-hour WAV's first call
+// against 10 ms afterwards.  The threads are made by the worker's own thread while it is bound to its GPU's NUMA node, so they read
+// into the pinned ring from that node's cores.
+class ReaderPool {
+ public:
+  explicit ReaderPool(unsigned n) {
+    for (unsigned i = 0; i < n; i++) {
+      try {
+        th_.emplace_back([this] { loop(); });
+      } catch (...) {
+        break;
+      }
+    }
+  }
+  ~ReaderPool() {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  unsigned size() const { return (unsigned)th_.size(); }
+  // fn(i) for i in [0, count): on the pool's threads and on the caller; returns when every piece is done
+  void run(unsigned count, const std::function<void(unsigned)> &fn) {
+    if (count == 0) return;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      fn_ = &fn;
+      count_ = count;
+      next_.store(0, std::memory_order_relaxed);
+      left_.store(count, std::memory_order_relaxed);
+      gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lock(mu_);
+    done_.wait(lock, [this] { return left_.load(std::memory_order_acquire) == 0 && busy_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const unsigned i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= count_) return;
+      (*fn_)(i);
+      left_.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lock(mu_);
+    for (;;) {
+      cv_.wait(lock, [&] { return stop_ || gen_ != seen; });
+      if (stop_) return;
+      seen = gen_;
+      busy_++;
+      lock.unlock();
+      work();
+      lock.lock();
+      busy_--;
+      if (left_.load(std::memory_order_acquire) == 0 && busy_ == 0) done_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(unsigned)> *fn_ = nullptr;
+  unsigned count_ = 0, busy_ = 0;
+  unsigned long long gen_ = 0;
+  std::atomic<unsigned> next_{0}, left_{0};
+  bool stop_ = false;
+};
+static thread_local ReaderPool *tl_reader_pool = nullptr;      // the calling worker's pool, if its handle has one
+
+void copy_wide(void *dst, const void *src, size_t bytes);
+void copy_wide_pooled(void *dst, const void *src, size_t bytes) {
+  ReaderPool *pool = tl_reader_pool;
+  const size_t kMin = (size_t)2 << 20;
+  const size_t want = pool ? std::max<size_t>(1, std::min<size_t>(pool->size() + 1, bytes / kMin)) : 1;
+  if (want <= 1) { copy_wide(dst, src, bytes); return; }
+  const size_t per = (((bytes + want - 1) / want) + 4095) & ~(size_t)4095;
+  const unsigned pieces = (unsigned)((bytes + per - 1) / per);
+  pool->run(pieces, [&](unsigned i) {
+    const size_t off = (size_t)i * per, len = std::min(per, bytes - off);
+    memcpy((char *)dst + off, (const char *)src + off, len);
+  });
+}
 void copy_wide(void *dst, const void *src, size_t bytes) {
   const size_t kMin = (size_t)8 << 20;
   unsigned nt = bytes < 2 * kMin ? 1u : (unsigned)std::min<size_t>(8, bytes / kMin);
@@ -170,6 +265,10 @@ void copy_wide(void *dst, const void *src, size_t bytes) {
 
 // pread spread over a few threads (round 4): a file in the page cache is read at memcpy speed per thread, and BASELINE config 4
 // as worded (a 1-hour WAV, 346 MB) was bound by ONE thread doing that -- 0.11 s of wall time around 1.2 ms of kernels
+// Threads one reader may use at once (set by the *_workers entries: the host's cores are shared by the workers).
+static std::atomic<unsigned> g_read_threads{8};
+
+
 bool read_wide(int fd, void *dst, size_t offset, size_t bytes) {
   auto read_all = [fd](char *d, size_t off, size_t n) {
     while (n) {
@@ -181,8 +280,26 @@ bool read_wide(int fd, void *dst, size_t offset, size_t bytes) {
     }
     return true;
   };
-  const size_t kMin = (size_t)8 << 20;
-  unsigned nt = bytes < 2 * kMin ? 1u : (unsigned)std::min<size_t>(8, bytes / kMin);
+  // (round 5: pieces of 2 MiB and up, as many threads as the caller's share of the cores -- a chunk of a few tens of MB read by
+  // ONE to five threads at ~8 GB/s each was what a 1-hour WAV's 346 MB waited for: 19.7 ms wall around 1.2 ms of kernels)
+  const size_t kMin = (size_t)2 << 20;
+  if (ReaderPool *pool = tl_reader_pool) {                       // the worker's kept threads: no thread is made here
+    const size_t want = std::max<size_t>(1, std::min<size_t>(pool->size() + 1, bytes / kMin));
+    if (want > 1) {
+      const size_t per = (((bytes + want - 1) / want) + 4095) & ~(size_t)4095;
+      const unsigned pieces = (unsigned)((bytes + per - 1) / per);
+      std::vector<char> ok(pieces, 1);
+      pool->run(pieces, [&](unsigned i) {
+        const size_t off = (size_t)i * per, len = std::min(per, bytes - off);
+        ok[i] = read_all((char *)dst + off, offset + off, len) ? 1 : 0;
+      });
+      for (char c : ok)
+        if (!c) return false;
+      return true;
+    }
+    return read_all((char *)dst, offset, bytes);
+  }
+  unsigned nt = bytes < 2 * kMin ? 1u : (unsigned)std::min<size_t>(g_read_threads.load(std::memory_order_relaxed), bytes / kMin);
   const unsigned hw = std::thread::hardware_concurrency();
   if (hw && nt > hw) nt = hw;
   if (nt <= 1) return read_all((char *)dst, offset, bytes);
@@ -241,7 +358,33 @@ struct Job {
   const unsigned char *pinned_src = nullptr;   // the whole stream in pinned host memory (hop 0 at this address): uploaded
                                                // from where it lies, no staging copy
   Sink sink;                             // rows of frame f go to index f - frame_lo
+  glfer_hip_phases *phases = nullptr;    // optional: where this job's time went (glfer_hip_workers_*)
 };
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Frames per chunk of a job of `frames` frames: the default is 16384 frames and at most 256 MiB of samples (tools/chunk_probe.py: long
+// streams run at the link's rate there); a SHORT job -- a worker's share of a 1-hour WAV is 1 300 frames of 32 KB -- is cut into at
+// least sixteen chunks of at least ~2 MiB, so that reading chunk c + 1, uploading it, and bringing chunk c - 1's rows home overlap
+// instead of happening once each, one after the other.
+size_t pick_chunk(const glfer_hip_plan *p, size_t frames, size_t asked) {
+  const size_t esz = sample_bytes(p->cfg.sample_format), hop = (size_t)p->hop;
+  size_t chunk = asked;
+  if (chunk == 0) {
+    chunk = 16384;
+    if (const char *ev = getenv("GLFER_INGEST_CHUNK")) {       // (tools/chunk_probe.py)
+      const long v = atol(ev);
+      if (v > 0) chunk = (size_t)v;
+    } else {
+      const size_t part = (frames + 15) / 16, floor_frames = std::max<size_t>(1, ((size_t)2 << 20) / (hop * esz));
+      if (part < chunk) chunk = std::max(part, floor_frames);
+    }
+    const size_t cap = ((size_t)256 << 20) / (hop * esz);
+    if (chunk > cap) chunk = cap;
+  }
+  if (chunk < 1) chunk = 1;
+  return (chunk + GLFER_FRAME_ALIGN - 1) / GLFER_FRAME_ALIGN * GLFER_FRAME_ALIGN;   // see launch_by_n
+}
 
 int run_job(const Job &job, size_t *frames_done) {
   glfer_hip_plan *p = job.p;
@@ -255,18 +398,8 @@ int run_job(const Job &job, size_t *frames_done) {
   // complete hops), plus the frames the LMP ring reaches back
   const size_t halo_hops = (size_t)((p->keep + p->hop - 1) / p->hop) +
                            (p->cfg.mode == GLFER_MODE_LMP ? (size_t)p->lmp_av - 1 : 0);
-  size_t chunk = job.chunk_frames;
-  if (chunk == 0) {                                            // default: 16384 frames, at most 256 MiB of samples
-    chunk = 16384;
-    if (const char *ev = getenv("GLFER_INGEST_CHUNK")) {       // (tools/chunk_probe.py)
-      const long v = atol(ev);
-      if (v > 0) chunk = (size_t)v;
-    }
-    const size_t cap = ((size_t)256 << 20) / (hop * esz);
-    if (chunk > cap) chunk = cap;
-  }
-  if (chunk < 1) chunk = 1;
-  chunk = (chunk + GLFER_FRAME_ALIGN - 1) / GLFER_FRAME_ALIGN * GLFER_FRAME_ALIGN;   // see launch_by_n
+  const double t_job = now_s();
+  const size_t chunk = pick_chunk(p, job.frames, job.chunk_frames);
   // chunk boundaries sit on GLOBAL multiples of GLFER_FRAME_ALIGN: the first chunk of a job that
   // starts off the grid is shortened to reach it
   const bool waterfall = job.sink.disp != nullptr;
@@ -339,7 +472,14 @@ int run_job(const Job &job, size_t *frames_done) {
     }
   }
   near_gpu.reset();                                // (the thread's own mask back before any work)
+  const bool timed = job.phases != nullptr;
+  for (int b = 0; b < 2 && timed && e == hipSuccess; b++)
+    for (int k = 0; k < 4 && e == hipSuccess; k++)
+      if (!R.ev_t[b][k]) e = hipEventCreate(&R.ev_t[b][k]);
   int rc = (e == hipSuccess) ? GLFER_OK : hip_fail(e, "ingest: allocate");
+  double ph_read = 0.0, ph_h2d = 0.0, ph_kernel = 0.0, ph_d2h = 0.0;
+  unsigned ph_chunks = 0;
+  const double t_loop = now_s();
 
   struct Pending { size_t first = 0, nf = 0; bool live = false; } pend[2];
   // hands chunk b's rows to the caller (after its stream has drained)
@@ -348,6 +488,14 @@ int run_job(const Job &job, size_t *frames_done) {
     hipError_t err = hipStreamSynchronize(st[b]);
     pend[b].live = false;
     if (err != hipSuccess) return hip_fail(err, "ingest: chunk");
+    if (timed) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, R.ev_t[b][0], R.ev_t[b][1]) == hipSuccess) ph_h2d += ms * 1e-3;
+      if (hipEventElapsedTime(&ms, R.ev_t[b][1], R.ev_t[b][2]) == hipSuccess) ph_kernel += ms * 1e-3;   // (from the upload's end: includes any wait for the stream's previous chunk)
+      if (hipEventElapsedTime(&ms, R.ev_t[b][2], R.ev_t[b][3]) == hipSuccess) ph_d2h += ms * 1e-3;
+      (void)hipGetLastError();
+      ph_chunks++;
+    }
     if (!direct_out && !dev_sink) {
       const size_t off = pend[b].first - job.frame_lo, nf = pend[b].nf;
       if (waterfall) {
@@ -370,12 +518,22 @@ int run_job(const Job &job, size_t *frames_done) {
     size_t nf = std::min(chunk - cf % chunk, frame_hi - cf);
     if (job.tail_fresh >= 0 && cf + nf + 1 == frame_hi) nf++;       // never leave the partial block alone in a chunk
     const size_t lo_hop = cf > halo_hops ? cf - halo_hops : 0;       // first hop the chunk's buffer holds
-    rc = drain(b);                                 // buffer set b is free once chunk c-2 is out
-    if (rc) break;
+    // Buffer set b: its pinned SAMPLE buffer is free as soon as chunk c-2's upload is done (round 5: the loop used to wait here for
+    // the whole of chunk c-2 -- kernels and download too -- before it read chunk c, so reading and the link took turns: a 1-hour WAV
+    // ran 13.4 ms with 8 ms of reading and 7 ms of copies each way); everything else of the set is ordered on its stream, and the
+    // chunk's rows are handed over (drain) after the read, just before the set's next work is queued.
+    if (pend[b].live && !job.pinned_src) {
+      e = hipEventSynchronize(R.ev_up[b]);
+      if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
+    }
     if (job.pinned_src) {
+      rc = drain(b);
+      if (rc) break;
       // the caller's stream is pinned: history, hops and all go up from where they lie
       const size_t up = cf - lo_hop + nf;
+      if (timed) (void)hipEventRecord(R.ev_t[b][0], R.up);
       e = hipMemcpyAsync(d_in[b], job.pinned_src + lo_hop * hop * esz, up * hop * esz, hipMemcpyHostToDevice, R.up);
+      if (timed) (void)hipEventRecord(R.ev_t[b][1], R.up);
       if (e == hipSuccess) e = hipEventRecord(R.ev_up[b], R.up);
       if (e == hipSuccess) e = hipStreamWaitEvent(st[b], R.ev_up[b], 0);
       if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
@@ -383,6 +541,7 @@ int run_job(const Job &job, size_t *frames_done) {
     // history: from the previous chunk's pinned buffer where it has it, else from the reader
     size_t have = 0;                               // hops of [lo_hop, cf) copied so far
     const int pb = b ^ 1;
+    const double t_read = now_s();
     if (job.pinned_src) {
       have = cf - lo_hop;
     } else if (prev_hops && lo_hop >= prev_lo_hop && lo_hop < prev_lo_hop + prev_hops) {
@@ -398,11 +557,18 @@ int run_job(const Job &job, size_t *frames_done) {
       const size_t got = job.read(h_in[b] + (cf - lo_hop) * hop * esz, cf, nf);
       if (got < nf) { nf = got; ended = true; }
     }
+    ph_read += now_s() - t_read;
+    if (!job.pinned_src) {
+      rc = drain(b);                               // chunk c-2's rows are home (usually long since): the set's device buffers and its pinned row buffer are free
+      if (rc) break;
+    }
     if (nf == 0) break;
     const bool has_tail = job.tail_fresh >= 0 && cf + nf == frame_hi;
     const size_t up_hops = cf - lo_hop + nf;
     if (!job.pinned_src) {
+      if (timed) (void)hipEventRecord(R.ev_t[b][0], R.up);
       e = hipMemcpyAsync(d_in[b], h_in[b], up_hops * hop * esz, hipMemcpyHostToDevice, R.up);
+      if (timed) (void)hipEventRecord(R.ev_t[b][1], R.up);
       if (e == hipSuccess) e = hipEventRecord(R.ev_up[b], R.up);
       if (e == hipSuccess) e = hipStreamWaitEvent(st[b], R.ev_up[b], 0);
       if (e != hipSuccess) { rc = hip_fail(e, "ingest: upload"); break; }
@@ -411,6 +577,7 @@ int run_job(const Job &job, size_t *frames_done) {
     float *rows = dev_sink ? job.sink.d_rows + (cf - job.frame_lo) * bins : d_psd[b];
     rc = glfer_run_device(p, vbase, (cf + nf) * hop, cf, nf, rows, nullptr, st[b], has_tail ? job.tail_fresh : -1);
     if (rc) break;
+    if (timed) (void)hipEventRecord(R.ev_t[b][2], st[b]);
     if (dev_sink) {
       if (job.sink.d_stats) rc = glfer_hip_floor_device(rows, nf, (int)bins, job.sink.d_stats + (cf - job.frame_lo) * 4, st[b]);
       if (rc) break;
@@ -433,6 +600,7 @@ int run_job(const Job &job, size_t *frames_done) {
       e = hipMemcpyAsync(dst, d_psd[b], nf * bins * sizeof(float), hipMemcpyDeviceToHost, st[b]);
     }
     if (e != hipSuccess) { rc = hip_fail(e, "ingest: download"); break; }
+    if (timed) (void)hipEventRecord(R.ev_t[b][3], st[b]);
     pend[b].first = cf;
     pend[b].nf = nf;
     pend[b].live = true;
@@ -453,13 +621,69 @@ int run_job(const Job &job, size_t *frames_done) {
     std::lock_guard<std::mutex> lock(g_ring_mu);
     ring->busy = false;
   }
+  if (timed) {
+    glfer_hip_phases &ph = *job.phases;
+    ph.setup_s += t_loop - t_job;
+    ph.read_s += ph_read;
+    ph.h2d_s += ph_h2d;
+    ph.kernel_s += ph_kernel;
+    ph.d2h_s += ph_d2h;
+    ph.wall_s += now_s() - t_job;
+    ph.chunks += ph_chunks;
+  }
   return rc;
+}
+
+// The plan's ring sized in advance for PSD jobs in chunks of `chunk` frames whose rows go home by DMA (glfer_hip_workers_create: a
+// handle's first call must not spend 30-40 ms per worker allocating pinned and device buffers).  The same buffers run_job would make.
+int reserve_psd_ring(glfer_hip_plan *p, size_t chunk) {
+  DeviceGuard guard(p->cfg.device);
+  HIP_TRY(guard.error());
+  const size_t esz = sample_bytes(p->cfg.sample_format), hop = (size_t)p->hop, bins = (size_t)p->bins;
+  const size_t halo_hops = (size_t)((p->keep + p->hop - 1) / p->hop) + (p->cfg.mode == GLFER_MODE_LMP ? (size_t)p->lmp_av - 1 : 0);
+  const size_t in_bytes = (halo_hops + chunk + 1) * hop * esz, rows_cap = chunk + 1;
+  std::lock_guard<std::mutex> lock(g_ring_mu);
+  if (!p->ring) p->ring = glfer::ingest_ring_take(p->cfg.device);
+  if (!p->ring) p->ring = new glfer::IngestRing();
+  glfer::IngestRing &R = *p->ring;
+  if (R.busy) return GLFER_OK;
+  NodeBinding near_gpu(p->cfg.device);
+  hipError_t e = hipSuccess;
+  auto ensure = [&](void **ptr, size_t *cap, size_t bytes, int kind) {
+    if (e != hipSuccess || (*ptr && *cap >= bytes)) return;
+    if (*ptr) (void)(kind == 0 ? hipHostFree(*ptr) : hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    e = kind == 0 ? hipHostMalloc(ptr, bytes, hipHostMallocDefault) : hipMalloc(ptr, bytes);
+    if (e == hipSuccess) *cap = bytes;
+  };
+  if (!R.up) e = hipStreamCreateWithFlags(&R.up, hipStreamNonBlocking);
+  for (int b = 0; b < 2 && e == hipSuccess; b++) {
+    if (!R.ev_up[b]) e = hipEventCreateWithFlags(&R.ev_up[b], hipEventDisableTiming);
+    if (e == hipSuccess && !R.st[b]) e = hipStreamCreateWithFlags(&R.st[b], hipStreamNonBlocking);
+    for (int k = 0; k < 4 && e == hipSuccess; k++)
+      if (!R.ev_t[b][k]) e = hipEventCreate(&R.ev_t[b][k]);
+    const bool fresh = !R.h_in[b] || R.cap[b][0] < in_bytes;
+    ensure((void **)&R.h_in[b], &R.cap[b][0], in_bytes, 0);
+    ensure((void **)&R.d_in[b], &R.cap[b][1], in_bytes, 1);
+    ensure((void **)&R.d_psd[b], &R.cap[b][2], rows_cap * bins * sizeof(float), 1);
+    // the pinned buffer's pages are mapped for the CPU on first touch: touched here, not by the first call's reader; and one copy each
+    // way through the set's streams (the copy engines' first transfers after an idle spell run at a fraction of their rate)
+    if (e == hipSuccess && fresh) {
+      memset(R.h_in[b], 0, in_bytes);
+      e = hipMemcpyAsync(R.d_in[b], R.h_in[b], in_bytes, hipMemcpyHostToDevice, R.up);
+      if (e == hipSuccess) e = hipStreamSynchronize(R.up);
+      if (e == hipSuccess) e = hipMemcpyAsync(R.h_in[b], R.d_in[b], in_bytes, hipMemcpyDeviceToHost, R.st[b]);
+      if (e == hipSuccess) e = hipStreamSynchronize(R.st[b]);
+    }
+  }
+  return e == hipSuccess ? GLFER_OK : hip_fail(e, "workers: reserve ring");
 }
 
 // reader over a host array of whole hops
 std::function<size_t(unsigned char *, size_t, size_t)> array_reader(const void *h_stream, size_t hop_bytes) {
   return [=](unsigned char *dst, size_t hop_index, size_t nhops) {
-    copy_wide(dst, (const unsigned char *)h_stream + hop_index * hop_bytes, nhops * hop_bytes);
+    copy_wide_pooled(dst, (const unsigned char *)h_stream + hop_index * hop_bytes, nhops * hop_bytes);
     return nhops;
   };
 }
@@ -749,17 +973,34 @@ int on_workers(unsigned world, const std::function<int(unsigned)> &work, const i
 // One worker (host thread + plan + two streams + pinned ring) per entry of devices[]; an ordinal may
 // appear more than once -- several workers then share that GPU, which is how a one-GPU box exercises
 // the whole multi-worker path (frame offsets, halos from the middle of the stream, disjoint rows).
-int psd_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, const Source &src, float *h_psd) {
+// plans (may be null): worker r's plan, kept by a glfer_hip_workers handle -- its tables and its ring are there already; without, a plan
+// per worker is made and destroyed inside the call (its ring parks with the device if the slot is free).
+// phases (may be null): per field the LARGEST value over the workers (they run side by side), the chunks summed.
+int psd_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, const Source &src, float *h_psd,
+                glfer_hip_plan *const *plans = nullptr, glfer_hip_phases *phases = nullptr,
+                const std::vector<std::unique_ptr<ReaderPool>> *pools = nullptr) {
   const unsigned world = (unsigned)nworkers;
   const size_t frames = src.frames, bins = (size_t)cfg->n / 2 + 1;
-  return on_workers(world, [&](unsigned r) -> int {
+  // the host's cores are shared by the workers' readers (a 1-GPU box hands a job 16)
+  unsigned avail = std::thread::hardware_concurrency();
+  {
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) avail = (unsigned)CPU_COUNT(&set);
+  }
+  g_read_threads.store(std::max(1u, std::min(16u, (avail ? avail : 8u) / world)), std::memory_order_relaxed);
+  std::vector<glfer_hip_phases> per(phases ? world : 0);
+  const double t0 = now_s();
+  int rc_all = on_workers(world, [&](unsigned r) -> int {
     size_t first = 0, count = 0;
     frame_range(frames, r, world, &first, &count);
     if (count == 0) return GLFER_OK;
-    glfer_hip_config c = *cfg;
-    c.device = devices[r];
-    glfer_hip_plan *plan = nullptr;
-    int rc = glfer_hip_plan_create(&c, &plan);
+    glfer_hip_plan *plan = plans ? plans[r] : nullptr;
+    int rc = GLFER_OK;
+    if (!plan) {
+      glfer_hip_config c = *cfg;
+      c.device = devices[r];
+      rc = glfer_hip_plan_create(&c, &plan);
+    }
     if (rc == GLFER_OK) {
       Job job;
       job.p = plan;
@@ -769,15 +1010,34 @@ int psd_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, c
       job.read = src.open();
       job.pinned_src = src.pinned_src;
       job.sink.h_psd = h_psd + first * bins;
+      if (phases) {
+        memset(&per[r], 0, sizeof per[r]);
+        job.phases = &per[r];
+      }
       size_t done = 0;
+      tl_reader_pool = pools && r < pools->size() ? (*pools)[r].get() : nullptr;     // this worker's kept reader threads
       rc = job.read ? run_job(job, &done) : GLFER_E_ARG;
+      tl_reader_pool = nullptr;
       if (rc == GLFER_OK && done != count) rc = GLFER_E_HIP;
     }
     std::string msg = rc ? glfer::error_text() : std::string();
-    glfer_hip_plan_destroy(plan);
+    if (!plans) glfer_hip_plan_destroy(plan);
     if (rc) glfer::set_error_text(msg);
     return rc;
   }, devices);
+  if (phases) {
+    memset(phases, 0, sizeof *phases);
+    for (const glfer_hip_phases &w : per) {
+      phases->setup_s = std::max(phases->setup_s, w.setup_s);
+      phases->read_s = std::max(phases->read_s, w.read_s);
+      phases->h2d_s = std::max(phases->h2d_s, w.h2d_s);
+      phases->kernel_s = std::max(phases->kernel_s, w.kernel_s);
+      phases->d2h_s = std::max(phases->d2h_s, w.d2h_s);
+      phases->chunks += w.chunks;
+    }
+    phases->wall_s = now_s() - t0;
+  }
+  return rc_all;
 }
 
 // The waterfall of main_window_draw (g_main.c:1099-1236) over several workers.  The level tracking is
@@ -878,6 +1138,147 @@ int waterfall_workers(const glfer_hip_config *cfg, const int *devices, int nwork
   return rc;
 }
 
+}  // namespace
+
+// A kept set of workers (include/glfer_hip.h): per worker a plan on its GPU -- tables, and the chunk ring that stays with the plan.
+struct glfer_hip_workers {
+  glfer_hip_config cfg;
+  std::vector<int> devices;
+  std::vector<glfer_hip_plan *> plans;
+  std::vector<std::unique_ptr<ReaderPool>> pools;  // worker r's reader threads (made by a thread bound to its GPU's NUMA node)
+  std::mutex mu;                                   // one call at a time
+};
+
+namespace {
+
+bool same_cfg(const glfer_hip_config &a, const glfer_hip_config &b) {   // (field by field: the struct has padding; cfg.device is per worker)
+  return a.mode == b.mode && a.n == b.n && a.overlap == b.overlap && a.window_type == b.window_type && a.limiter_a == b.limiter_a &&
+         a.enable_limiter == b.enable_limiter && a.sub_mean == b.sub_mean && a.history_mode == b.history_mode && a.mtm_w == b.mtm_w &&
+         a.mtm_k == b.mtm_k && a.sample_format == b.sample_format && a.hparma_t == b.hparma_t && a.hparma_p_e == b.hparma_p_e &&
+         a.lmp_av == b.lmp_av && a.psd_pitch == b.psd_pitch;
+}
+
+int make_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, size_t hint_frames, glfer_hip_workers **out) {
+  std::unique_ptr<glfer_hip_workers> w(new (std::nothrow) glfer_hip_workers());
+  if (!w) return GLFER_E_NOMEM;
+  w->cfg = *cfg;
+  w->devices.assign(devices, devices + nworkers);
+  w->plans.assign((size_t)nworkers, nullptr);
+  w->pools.resize((size_t)nworkers);
+  unsigned avail = std::thread::hardware_concurrency();
+  {
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) avail = (unsigned)CPU_COUNT(&set);
+  }
+  const unsigned per_worker = std::max(1u, std::min(16u, (avail ? avail : 8u) / (unsigned)nworkers));   // the caller's thread is one of them
+  const int hop = (int)(cfg->n * (1.0 - cfg->overlap));
+  if (hop <= 0) return GLFER_E_ARG;
+  // every worker makes its own plan and ring, side by side, bound to its GPU's NUMA node (the first plan's DPSS tapers are reused by the others)
+  glfer_hip_config c0 = *cfg;
+  c0.device = devices[0];
+  int rc = glfer_hip_plan_create(&c0, &w->plans[0]);
+  if (rc == GLFER_OK)
+    rc = on_workers((unsigned)nworkers, [&](unsigned r) -> int {
+      int rcw = GLFER_OK;
+      if (r > 0) {
+        glfer_hip_config c = *cfg;
+        c.device = devices[r];
+        rcw = glfer_hip_plan_create(&c, &w->plans[r]);
+      }
+      if (rcw == GLFER_OK && per_worker > 1) {
+        try {
+          w->pools[r].reset(new ReaderPool(per_worker - 1));     // (made here: this thread is bound to the GPU's NUMA node)
+        } catch (...) {
+        }
+      }
+      if (rcw == GLFER_OK && hint_frames != (size_t)-1) {
+        size_t first = 0, count = 0;
+        frame_range(hint_frames ? hint_frames : (size_t)16384 * (size_t)nworkers, r, (unsigned)nworkers, &first, &count);
+        if (count) rcw = reserve_psd_ring(w->plans[r], pick_chunk(w->plans[r], count, 0));
+      }
+      return rcw;
+    }, devices);
+  if (rc != GLFER_OK) {
+    std::string msg = glfer::error_text();
+    for (glfer_hip_plan *p : w->plans) glfer_hip_plan_destroy(p);
+    glfer::set_error_text(msg);
+    return rc;
+  }
+  *out = w.release();
+  return GLFER_OK;
+}
+
+void free_workers(glfer_hip_workers *w) {
+  if (!w) return;
+  for (glfer_hip_plan *p : w->plans) glfer_hip_plan_destroy(p);
+  delete w;
+}
+
+// the stateless entries' own handles: the two most recently used
+std::mutex g_kept_mu;
+std::vector<std::shared_ptr<glfer_hip_workers>> g_kept;
+
+std::shared_ptr<glfer_hip_workers> kept_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, int *rc) {
+  *rc = GLFER_OK;
+  if (!glfer::scratch_keeping() || glfer::scratch_cap() == 0) return nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_kept_mu);
+    for (size_t i = 0; i < g_kept.size(); i++) {
+      glfer_hip_workers &k = *g_kept[i];
+      if ((int)k.devices.size() == nworkers && std::equal(k.devices.begin(), k.devices.end(), devices) && same_cfg(k.cfg, *cfg)) {
+        std::shared_ptr<glfer_hip_workers> hit = g_kept[i];
+        g_kept.erase(g_kept.begin() + (long)i);
+        g_kept.push_back(hit);                     // most recently used last
+        return hit;
+      }
+    }
+  }
+  glfer_hip_workers *raw = nullptr;
+  *rc = make_workers(cfg, devices, nworkers, (size_t)-1, &raw);      // (rings grow on the first call: the job's size is not known here)
+  if (*rc != GLFER_OK) return nullptr;
+  std::shared_ptr<glfer_hip_workers> made(raw, free_workers);
+  std::lock_guard<std::mutex> lock(g_kept_mu);
+  if (g_kept.size() >= 2) g_kept.erase(g_kept.begin());
+  g_kept.push_back(made);
+  return made;
+}
+
+// a stateless entry's call: through a kept handle when one can be had (and is idle), else with plans of its own
+int psd_workers_kept(const glfer_hip_config *cfg, const int *devices, int nworkers, const Source &src, float *h_psd) {
+  int rc = GLFER_OK;
+  std::shared_ptr<glfer_hip_workers> k = kept_workers(cfg, devices, nworkers, &rc);
+  if (rc != GLFER_OK) return rc;
+  if (k) {
+    std::unique_lock<std::mutex> busy(k->mu, std::try_to_lock);
+    if (busy.owns_lock()) return psd_workers(cfg, devices, nworkers, src, h_psd, k->plans.data(), nullptr, &k->pools);
+  }
+  return psd_workers(cfg, devices, nworkers, src, h_psd);
+}
+
+}  // namespace
+
+namespace glfer {
+// the stateless entries' kept handles: dropped by glfer_hip_scratch_trim(device, 0) / glfer_hip_scratch_limit(0); their rings' bytes on
+// `dev` are part of what glfer_hip_scratch_held reports
+void workers_drop_kept() {
+  std::vector<std::shared_ptr<glfer_hip_workers>> gone;
+  {
+    std::lock_guard<std::mutex> lock(g_kept_mu);
+    gone.swap(g_kept);
+  }
+}                                                    // (a handle still in a running call lives until that call ends: shared_ptr)
+size_t workers_kept_bytes(int dev) {
+  std::lock_guard<std::mutex> lock(g_kept_mu);
+  size_t b = 0;
+  for (const auto &k : g_kept)
+    for (const glfer_hip_plan *p : k->plans)
+      if (p && p->cfg.device == dev && p->ring) b += ring_bytes(p->ring);
+  return b;
+}
+}  // namespace glfer
+
+namespace {
+
 int mask_to_devices(unsigned device_mask, int devs[32]) {
   int n = 0;
   for (int d = 0; d < 32; d++)
@@ -931,8 +1332,8 @@ int glfer_hip_spectrogram_host_workers(const glfer_hip_config *cfg, const int *d
     DeviceGuard g0(devices[0]);                                  // (pointer attributes need a current device)
     pinned_in = g0.error() == hipSuccess && is_pinned_host(h_stream);
   }
-  return psd_workers(cfg, devices, nworkers, array_source(h_stream, frames, (size_t)hop * sample_bytes(cfg->sample_format), pinned_in),
-                     h_psd);
+  return psd_workers_kept(cfg, devices, nworkers, array_source(h_stream, frames, (size_t)hop * sample_bytes(cfg->sample_format), pinned_in),
+                          h_psd);
 }
 
 // The GPUs named by a bit mask, one worker each.
@@ -1096,7 +1497,57 @@ int glfer_hip_spectrogram_wav_workers(const glfer_hip_config *cfg, const int *de
   *nframes_out = src.frames;
   if (src.frames == 0) return GLFER_OK;
   if (!h_psd) return GLFER_E_ARG;
-  return psd_workers(cfg, devices, nworkers, src, h_psd);
+  return psd_workers_kept(cfg, devices, nworkers, src, h_psd);
+}
+
+// ---- the persistent set of workers (include/glfer_hip.h) ------------------------------------------------------------------------
+int glfer_hip_workers_create(const glfer_hip_config *cfg, const int *devices, int nworkers, size_t hint_frames, glfer_hip_workers **out) {
+  if (!cfg || !out) return GLFER_E_ARG;
+  *out = nullptr;
+  int rc = check_devices(devices, nworkers);
+  if (rc) return rc;
+  if (hint_frames == (size_t)-1) return GLFER_E_ARG;
+  return make_workers(cfg, devices, nworkers, hint_frames, out);
+}
+
+void glfer_hip_workers_destroy(glfer_hip_workers *w) {
+  if (!w) return;
+  { std::lock_guard<std::mutex> wait_for_a_running_call(w->mu); }
+  free_workers(w);
+}
+
+int glfer_hip_workers_spectrogram_wav(glfer_hip_workers *w, const char *path, float *h_psd, size_t max_frames, size_t *nframes_out,
+                                      unsigned flags, glfer_hip_phases *phases) {
+  if (!w || !path || !nframes_out) return GLFER_E_ARG;
+  Source src;
+  int rc = wav_source(path, (int)(w->cfg.n * (1.0 - w->cfg.overlap)), w->cfg.sample_format, w->cfg.mode, flags, max_frames, &src);
+  if (rc) return rc;
+  *nframes_out = src.frames;
+  if (phases) memset(phases, 0, sizeof *phases);
+  if (src.frames == 0) return GLFER_OK;
+  if (!h_psd) return GLFER_E_ARG;
+  std::lock_guard<std::mutex> one_call(w->mu);
+  return psd_workers(&w->cfg, w->devices.data(), (int)w->devices.size(), src, h_psd, w->plans.data(), phases, &w->pools);
+}
+
+int glfer_hip_workers_spectrogram_host(glfer_hip_workers *w, const void *h_stream, size_t nsamples, float *h_psd, size_t *nframes_out,
+                                       glfer_hip_phases *phases) {
+  if (!w || !h_stream || !nframes_out) return GLFER_E_ARG;
+  const int hop = (int)(w->cfg.n * (1.0 - w->cfg.overlap));
+  const size_t frames = nsamples / (size_t)hop;
+  *nframes_out = frames;
+  if (phases) memset(phases, 0, sizeof *phases);
+  if (frames == 0) return GLFER_OK;
+  if (!h_psd) return GLFER_E_ARG;
+  bool pinned_in = false;
+  {
+    DeviceGuard g0(w->devices[0]);                                 // (pointer attributes need a current device)
+    pinned_in = g0.error() == hipSuccess && is_pinned_host(h_stream);
+  }
+  std::lock_guard<std::mutex> one_call(w->mu);
+  return psd_workers(&w->cfg, w->devices.data(), (int)w->devices.size(),
+                     array_source(h_stream, frames, (size_t)hop * sample_bytes(w->cfg.sample_format), pinned_in), h_psd, w->plans.data(), phases,
+                     &w->pools);
 }
 
 int glfer_hip_spectrogram_wav_multi(const glfer_hip_config *cfg, unsigned device_mask, const char *path, float *h_psd,

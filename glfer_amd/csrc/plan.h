@@ -68,12 +68,15 @@ struct IngestRing {
   hipStream_t st[2] = {nullptr, nullptr};
   hipStream_t up = nullptr;                       // every chunk's upload (round 4): uploads queue behind one another, so that chunk c + 1 goes up while chunk c's rows come down
   hipEvent_t ev_up[2] = {nullptr, nullptr};       // chunk b's upload done: its stream's kernels wait for it
+  hipEvent_t ev_t[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // timing (glfer_hip_phases, made on first use): upload begins / ends, kernels end, download ends
   size_t cap[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
   bool busy = false;
 };
 void ingest_ring_free(IngestRing *r);          // parks the ring as the device's spare, or frees it
 IngestRing *ingest_ring_take(int dev);         // the device's parked ring (the caller owns it), or null
 void ingest_ring_drop_spare(int dev);          // frees the parked ring (glfer_hip_scratch_trim, glfer_hip_scratch_limit)
+void workers_drop_kept();                      // the *_workers entries' kept handles (ingest.cpp): all of them
+size_t workers_kept_bytes(int dev);            // their rings' bytes on `dev`
 size_t ingest_ring_spare_bytes(int dev);       // pinned host + device bytes of the parked ring (counted by glfer_hip_scratch_held)
 
 }  // namespace glfer
@@ -113,6 +116,8 @@ struct glfer_hip_plan {
   // harmonic F-test (mtm.c:124-136): built on first use
   float *d_ftaps_mu_first = nullptr;   // the allocation: [hn][taper 0..ntapers-1][hn], each [2n] alone in slot 0 of the packed layout
   float *d_ftaps = nullptr;         // = d_ftaps_mu_first + 2n: [ntapers+1][2n], taper j, then hn
+  float *d_ftaps2 = nullptr;        // the paired form (round 5): [ceil((ntapers+1)/2)][2n] with (hn, taper 0), (taper 1, taper 2) ... as (re, im), halved;
+  float *d_ftaps2_nomu = nullptr;   //   then [ceil(ntapers/2)][2n] with (taper 0, taper 1) ... (mu_live = 0); one allocation
   double *d_U0 = nullptr;           // [ntapers]
   std::vector<double> U0;           // [ntapers]
   std::vector<float> hn;            // [n]

@@ -62,10 +62,14 @@ namespace glfer {
 // per-bin float sum with the reference's own double/float statement types; the quotient is formed
 // and stored after the last round.  No spectrum goes through HBM (round 2's first form wrote
 // ntap+1 spectra per frame and read them back: 7.4 M frames/s at N = 4096).
-template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD, int STG = GLFER16_STAGGER, int KM = 0, bool FT = false>
+// FT = 2 (round 5): the same statistic from HALF the transforms -- the six real sequences of N = 4096, 5 tapers (hn and the tapers)
+// go through three packed transforms, two sequences each (re / im), and every pair is separated through the mirror bins in LDS:
+// with Z = FFT(a + i b), X_a[k] = (Z[k] + conj Z[N-k]) / 2 and X_b[k] = (Z[k] - conj Z[N-k]) / (2 i) (the halves ride in the tables).
+// The accumulation per taper, its order and its statement types are those of FT = 1.
+template <int LOGN, int FMT, bool GEN, int WPS = GLFER16_WAVES_PER_SIMD, int STG = GLFER16_STAGGER, int KM = 0, int FT = 0>
 __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(SpectroParams p) {
   static_assert(KM == 0 || (!GEN && (KM == 16 || KM == 8 || KM == 4)), "in-kernel mean removal: the plain path");
-  static_assert(!FT || !GEN, "F statistic: the plain path");
+  static_assert(FT == 0 || !GEN, "F statistic: the plain path");
   constexpr int NH = KM > 0 ? 16 / KM : 1;
   using C = Plan16<LOGN>;
   using L = Launch16<LOGN>;
@@ -262,7 +266,62 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
     // After the last pass register rho = b + B*brev(q',R) holds bin t + T*(b + B*q').
     const long long f = fblk + fl;
     const bool live = f < p.nframes;
-    if constexpr (FT) {
+    if constexpr (FT == 2) {
+      constexpr int R = C::radix(NPASS - 1), B = 16 / R;
+      // Z to LDS by bin, one barrier, and every lane reads the mirror bins of its bins k <= N/2 (registers with b + B q' <= 8)
+      frame_sync<T>();
+      static_for<0, 16>([&](auto rc) {
+        constexpr int rho = decltype(rc)::value;
+        constexpr int b = rho % B, qp = brev(rho / B, R);
+        xb[(int)t + T * (b + B * qp)] = v2f32{zr[rho], zi[rho]};
+      });
+      frame_sync<T>();
+      // one sequence's spectrum at the lane's bin of register rho: mu (the hn sequence) is kept, a taper's goes into the sum (mtm.c:203-210)
+      auto take = [&](auto rc, int seq, float xr, float xi, int k) {
+        constexpr int rho = decltype(rc)::value;
+        if (seq >= p.ft_nseq) return;                              // (an odd number of sequences: the last table's second half is zero)
+        const int jt = p.ft_mu_live ? seq - 1 : seq;               // taper of this sequence (-1: hn)
+        if (jt < 0) {
+          ftmur[rho] = xr;
+          ftmui[rho] = xi;
+          ftsum[rho] = 0.0f;
+          return;
+        }
+        if (!p.ft_mu_live && seq == 0) {
+          ftmur[rho] = 0.0f;
+          ftmui[rho] = 0.0f;
+          ftsum[rho] = 0.0f;
+        }
+        const double U0j = p.ft_U0[jt];
+        {
+#pragma clang fp contract(off)
+          const double tmpr = (double)xr - (double)ftmur[rho] * U0j;
+          const double tmpi = (double)xi - (double)ftmui[rho] * U0j;
+          const double both = tmpr * tmpr + tmpi * tmpi, one = tmpr * tmpr;
+          ftsum[rho] = (float)((double)ftsum[rho] + (k == 0 ? one : both));
+        }
+      };
+      static_for<0, 16>([&](auto rc) {
+        constexpr int rho = decltype(rc)::value;
+        constexpr int b = rho % B, qp = brev(rho / B, R);
+        if constexpr (b + B * qp <= 8) {
+          const int k = (int)t + T * (b + B * qp);
+          const v2f32 zm = xb[(N - k) & (N - 1)];                  // Z[N-k] (k = 0: Z[0] itself; k = N/2: itself)
+          float ar, ai, br, bi;
+          {
+#pragma clang fp contract(off)
+            ar = zr[rho] + zm.x;                                   // X_a = Z[k] + conj Z[N-k]       (the 1/2 is in the tables)
+            ai = zi[rho] - zm.y;
+            br = zi[rho] + zm.y;                                   // X_b = (Z[k] - conj Z[N-k]) / i
+            bi = zm.x - zr[rho];
+          }
+          take(rc, 2 * pair, ar, ai, k);
+          take(rc, 2 * pair + 1, br, bi, k);
+        }
+      });
+      if constexpr (GLFER16_BARRIER_AFTER_READS != 0) frame_sync<T>();   // mirror bins read: the buffer is free for the next round's writes
+    }
+    if constexpr (FT == 1) {
       constexpr int R = C::radix(NPASS - 1), B = 16 / R;
       const int jt = p.ft_mu_live ? pair - 1 : pair;             // taper of this round (-1: the hn round)
       if (jt < 0) {
@@ -288,9 +347,12 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
           }
         });
       }
+    }
+    if constexpr (FT != 0) {
+      constexpr int R = C::radix(NPASS - 1), B = 16 / R;
       if (npair == 0 && live) {                                  // the frame's last round: the quotient (mtm.c:222-233)
         float *o = p.ftest + (size_t)f * (N / 2 + 1);
-        const int kk = p.npairs - (p.ft_mu_live ? 2 : 1);        // params->kmax = ntap - 1
+        const int kk = (FT == 2 ? p.ft_nseq : p.npairs) - (p.ft_mu_live ? 2 : 1);        // params->kmax = ntap - 1
         static_for<0, 16>([&](auto rc) {
           constexpr int rho = decltype(rc)::value;
           constexpr int b = rho % B, qp = brev(rho / B, R);
@@ -328,7 +390,7 @@ __global__ __launch_bounds__(Launch16<LOGN>::BLOCK, WPS) void spectro16_kernel(S
     for (int r = 0; r < 16; r++)
       acc[r] = __builtin_fmaf(zr[r], zr[r], __builtin_fmaf(zi[r], zi[r], acc[r]));
 
-    if (!FT && npair == 0) {
+    if (FT == 0 && npair == 0) {
       // ---- last pair of this frame: mirror fold through LDS, psd[k] = acc[k] + acc[(N-k) mod N]
       float *fold = reinterpret_cast<float *>(xb);
       frame_sync<T>();
@@ -499,7 +561,9 @@ static hipError_t launch16_fmt(const SpectroParams &p, hipStream_t st) {
   if (p.ftest) {
     // the F statistic: one taper per round (two spill-free wavefronts per SIMD: mu and the sums are 48 more registers)
     if (p.nonlin || p.spec || p.mean_inkernel || !p.ft_U0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((spectro16_kernel<L, FMT, false, 2, GLFER16_STAGGER, 0, true>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    // (the paired form keeps mu and the sums for the bins k <= N/2 only -- 27 registers, not 48: three wavefronts per SIMD)
+    if (p.ft_nseq > 0) hipLaunchKernelGGL((spectro16_kernel<L, FMT, false, 3, GLFER16_STAGGER, 0, 2>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((spectro16_kernel<L, FMT, false, 2, GLFER16_STAGGER, 0, 1>), dim3(grid), dim3(LC::BLOCK), 0, st, p);
     return hipGetLastError();
   }
   if (p.mean_inkernel) {

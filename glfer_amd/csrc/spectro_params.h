@@ -46,6 +46,10 @@ struct SpectroParams {
   const double *ft_U0;     /* device: [ntap]                                                  */
   float ft_sum_U0_sqr;
   int ft_mu_live;          /* 0: mu is all zeros (the reference build without FFTW, mtm.c:173) */
+  int ft_nseq;             /* > 0: the PAIRED form (round 5): taps holds [ceil(ft_nseq / 2)][2N] tables with TWO real sequences each
+                              (re: sequence 2r, im: sequence 2r+1, both scaled by 1/2; the sequences are hn -- when ft_mu_live --
+                              then tapers 0..ntap-1), one N-point transform per pair, the two spectra separated through the
+                              mirror bins (X_a = Z[k] + conj Z[N-k], X_b = (Z[k] - conj Z[N-k]) / i)                 */
   int mean_inkernel;       /* per-hop mean removal (fft.c:86-96) inside spectro16h.hip: the stream is the RAW one;
                               only where the hop is 2, 4, 8 or 16 sixteenths of N               */
   const float *means;      /* device, optional (with mean_inkernel): means[h] = the mean of hop h of the whole stream (virtual

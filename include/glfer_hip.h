@@ -325,6 +325,33 @@ int glfer_hip_spectrogram_wav_multi(const glfer_hip_config *cfg, unsigned device
 int glfer_hip_spectrogram_wav_workers(const glfer_hip_config *cfg, const int *devices, int nworkers, const char *path,
                                       float *h_psd, size_t max_frames, size_t *nframes_out, unsigned flags);
 
+/* ---- a persistent set of workers for the *_workers / *_multi entries (round 5) -------------------------------------------------
+ * The stateless entries above make everything a worker needs inside the call.  For BASELINE config 4 as worded -- a 1-hour WAV,
+ * 346 MB, 10 546 frames, 1.2 ms of kernels -- that set-up WAS the call: DPSS tapers (0.1-0.3 s at N = 16384, kept by the library
+ * after the first plan), tables uploaded per plan, 30-40 ms of pinned and device buffers per worker unless the device's one parked
+ * ring was free.  A handle keeps, per worker: its plan (tables on its GPU) and ITS OWN chunk ring, sized at creation for jobs of
+ * hint_frames frames in all (0 = the default chunk); calls through the handle allocate nothing.  One call at a time per handle
+ * (a second one waits).  The stateless entries keep the two most recently used handles themselves (same configuration and worker
+ * list -> same handle; GLFER_SCRATCH_CACHE=0 or glfer_hip_scratch_limit(0): nothing is kept, glfer_hip_scratch_trim(device, 0)
+ * drops them), so repeated calls are fast there too -- what a handle adds is the set-up OUTSIDE the first call.
+ * phases (may be NULL): where the call's time went -- per field the largest value over the workers (they run side by side),
+ * seconds: set-up inside the call (ring look-up, any allocation), reading / copying the samples into pinned memory, uploads,
+ * kernels (from a chunk's upload end to its kernels' end), downloads -- sums over a worker's chunks, which OVERLAP one another, so
+ * the fields add up to more than wall_s -- and the call's wall time; chunks = chunks of all workers. */
+typedef struct glfer_hip_phases {
+  double setup_s, read_s, h2d_s, kernel_s, d2h_s, wall_s;
+  unsigned chunks;
+} glfer_hip_phases;
+typedef struct glfer_hip_workers glfer_hip_workers;
+int glfer_hip_workers_create(const glfer_hip_config *cfg, const int *devices, int nworkers, size_t hint_frames,
+                             glfer_hip_workers **out);
+void glfer_hip_workers_destroy(glfer_hip_workers *w);
+/* glfer_hip_spectrogram_wav_workers / glfer_hip_spectrogram_host_workers through a handle */
+int glfer_hip_workers_spectrogram_wav(glfer_hip_workers *w, const char *path, float *h_psd, size_t max_frames,
+                                      size_t *nframes_out, unsigned flags, glfer_hip_phases *phases);
+int glfer_hip_workers_spectrogram_host(glfer_hip_workers *w, const void *h_stream, size_t nsamples, float *h_psd,
+                                       size_t *nframes_out, glfer_hip_phases *phases);
+
 /* K0 on its own: per-hop mean removal (fft.c:86-96).  d_out[i] = sample(d_in[i]) - mean of the
  * hop i belongs to; nhops hops of `hop` samples each.  (The spectrogram entries apply it
  * themselves when cfg.sub_mean is set; this entry serves the per-hop shims, which must hand

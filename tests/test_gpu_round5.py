@@ -181,3 +181,64 @@ def test_average_inside_the_launch_at_bench_scale(lib, torch_cuda):
     assert torch.equal(avg, want_avg) and torch.equal(ret[:, 1], want_ret[:, 1])
     assert torch.allclose(ret[:, 0], want_ret[:, 0], rtol=1e-12, atol=0)
     sp.close()
+
+
+# ---- a kept set of workers ------------------------------------------------------------------------------
+def _write_wav(path, pcm, rate=48000):
+    import struct
+    bits = 8 * pcm.dtype.itemsize
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, rate, rate * bits // 8, bits // 8, bits))
+        f.write(b"data" + struct.pack("<I", pcm.nbytes))
+        pcm.tofile(f)
+
+
+@pytest.mark.parametrize("mode,n,overlap,workers", [("mtm", 16384, 0.0, 3), ("fft", 1024, 0.5, 5), ("mtm", 4096, 0.75, 2)])
+def test_workers_handle_keeps_plans_and_rings(lib, oracle, torch_cuda, tmp_path, mode, n, overlap, workers):
+    """glfer_hip_workers_*: a handle's calls (file and host buffer, several workers sharing this GPU) give the rows of the one-plan
+    entries bit for bit, call after call; the phases add up to something sane; the stateless entry -- which now keeps its own
+    handles -- gives the same rows, and glfer_hip_scratch_trim(device, 0) takes what it kept back."""
+    import ctypes as C
+    h = oracle.hop(n, overlap)
+    frames = 700 if n == 16384 else 2500
+    x = synth_stream(frames * h + 123, seed=n + workers) * 0.8 + np.float32(0.05)
+    pcm = np.clip(np.round(x * 30000), -32768, 32767).astype(np.int16)
+    path = str(tmp_path / "in.wav")
+    _write_wav(path, pcm)
+    if mode == "mtm":
+        params = lib.MtmParams(n=n, overlap=overlap, w=2.5, kmax=4, sample_format=lib.SAMPLES_S16, sub_mean=1)
+    else:
+        params = lib.FftParams(n=n, window_type=0, overlap=overlap, sample_format=lib.SAMPLES_S16, sub_mean=1)
+    sp = lib.Spectrogram(params)
+    want = sp.run_wav(path)
+    want_tail = sp.run_wav(path, partial_tail=True)
+    sp.close()
+    assert want.shape[0] == frames and want_tail.shape[0] == frames + 1
+    W = lib.Workers(params, [0] * workers, hint_frames=frames)
+    rows = lib.pinned_empty((frames + 1, n // 2 + 1), np.float32)
+    for rep in range(3):
+        rows[:] = -1.0
+        nf, ph = W.run_wav(path, rows[:frames])
+        assert nf == frames and np.array_equal(rows[:frames], want), rep
+        assert ph["wall_s"] > 0 and ph["chunks"] >= workers and ph["kernel_s"] > 0 and ph["read_s"] > 0 and ph["wall_s"] < 5.0
+    nf, _ = W.run_wav(path, rows, partial_tail=True)
+    assert nf == frames + 1 and np.array_equal(rows, want_tail)
+    pin = lib.pinned_empty((frames * h,), np.int16)
+    pin[:] = pcm[:frames * h]
+    rows[:] = -1.0
+    nf, ph = W.run_host(pin, rows[:frames])
+    assert nf == frames and np.array_equal(rows[:frames], want) and ph["read_s"] >= 0
+    nf, _ = W.run_host(pcm[:frames * h].copy(), rows[:frames])          # pageable samples: staged
+    assert nf == frames and np.array_equal(rows[:frames], want)
+    W.close()
+    # the stateless entry: twice (the second call finds the workers it kept), then everything handed back
+    L = lib.api.lib()
+    for rep in range(2):
+        got = lib.spectrogram_wav_workers(params, path, [0] * workers)
+        assert np.array_equal(got, want), rep
+    assert L.glfer_hip_scratch_held(0) > 0
+    L.glfer_hip_scratch_trim(0, 0)
+    assert L.glfer_hip_scratch_held(0) == 0
+    got = lib.spectrogram_wav_workers(params, path, [0] * workers)
+    assert np.array_equal(got, want)
+    L.glfer_hip_scratch_trim(0, 0)

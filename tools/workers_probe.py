@@ -1,9 +1,9 @@
 """glfer_hip_spectrogram_host_workers with 1, 2, 4, 8 workers sharing ONE GPU (the host side of the multi-GPU entry: a thread, a plan
 and a chunk ring per worker; the GPU and its link are shared here, so the rate should hold, not scale), pinned ends; rows compared
 with the one-worker run.   python tools/workers_probe.py
-Measured (round 4, one box): 5.15 / 4.31 / 3.62 / 3.09 M frames/s with 1 / 2 / 4 / 8 workers.  The fall is this rehearsal's own: a device parks ONE
-chunk ring between calls (ingest_ring_take), so all but one of the workers that share the GPU allocate 2 x 256 MiB of pinned and device buffers
-inside every call; with a worker per GPU -- what the entry is for -- each device has its parked ring."""
+Round 4 measured 5.15 / 4.31 / 3.62 / 3.09 M frames/s with 1 / 2 / 4 / 8 workers: a device parked ONE chunk ring between calls, so all but one of the
+workers that share the GPU allocated their pinned and device buffers inside every call.  Round 5: the entry keeps its workers (a plan and a ring EACH)
+between calls, and a glfer_hip_workers handle does so explicitly -- both are timed here."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
@@ -28,4 +28,14 @@ for workers in (1, 2, 4, 8):
         ref = rows[::997].copy()
     else:
         assert np.array_equal(ref, rows[::997]), workers
-    print("%d worker(s) on one GPU: %.2f M frames/s, %.1f GB/s over PCIe both ways" % (workers, frames / best / 1e6, frames * (8192 + 8196) / best / 1e9), flush=True)
+    W = G.Workers(params, [0] * workers, hint_frames=frames)
+    hb = 1e9
+    for rep in range(3):
+        t0 = time.perf_counter()
+        nf, _ = W.run_host(pcm, rows, phases=False)
+        hb = min(hb, time.perf_counter() - t0)
+    _, ph = W.run_host(pcm, rows)
+    W.close()
+    assert nf == frames and np.array_equal(ref, rows[::997]), workers
+    print("%d worker(s) on one GPU: stateless entry %.2f M frames/s (%.1f GB/s over PCIe both ways), through a handle %.2f M frames/s; phases of one more call (with timing events) %s"
+          % (workers, frames / best / 1e6, frames * (8192 + 8196) / best / 1e9, frames / hb / 1e6, {k: round(v, 4) if isinstance(v, float) else v for k, v in ph.items()}), flush=True)
