@@ -260,7 +260,7 @@ def pmc_summary(pmc_name):
     """Committed rocprofv3 PMC summary of a workload (newest round first): (dict, path) or (None, None)."""
     if pmc_name is None:
         return None, None
-    for rnd in ("r04_", "r03_", "r02_", "r01_"):
+    for rnd in ("r05_", "r04_", "r03_", "r02_", "r01_"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", rnd + pmc_name))), "profiles/" + rnd + pmc_name
         except Exception:
