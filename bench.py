@@ -230,7 +230,12 @@ def host_side_phase(dist, rank, cpu_group, work):
     the job through the host entries (one worker thread, plan and pinned ring per GPU: glfer_hip_spectrogram_host_multi,
     glfer_hip_spectrogram_wav_multi) while the other ranks wait at a barrier on the CPU (a gloo group: an RCCL barrier would
     keep their GPUs spinning under rank 0's workers).  Returns work()'s result on rank 0, None elsewhere."""
-    out = work() if rank == 0 else None
+    out = None
+    if rank == 0:
+        try:
+            out = work()
+        except Exception as exc:                     # the line and the other ranks must not be lost to a host-side row
+            out = {"error": "%s: %s" % (type(exc).__name__, exc)}
     dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
     return out
 
@@ -795,7 +800,10 @@ def main():
         line["c4_as_worded"] = c4_as_worded(torch, G, local)
     # ---- N > 1: the host-side rows (rank 0 drives every GPU of the job from one process; the other ranks wait on the CPU)
     if world > 1 and not args.no_secondary and args.workload == "mtm":
-        cpu_group = None if rehearse else dist.new_group(backend="gloo")
+        try:
+            cpu_group = None if rehearse else dist.new_group(backend="gloo")
+        except Exception:                            # no gloo beside RCCL on this stack: the default group's barrier (the waiting ranks' GPUs spin)
+            cpu_group = None
         devs = [0] * world if rehearse else list(range(world))
         host = host_side_phase(dist, rank, cpu_group, lambda: {"end_to_end": end_to_end_multi(torch, G, local, devs),
                                                                "c4_as_worded": c4_as_worded(torch, G, local, devs)})
