@@ -1464,11 +1464,16 @@ static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroPara
     // (short launches: the producers' lead over the first consumers is a bubble of nhops / producers' rate -- keep the two launches)
     const long min_frames = [] { const char *e = getenv("GLFER_FUSED_MIN_FRAMES"); return e && *e ? atol(e) : 65536L; }();   // (tests lower it)
     if (producers > 0 && periodogram_table && npieces == 1 && (long)(b1 - b0) >= min_frames) {
-      const int chunk = 4096;
+      // GLFER_FUSED_BLOCK_FRAMES > 0 (round 5): the lock-stepped form -- consumer workgroups of so many frames walked front by front,
+      // a flag per 64-hop group, the producers GLFER_FUSED_LOOK hops (default 1024) beyond what their front's resident consumers span
+      const long block_frames = [] { const char *e = getenv("GLFER_FUSED_BLOCK_FRAMES"); return e && *e ? atol(e) : 0L; }();
+      const long look = [] { const char *e = getenv("GLFER_FUSED_LOOK"); return e && *e ? atol(e) : 1024L; }();
+      const bool lockstep = block_frames > 0;
+      const int chunk = lockstep ? 64 : 4096;
       const size_t nchunks = (nhops + chunk - 1) / chunk;
       unsigned *ready = nullptr;
-      e = glfer::scratch_malloc((void **)&ready, nchunks * sizeof(unsigned), st);
-      if (e == hipSuccess) e = hipMemsetAsync(ready, 0, nchunks * sizeof(unsigned), st);
+      e = glfer::scratch_malloc((void **)&ready, (nchunks + 8) * sizeof(unsigned), st);
+      if (e == hipSuccess) e = hipMemsetAsync(ready, 0, (nchunks + 8) * sizeof(unsigned), st);
       if (e == hipSuccess) {
         q.nprod = (int)(producers / 8 * 8);
         q.prod_chunk = chunk;
@@ -1476,6 +1481,12 @@ static int launch_body_with_reference_means(glfer_hip_plan *p, const SpectroPara
         q.means_ready = ready;
         q.prod_hop0 = (long long)hop_lo;
         q.prod_nhops = (long long)nhops;
+        if (lockstep) {
+          q.prod_front_frames = -1;                                            // (the launcher sizes the fronts from its grid)
+          q.prod_block_frames = (int)block_frames;
+          q.prod_look = (int)look;
+          q.front_done = ready + nchunks;
+        }
         e = launch_by_n(q, p->n, st);
       }
       if (ready) glfer::scratch_free(ready, st);

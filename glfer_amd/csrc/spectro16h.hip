@@ -144,7 +144,32 @@ __device__ __forceinline__ void produce_hop_means(const SpectroParams &p, float 
   const int H = p.H;
   const long long groups = (p.prod_nhops + 63) / 64;
   const unsigned half = lane >> 5, l32 = lane & 31u;
-  for (long long g = wave; g < groups; g += nwaves) {
+  // The lock-stepped form: this wavefront belongs to front `fr` and walks that front's groups only, never more than prod_look hops
+  // past what the front's consumers have FINISHED (front_done x frames per workgroup) -- the consumers that are running need hops
+  // inside that allowance (the launcher sizes it: resident ranges + a margin), so nobody waits for somebody who waits for him.
+  long long g_first = wave, g_step = nwaves, g_end = groups, front_hop0 = 0;
+  int fr = -1;
+  if (p.prod_front_frames > 0) {
+    fr = (int)(wave & 7);                                   // (the caller hands wave = wavefront-in-front * 8 + front)
+    const long long nfronts_waves = nwaves >> 3;
+    const long long f_lo = (long long)fr * p.prod_front_frames, f_hi = f_lo + p.prod_front_frames < p.nframes ? f_lo + p.prod_front_frames : p.nframes;
+    if (f_lo >= p.nframes) return;
+    front_hop0 = p.frame0 + f_lo - (p.frame0 - p.prod_hop0);            // the front's first frame's OLDEST hop (its history reaches prod_hop0's distance back)
+    const long long g0 = (front_hop0 - p.prod_hop0) / 64;
+    g_end = (p.frame0 + f_hi - p.prod_hop0 + 63) / 64;
+    if (g_end > groups) g_end = groups;
+    g_first = g0 + (wave >> 3);
+    g_step = nfronts_waves;
+  }
+  for (long long g = g_first; g < g_end; g += g_step) {
+    if (fr >= 0) {
+      const long long ahead = p.prod_hop0 + g * 64 - front_hop0;        // hops from the front's start to this group
+      for (int spin = 0; spin < (1 << 16); spin++) {
+        const long long done = (long long)__hip_atomic_load(p.front_done + fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * p.prod_block_frames;
+        if (ahead <= done + p.prod_look) break;
+        __builtin_amdgcn_s_sleep(64);
+      }
+    }
     const long long hop0 = p.prod_hop0 + g * 64;
     const long long left = p.prod_hop0 + p.prod_nhops - hop0;
     const int rows = (int)(left < 64 ? left : 64);
@@ -152,18 +177,19 @@ __device__ __forceinline__ void produce_hop_means(const SpectroParams &p, float 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.stream)) + hop0 * (long long)H * esz, 0,
         (unsigned)(span > 0x7fffffffLL ? 0x7fffffffLL : span), 0x00020000);
-    float v[32];
-    auto fetch = [&](int k0) {                       // instruction j: hops 2j (lanes 0-31) and 2j + 1 (lanes 32-63), sample k0 + (lane & 31)
+    // Two tiles in flight (round 5: with one -- 8 KB per ~2 us of HBM latency -- a producer wavefront streamed ~4 GB/s, and the lock-stepped
+    // launch's few producers could not keep their front ahead of its consumers)
+    float va[32], vb[32];
+    auto fetch = [&](float (&v)[32], int k0) {       // instruction j: hops 2j (lanes 0-31) and 2j + 1 (lanes 32-63), sample k0 + (lane & 31)
       const unsigned base = k0 + (int)l32 < H ? ((unsigned)half * (unsigned)H + (unsigned)(k0 + (int)l32)) * esz : 0x80000000u;
 #pragma unroll
       for (int j = 0; j < 32; j++) v[j] = buf_sample<FMT>(rs, base + (unsigned)(2 * j) * (unsigned)H * esz, 0u);
     };
     float s = 0.0f;
-    fetch(0);
-    for (int k0 = 0; k0 < H; k0 += 32) {
+    auto step = [&](float (&v)[32], int k0) {        // tile k0 out of its registers, the tile after next into them, then the chain over its 32 samples
 #pragma unroll
       for (int j = 0; j < 32; j++) tile[(2 * j + (int)half) * 33 + (int)l32] = v[j];
-      if (k0 + 32 < H) fetch(k0 + 32);               // the next tile's loads fly under this tile's chain
+      if (k0 + 64 < H) fetch(v, k0 + 64);
       const int kn = H - k0 < 32 ? H - k0 : 32;
       const float *row = tile + lane * 33;
       if (kn == 32) {
@@ -172,6 +198,12 @@ __device__ __forceinline__ void produce_hop_means(const SpectroParams &p, float 
       } else {
         for (int k = 0; k < kn; k++) s += row[k];
       }
+    };
+    fetch(va, 0);
+    if (32 < H) fetch(vb, 32);
+    for (int k0 = 0; k0 < H; k0 += 64) {
+      step(va, k0);
+      if (k0 + 32 < H) step(vb, k0 + 32);
     }
     // Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): the group's 64 means leave as `sc1` stores -- whole 128-byte
     // lines by one store instruction of one wavefront, written through, so NO agent release is needed (a `__threadfence()` here
@@ -180,7 +212,10 @@ __device__ __forceinline__ void produce_hop_means(const SpectroParams &p, float 
     // side).  The consumer: a relaxed `sc1` poll by one wavefront, an agent acquire, a workgroup barrier, plain loads.
     if ((int)lane < rows) __hip_atomic_store(p.means_out + hop0 + lane, s / (float)H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // fft.c:92: float /= int
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(p.means_ready + (g * 64) / p.prod_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+      if (p.prod_front_frames > 0) __hip_atomic_store(p.means_ready + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a flag per group (two fronts may both write a boundary group: the same bits)
+      else __hip_atomic_fetch_add(p.means_ready + (g * 64) / p.prod_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -242,8 +277,10 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       if (blockIdx.x < (unsigned)p.nprod) {
         static_assert(L::BLOCK % 64 == 0 && (L::BLOCK / 64) * 64 * 33 * 4 <= L::LDS_WORDS * 8, "a [64][33] float tile per wavefront out of the exchange buffer");
         const unsigned wv = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-        produce_hop_means<FMT>(p, reinterpret_cast<float *>(lds) + wv * (64 * 33), tid & 63u, (long long)blockIdx.x * (L::BLOCK / 64) + wv,
-                               (long long)p.nprod * (L::BLOCK / 64));
+        // (lock-stepped: producer workgroup j serves front j mod 8; its wavefronts are numbered (wavefront within the front) * 8 + front)
+        const long long wave_id = p.prod_front_frames > 0 ? ((long long)(blockIdx.x >> 3) * (L::BLOCK / 64) + wv) * 8 + (blockIdx.x & 7u)
+                                                          : (long long)blockIdx.x * (L::BLOCK / 64) + wv;
+        produce_hop_means<FMT>(p, reinterpret_cast<float *>(lds) + wv * (64 * 33), tid & 63u, wave_id, (long long)p.nprod * (L::BLOCK / 64));
         return;
       }
       grid_w = gridDim.x - (unsigned)p.nprod;
@@ -452,6 +489,21 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
       const long long c_lo = (h_lo - p.prod_hop0) / p.prod_chunk, c_hi = (h_hi - 1 - p.prod_hop0) / p.prod_chunk;
       // ONE wavefront polls (every poll is a load that goes past L2: two thousand pollers on a handful of counters starve the
       // producers they are waiting for -- measured: 0.4 TB/s of means), the others wait at the barrier and then acquire for themselves
+      if (p.prod_front_frames > 0) {
+        if (tid < 64) {
+          const long long g_lo = (h_lo - p.prod_hop0) / 64, g_hi = (h_hi - 1 - p.prod_hop0) / 64;
+          for (long long g = g_lo; g <= g_hi; g++) {
+            bool ok = false;
+            for (int spin = 0; spin < (1 << 16) && !ok; spin++) {
+              ok = __hip_atomic_load(p.means_ready + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+              if (!ok) __builtin_amdgcn_s_sleep(32);
+            }
+            // a producer that never came (a launch must end whatever happens): the hops' means are poisoned, the rows come out NaN
+            if (!ok && tid == 0)
+              for (int k = 0; k < 64 && g * 64 + k < p.prod_nhops; k++) p.means_out[p.prod_hop0 + g * 64 + k] = __builtin_nanf("");
+          }
+        }
+      } else
       if (tid < 64) {
         for (long long c = c_lo; c <= c_hi; c++) {
           const long long in_chunk = p.prod_nhops - c * p.prod_chunk < p.prod_chunk ? p.prod_nhops - c * p.prod_chunk : p.prod_chunk;
@@ -941,6 +993,11 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
   } else {
     while (frame_body(std::integral_constant<int, 0>{})) {}
   }
+  if constexpr (MTAB != 0) {
+    // the lock-stepped fused launch: this front's producers may move on (one count per finished consumer workgroup)
+    if (p.nprod > 0 && p.prod_front_frames > 0 && tid == 0)
+      __hip_atomic_fetch_add(p.front_done + (block_w & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 }  // namespace glfer
@@ -1023,6 +1080,26 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
     if (g >= 64) g &= ~7u;
     if (p.means) {                                   // the means are given: the table form, at the plain form's occupancy
       constexpr int W = GLFER16H_WAVES_PER_SIMD;
+      if (p.nprod > 0 && p.prod_front_frames < 0) {
+        // the lock-stepped fused launch (round 5): short consumer ranges (prod_block_frames asks for so many frames per workgroup) walked
+        // front by front, the producers throttled to stay inside the Infinity Cache
+        if ((p.nprod & 7) || p.prod_block_frames < 1) return hipErrorInvalidValue;
+        SpectroParams q = p;
+        long long gc = ((long long)p.nframes + p.prod_block_frames - 1) / p.prod_block_frames;
+        gc = (gc + 7) / 8 * 8;
+        const long long per = ((long long)p.nframes + gc * LC::FPB - 1) / (gc * LC::FPB);
+        q.prod_block_frames = (int)(per * LC::FPB);
+        q.prod_front_frames = (gc / 8) * per * LC::FPB;
+        q.prod_look = 96 * q.prod_block_frames + p.prod_look;       // what a front's resident consumers span (3 workgroups x 32 CUs an XCD) + the margin asked for
+        const unsigned gl = (unsigned)(gc + p.nprod);
+        constexpr int WL = GLFER16H_WAVES_PER_SIMD;
+        if (k16 == 16) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, WL, GLFER16H_VAR, 0, 0, 0, 1, 1>), dim3(gl), dim3(LC::BLOCK), 0, st, q);
+        else if (k16 == 2) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, WL, GLFER16H_VAR, 0, 0, 2, 1, 1>), dim3(gl), dim3(LC::BLOCK), 0, st, q);
+        else if (k16 == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, WL, GLFER16H_VAR, 0, 0, 4, 1, 1>), dim3(gl), dim3(LC::BLOCK), 0, st, q);
+        else if (k16 == 8) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, WL, GLFER16H_VAR, 0, 0, 8, 1, 1>), dim3(gl), dim3(LC::BLOCK), 0, st, q);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+      }
       if (p.nprod > 0) {                             // the fused launch: producers in front of the grid as it would have been
         if (p.nprod & 7) return hipErrorInvalidValue;
         grid += (unsigned)p.nprod;

@@ -64,6 +64,15 @@ struct SpectroParams {
   unsigned *means_ready;   /* device: [ceil(prod_nhops / prod_chunk)] hop groups of the chunk that are written (zeroed before the launch) */
   long long prod_hop0;     /* the hops to produce: [prod_hop0, prod_hop0 + prod_nhops) of the whole stream             */
   long long prod_nhops;
+  /* round 5, the LOCK-STEPPED fused launch (prod_front_frames > 0): the consumer workgroups walk the stream in eight fronts (one per
+     XCD: consumer workgroup w belongs to front w mod 8 and takes the front's next range of frames), producer workgroup j serves front
+     j mod 8 and stays at most prod_look hops ahead of what that front's consumers have finished, so that the estimator's read of a
+     hop comes out of the Infinity Cache the producers filled a few tens of microseconds earlier.  means_ready then holds one flag
+     per 64-hop group (prod_chunk = 64), followed by front_done[8] (consumer workgroups finished per front).                     */
+  long long prod_front_frames;   /* frames per front: (consumer workgroups / 8) x frames per workgroup                                */
+  int prod_block_frames;         /* frames per consumer workgroup                                                                    */
+  int prod_look;                 /* hops a front's producers may run ahead of its finished consumers                                  */
+  unsigned *front_done;          /* device: [8]                                                                                     */
   /* update_avg_plain (avg.c:108-159) INSIDE spectro16h.hip's periodogram kernel (round 5): avg != NULL.  A frame slot walks
      consecutive frames and keeps the last depth-1 PSD rows of its bins in registers; the window's sum is taken in double per
      bin and divided by depth+1 as the reference does once its window is full (avg.c:138-139,155).  EVERY frame of the launch

@@ -164,7 +164,8 @@ def test_reference_means_piece_by_piece(lib, oracle, torch_cuda, case):
               lib.MtmParams(n=n, overlap=overlap, w=2.5, kmax=4, sub_mean=lib.SUBMEAN_EXACT, sample_format=sf))
     sp = lib.Spectrogram(params)
     d = torch.from_numpy(raw).cuda()
-    knobs = ("GLFER_EXACT_PIECE_MB", "GLFER_EXACT_STREAMS", "GLFER_MEANS_HPW", "GLFER_MEANS_BLOCKS", "GLFER_MEANS_PRODUCERS", "GLFER_FUSED_MIN_FRAMES")
+    knobs = ("GLFER_EXACT_PIECE_MB", "GLFER_EXACT_STREAMS", "GLFER_MEANS_HPW", "GLFER_MEANS_BLOCKS", "GLFER_MEANS_PRODUCERS", "GLFER_FUSED_MIN_FRAMES",
+             "GLFER_FUSED_BLOCK_FRAMES", "GLFER_FUSED_LOOK")
     saved = {k: os.environ.get(k) for k in knobs}
 
     def run(**env):
@@ -180,6 +181,10 @@ def test_reference_means_piece_by_piece(lib, oracle, torch_cuda, case):
         # ... and the fused launch (the periodogram's table form: the means produced by the launch's own first workgroups)
         for env in (dict(), dict(GLFER_FUSED_MIN_FRAMES=64, GLFER_MEANS_PRODUCERS=8), dict(GLFER_FUSED_MIN_FRAMES=64, GLFER_MEANS_PRODUCERS=64),
                     dict(GLFER_FUSED_MIN_FRAMES=64, GLFER_MEANS_PRODUCERS=256),
+                    # round 5: the lock-stepped fused launch (consumer workgroups of a few frames walked front by front, producers throttled)
+                    dict(GLFER_FUSED_MIN_FRAMES=64, GLFER_MEANS_PRODUCERS=8, GLFER_FUSED_BLOCK_FRAMES=16, GLFER_FUSED_LOOK=64),
+                    dict(GLFER_FUSED_MIN_FRAMES=64, GLFER_MEANS_PRODUCERS=64, GLFER_FUSED_BLOCK_FRAMES=8, GLFER_FUSED_LOOK=0),
+                    dict(GLFER_FUSED_MIN_FRAMES=64, GLFER_MEANS_PRODUCERS=16, GLFER_FUSED_BLOCK_FRAMES=64, GLFER_FUSED_LOOK=1024),
                     dict(GLFER_EXACT_PIECE_MB=1, GLFER_EXACT_STREAMS=1, GLFER_MEANS_HPW=16),
                     dict(GLFER_EXACT_PIECE_MB=1, GLFER_EXACT_STREAMS=2, GLFER_MEANS_HPW=4, GLFER_MEANS_BLOCKS=8),
                     dict(GLFER_EXACT_PIECE_MB=1, GLFER_EXACT_STREAMS=3, GLFER_MEANS_HPW=16, GLFER_MEANS_BLOCKS=8),
