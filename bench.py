@@ -793,6 +793,15 @@ def main():
                                       "frac": r["frames"] * b / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": b,
                                       "note": "bytes this form moves by construction: the hop in, 8 B per bin of averages + 32 B of return values out"
                                               + (", 4 B per bin of PSD row out" if extra == 4 else (", the PSD row out and in again" if extra == 8 else ""))}})
+        # ... and the same one launch under the reference's default, per-hop mean removal in its own order (the means pass in front, given to the kernel)
+        r = measure(torch, G, dist, "fft", 262144, 5, SECONDARY_WARMUP, world, rank, local, rehearse, params_kw=dict(sub_mean=G.SUBMEAN_EXACT), avg_depth=4,
+                    avg_form="fused", dc=0.1)
+        b = 4 * r["hop"] + 8 * r["bins"] + 32
+        rows.append({"workload": r["name"] + " + update_avg_plain depth 4, per-hop mean removal on (the reference's order; one estimator launch behind the means pass)",
+                     "key": "fft+mean+avg", "value": r["fps"], "unit": "frames/s", "steps": 5, "warmup": SECONDARY_WARMUP, "ms_per_step": r["ms_per_step"],
+                     "kernel_ms": r["kernel_ms"], "frames_per_step": r["frames"],
+                     "roofline": {"bound": "hbm", "achieved": r["frames"] * b / (r["kernel_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": r["frames"] * b / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": b}})
         rows.extend(stats_rows(torch, G, local))
         line["secondary"] = rows
         line["parity"] = parity_vs_oracle(torch, G, args.workload, local)

@@ -1965,8 +1965,12 @@ int glfer_hip_spectrogram_avg_device(glfer_hip_plan *p, const void *d_stream, si
   sp.frame0 = (long long)first;
   sp.nframes = (int)nframes;
   static const bool fused_off = [] { const char *e = getenv("GLFER_AVG_FUSED"); return e && *e == '0'; }();   // (A/B runs and the tests that compare the two)
-  const bool fused = !fused_off && avg_mode == GLFER_AVG_PLAIN && depth <= 4 && p->cfg.mode == GLFER_MODE_FFT && !p->nonlin && !p->cfg.sub_mean &&
-                     !p->cfg.history_mode && p->n >= 512 && p->n <= 4096 && n_out <= 2 * p->n && body_route(sp, p->n) == ROUTE_REAL_INPUT;
+  // mean removal: off, or the reference's own (cfg.sub_mean = 1: the means are taken first, in its summation order, and given to the kernel)
+  // where the hop is 2, 4, 8 or 16 sixteenths of the block; the in-kernel sums (GLFER_SUBMEAN_FAST) take the two launches
+  const bool with_means = p->cfg.sub_mean != 0;
+  const bool fused = !fused_off && avg_mode == GLFER_AVG_PLAIN && depth <= 4 && p->cfg.mode == GLFER_MODE_FFT && !p->nonlin &&
+                     !p->cfg.history_mode && p->n >= 512 && p->n <= 4096 && n_out <= 2 * p->n && body_route(sp, p->n) == ROUTE_REAL_INPUT &&
+                     (!with_means || (reference_means(p) && route_takes_mean(ROUTE_REAL_INPUT, sp, p->n) && !getenv("GLFER_MEAN_PREPASS")));
   // the first frame every one of whose depth-1 predecessors lies inside the stream AND inside this call's averaging state
   const size_t first_inside = (size_t)((p->keep + p->hop - 1) / p->hop), end = first + nframes;
   const size_t b0 = std::max(first, first_inside) + (size_t)(depth - 1);
@@ -1984,9 +1988,25 @@ int glfer_hip_spectrogram_avg_device(glfer_hip_plan *p, const void *d_stream, si
     hipError_t e = glfer::scratch_malloc((void **)&ret_scratch, std::min(piece, end - b0) * 4 * sizeof(double), st);
     if (e != hipSuccess) return hip_fail(e, "scratch (return values)");
   }
+  // the hop means of everything the body touches: its frames, the depth-1 frames a slot recomputes in front of them, their history
+  float *means = nullptr;
+  const size_t hops_back = (size_t)((p->keep + p->hop - 1) / p->hop), hop_lo = b0 - (size_t)(depth - 1) - hops_back;
+  if (with_means) {
+    hipError_t e = glfer::scratch_malloc((void **)&means, (end - hop_lo) * sizeof(float), st);
+    if (e == hipSuccess) e = launch_reference_means(p, sp, hop_lo, end - hop_lo, means, 0, st);
+    if (e != hipSuccess) {
+      if (means) glfer::scratch_free(means, st);
+      if (ret_scratch) glfer::scratch_free(ret_scratch, st);
+      return hip_fail(e, "hop means (average inside the kernel)");
+    }
+  }
   for (size_t f0 = b0; rc == GLFER_OK && f0 < end; f0 += piece) {
     const size_t nf = std::min(piece, end - f0);
     SpectroParams q = sp;
+    if (with_means) {
+      q.mean_inkernel = 1;
+      q.means = means - hop_lo;                              // indexed by GLOBAL hop (= frame) index
+    }
     q.frame0 = (long long)f0;
     q.nframes = (int)nf;
     q.psd = d_psd ? d_psd + (f0 - first) * bins : nullptr;
@@ -1999,6 +2019,7 @@ int glfer_hip_spectrogram_avg_device(glfer_hip_plan *p, const void *d_stream, si
     hipError_t e = launch_real_input(q, p->n, st);
     if (e != hipSuccess) rc = hip_fail(e, "estimator launch (average inside the kernel)");
   }
+  if (means) glfer::scratch_free(means, st);
   if (ret_scratch) glfer::scratch_free(ret_scratch, st);
   return rc;
 }

@@ -237,7 +237,8 @@ __device__ __forceinline__ void produce_hop_means(const SpectroParams &p, float 
 // themselves are stored only if p.psd is given.  Two wavefronts per SIMD (the rings and the double sums do not fit 168 VGPRs).
 template <int LOGN, int FMT, int WPS = GLFER16H_WAVES_PER_SIMD, int VAR = GLFER16H_VAR, int MT = 0, int HIST = 0, int SHIFT = 0, int MEAN = 0, int MTAB = 0, int AVG = 0>
 __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(SpectroParams p) {
-  static_assert(AVG == 0 || (MT == 0 && HIST == 0 && MEAN == 0 && MTAB == 0), "the average inside the kernel: the plain periodogram, history from the stream");
+  static_assert(AVG == 0 || (MT == 0 && HIST == 0 && ((MEAN == 0 && MTAB == 0) || (MEAN == 1 && MTAB == 1))),
+                "the average inside the kernel: the periodogram, plain or with GIVEN hop means (the reference's default, sub_mean = opt.autoscale), history from the stream");
   constexpr bool CONSEC = SHIFT > 0 || AVG != 0;         // every frame slot walks consecutive frames
   static_assert(MTAB == 0 || (MEAN == 1 && MT == 0), "given means: the periodogram's mean form");
   static_assert(SHIFT == 0 || (MT == 0 && HIST == 0), "register reuse: periodogram, history from the stream");
@@ -593,9 +594,9 @@ __global__ __launch_bounds__(LaunchH<LOGN>::BLOCK, WPS) void spectro16h_kernel(S
     static_for<0, NH - 1>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       absorb(std::integral_constant<int, q * KM>{}, std::integral_constant<int, (q + 1) * KM>{}, std::integral_constant<int, 0>{},
-             table_mean(rel_of(0), NH - 1 - q));
+             table_mean(rel_of(it), NH - 1 - q));                         // (it = 0, or -lead with AVG: the slot's first frame)
     });
-    mu_new = table_mean(rel_of(0), 0);
+    mu_new = table_mean(rel_of(it), 0);
   } else if constexpr (MEAN != 0) {
     if (mean_table) {
 #pragma unroll
@@ -1044,13 +1045,23 @@ static hipError_t launch16h_fmt(const SpectroParams &p, hipStream_t st) {
 #if GLFER16H_AVG_BUILDS
     // update_avg_plain inside the kernel: two wavefronts per SIMD, every slot walks consecutive frames and recomputes the
     // depth-1 frames in front of its range -- so a slot gets >= 32 frames where the launch is long enough (3 lead frames: < 10 %)
-    if (p.history_mode || p.mean_inkernel || p.avg_depth < 1 || p.avg_depth > 4 || p.avg_nout < (1 << (L - 1)) + 1) return hipErrorInvalidValue;
+    if (p.history_mode || (p.mean_inkernel && !p.means) || p.nprod || p.avg_depth < 1 || p.avg_depth > 4 || p.avg_nout < (1 << (L - 1)) + 1) return hipErrorInvalidValue;
     const long long per_cu2 = (2 * 256) / LC::BLOCK > 0 ? (2 * 256) / LC::BLOCK : 1;
     static const long long mult = [] { const char *e = getenv("GLFER_AVG_GRID_MULT"); const long v = e && *e ? atol(e) : 4; return (long long)(v < 1 ? 1 : v); }();
     const long long cap = mult * 256LL * per_cu2, want = work / 32 > 0 ? work / 32 : 1;
     unsigned ga = (unsigned)(want < cap ? want : cap);
     if (ga >= 64) ga &= ~7u;
     const int k16 = (16 * p.H) % (1 << L) == 0 ? (16 * p.H) >> L : 0;
+    if (p.mean_inkernel) {
+      // the reference's default (sub_mean = opt.autoscale) with the means GIVEN (taken in its own order by hop_means_seq_kernel): the
+      // table form's in-place correction in front of the same averaging block
+      if (k16 == 2) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 2, 1, 1, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);
+      else if (k16 == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 4, 1, 1, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);
+      else if (k16 == 8) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 8, 1, 1, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);
+      else if (k16 == 16) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 0, 1, 1, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);
+      else return hipErrorInvalidValue;
+      return hipGetLastError();
+    }
     if (k16 == 2) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 2, 0, 0, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);
     else if (k16 == 4) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 4, 0, 0, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);
     else if (k16 == 8) hipLaunchKernelGGL((spectro16h_kernel<L, FMT, 2, GLFER16H_VAR, 0, 0, 8, 0, 0, 1>), dim3(ga), dim3(LC::BLOCK), 0, st, p);

@@ -386,7 +386,8 @@ int glfer_hip_avg_device(int avg_mode, const float *d_psd, size_t nframes, int b
  * glfer_hip_avg_device writes them (d_ret may be NULL); d_psd [nframes][N/2+1] receives the PSD rows themselves, or NULL: they
  * are then never stored.  n_out >= N/2+1 (the reference's avgdata is N wide, source.c:312).
  * The plain average (GLFER_AVG_PLAIN) over a window of up to four frames (the reference's default depth, glfer.c:295-296) of
- * a periodogram plan (FFT mode, N = 512..4096, no RA9MB / limiter / mean removal, history from the stream) is taken INSIDE the
+ * a periodogram plan (FFT mode, N = 512..4096, no RA9MB / limiter, history from the stream; mean removal off, or the reference's own --
+ * cfg.sub_mean = 1 with a hop of 2, 4, 8 or 16 sixteenths of the block: the hop means are taken first and given to the kernel) is taken INSIDE the
  * estimator launch, on the |X|^2 values while they are in registers: per frame 4 H bytes in and 8 n_out bytes out, no PSD row
  * in memory.  Every other case runs the two launches.  d_avg is identical, double for double, to glfer_hip_avg_device over
  * the rows (a window's sum of float bins is exact in a double unless a bin spans more than ~2^26 within the window); the band

@@ -129,3 +129,61 @@ def test_random_waterfall_configuration(lib, case):
         assert torch.equal(rgb, w_rgb) and torch.equal(lev, w_lev)
     else:   # the chunk restarts of the band statistics fall elsewhere (other chunk length, tiles): ulps, a few cells
         assert (rgb != w_rgb).float().mean().item() < 2e-4 and (lev != w_lev).float().mean().item() < 2e-4
+
+
+def _avg_cases():
+    rng = np.random.default_rng(int(os.environ.get("GLFER_FUZZ_SEED", "20260")) + 5)
+    out = []
+    for i in range(int(os.environ.get("GLFER_FUZZ_AVG_CASES", "24"))):
+        n = int(rng.choice([512, 1024, 2048, 4096, 4096, 8192, 256]))
+        overlap = float(rng.choice([0.0, 0.25, 0.5, 0.75, 0.75, 0.875, 0.6]))
+        fmt = str(rng.choice(["f32", "f32", "s16", "u8"]))
+        depth = int(rng.choice([1, 2, 3, 4, 4, 4, 7]))
+        mode = str(rng.choice(["plain", "plain", "plain", "sumavg", "sumextreme"]))
+        bins = n // 2 + 1
+        lo = int(rng.integers(0, bins // 2))
+        hi = int(rng.integers(lo + 2, bins + 1))
+        frames = int(rng.integers(260, 900))
+        first = int(rng.integers(0, 40)) if rng.random() < 0.5 else 0
+        sub_mean = int(rng.random() < 0.2)
+        wide = bool(rng.random() < 0.3)
+        out.append((i, n, overlap, fmt, depth, mode, lo, hi, frames, first, sub_mean, wide))
+    return out
+
+
+@pytest.mark.parametrize("case", _avg_cases(), ids=lambda c: "%d-n%d-o%.3f-%s-d%d-%s-%d:%d-f%d+%d-m%d-w%d" % c)
+def test_random_average_inside_or_beside_the_launch(lib, oracle, case):
+    """glfer_hip_spectrogram_avg_device with parameters nobody hand-picked (sizes and depths inside and outside the in-launch form's range,
+    every averaging mode, mean removal, calls that start inside the stream): the averaged rows and return values must be those of
+    glfer_hip_avg_device over the rows of glfer_hip_spectrogram_device -- equal for the plain mode's rows and the peak bin, to 1e-11 where
+    a band reduction is involved."""
+    import torch
+    i, n, overlap, fmt, depth, mode, lo, hi, frames, first, sub_mean, wide = case
+    h = oracle.hop(n, overlap)
+    x = synth(frames * h + (i % 5), seed=700 + i) + np.float32(0.01 * (i % 4))
+    if fmt == "s16":
+        raw, sf = np.clip(np.round(x * 20000), -32768, 32767).astype(np.int16), lib.SAMPLES_S16
+    elif fmt == "u8":
+        raw, sf = np.clip(np.round(x * 100 + 128), 0, 255).astype(np.uint8), lib.SAMPLES_U8
+    else:
+        raw, sf = x, lib.SAMPLES_F32
+    if fmt != "f32" and h % 2:
+        pytest.skip("integer pairs need an even hop on the real-input kernel (the packed kernel takes these: covered by test_random_configuration)")
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=int(i % 8), overlap=overlap, sample_format=sf, sub_mean=sub_mean))
+    d = torch.from_numpy(raw).cuda()
+    mode_id = {"plain": lib.AVG_PLAIN, "sumavg": lib.AVG_SUMAVG, "sumextreme": lib.AVG_SUMEXTREME}[mode]
+    n_out = n if wide else sp.bins
+    nf = frames - first
+    rows = sp.run(d, first_frame=first, nframes=nf)
+    want_avg, want_ret = lib.update_avg(mode_id, rows, depth, lo, hi, max0=i & 1, n_out=n_out)
+    avg, ret, psd = sp.run_avg(d, mode_id, depth, lo, hi, max0=i & 1, n_out=n_out, want_psd=bool(i & 2), first_frame=first, nframes=nf)
+    torch.cuda.synchronize()
+    if psd is not None:
+        assert torch.equal(psd, rows)
+    if mode == "plain":
+        assert torch.equal(avg, want_avg)
+    else:
+        assert torch.allclose(avg, want_avg, rtol=1e-11, atol=1e-300)
+    assert torch.equal(ret[:, 1], want_ret[:, 1]) and torch.equal(ret[:, 3], want_ret[:, 3])
+    assert torch.allclose(ret[:, 0], want_ret[:, 0], rtol=1e-11, atol=0)
+    sp.close()

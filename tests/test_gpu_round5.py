@@ -113,6 +113,7 @@ def _pcm(x, fmt, lib, oracle):
     return x, x, lib.SAMPLES_F32
 
 
+@pytest.mark.parametrize("sub_mean", [0, 1], ids=["mean-off", "reference-means"])
 @pytest.mark.parametrize("n,overlap,fmt,depth,band,wide", [
     (4096, 0.75, "f32", 4, (0, 2049), False),          # the bench row (C2 + update_avg_plain, depth 4)
     (4096, 0.75, "f32", 4, (34, 103), True),           # the reference's default band (glfer.c:278-279: 400-1200 Hz at 48 kHz), avgdata N wide
@@ -123,7 +124,7 @@ def _pcm(x, fmt, lib, oracle):
     (4096, 0.6, "f32", 4, (0, 2049), False),           # a hop that is no whole number of register groups: every frame loaded whole
     (2048, 0.5, "s16", 1, (0, 1025), False),           # depth 1: the "average" of one row (divisor 2, avg.c:138-139)
 ])
-def test_average_inside_the_estimator_launch(lib, oracle, torch_cuda, monkeypatch, n, overlap, fmt, depth, band, wide):
+def test_average_inside_the_estimator_launch(lib, oracle, torch_cuda, monkeypatch, n, overlap, fmt, depth, band, wide, sub_mean):
     """glfer_hip_spectrogram_avg_device with the plain average taken inside the periodogram kernel (spectro16h.hip AVG): the
     averaged rows must be the doubles glfer_hip_avg_device makes of the PSD rows, the PSD rows (when asked for) the bits of
     glfer_hip_spectrogram_device, the peak bin equal and the band mean equal to 1e-12 (a sum over lanes in another order);
@@ -131,9 +132,10 @@ def test_average_inside_the_estimator_launch(lib, oracle, torch_cuda, monkeypatc
     torch = torch_cuda
     h = oracle.hop(n, overlap)
     frames = 1700
-    x = synth_stream(frames * h, seed=n + depth)
+    x = synth_stream(frames * h, seed=n + depth) + np.float32(0.2 * sub_mean)      # (a DC level where the means matter)
     raw, xf, sf = _pcm(x, fmt, lib, oracle)
-    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=lib.WINDOWS["hanning"], overlap=overlap, sample_format=sf))
+    # sub_mean = 1: the reference's default (fft.c:186: sub_mean = opt.autoscale) -- the hop means in its summation order, given to the kernel
+    sp = lib.Spectrogram(lib.FftParams(n=n, window_type=lib.WINDOWS["hanning"], overlap=overlap, sample_format=sf, sub_mean=sub_mean))
     d = torch.from_numpy(raw).cuda()
     minbin, maxbin = band
     n_out = n if wide else sp.bins

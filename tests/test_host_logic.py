@@ -337,3 +337,26 @@ def test_numa_lookups_for_the_worker_placement(lib, tmp_path):
     assert cpus(6)[0] == -1 and cpus(7)[0] == -1 and cpus(9)[0] == -1 and cpus(-1)[0] == -1
     # the real tree of this host, if it has one: a node's list parses or the call says so -- never a crash
     assert L.glfer_hip_numa_node_cpus(0, None, mask, len(mask)) >= -1
+
+
+def test_round5_entries_fail_cleanly_without_a_gpu(lib):
+    """The entries added in round 5 on a host with no usable HIP device (this container): an error code, never a crash and never a
+    CPU computation -- glfer_hip_workers_create, glfer_hip_spectrogram_avg_device (bad arguments are refused before any device is touched)."""
+    import ctypes as C
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present: the GPU suite covers these entries")
+    except ImportError:
+        pass
+    L = lib.api.lib()
+    assert L.glfer_hip_abi_version() == 5
+    cfg = lib.make_config(lib.MtmParams(n=4096, overlap=0.0, w=2.5, kmax=4), 0)
+    devs = (C.c_int * 2)(0, 0)
+    h = C.c_void_p()
+    rc = L.glfer_hip_workers_create(C.byref(cfg), devs, 2, 1000, C.byref(h))
+    assert rc in (-1, -2) and not h.value                      # GLFER_E_ARG / GLFER_E_HIP
+    L.glfer_hip_workers_destroy(None)
+    nf = C.c_size_t(7)
+    assert L.glfer_hip_workers_spectrogram_wav(None, b"/nonexistent.wav", None, 0, C.byref(nf), 0, None) == -1
+    assert L.glfer_hip_spectrogram_avg_device(None, None, 0, 0, 0, 2, 4, 0, 10, 0, 100, None, None, None, None) == -1
