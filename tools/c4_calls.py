@@ -30,5 +30,27 @@ try:
         W.run_wav(path, rows, phases=False)
         print("after 0.5 s idle, call %d: %.2f ms" % (i, (time.perf_counter() - t0) * 1e3), flush=True)
     W.close()
+    # is the slow first call the handle's, the process's, or the caller's row buffer's?  a SECOND handle in the same process, the same rows ...
+    W2 = G.Workers(params, [0] * w, hint_frames=frames)
+    for i in range(3):
+        t0 = time.perf_counter()
+        nf, ph = W2.run_wav(path, rows)
+        print("second handle, call %d: %.2f ms  %s" % (i, (time.perf_counter() - t0) * 1e3, {k: round(v * 1e3, 2) if isinstance(v, float) else v for k, v in ph.items()}), flush=True)
+    # ... and a fresh row buffer with the second handle (warm handle, cold rows)
+    rows2 = G.pinned_empty((frames, n // 2 + 1), np.float32)
+    for i in range(3):
+        t0 = time.perf_counter()
+        nf, ph = W2.run_wav(path, rows2)
+        print("warm handle, fresh pinned rows, call %d: %.2f ms  %s" % (i, (time.perf_counter() - t0) * 1e3, {k: round(v * 1e3, 2) if isinstance(v, float) else v for k, v in ph.items()}), flush=True)
+    # ... and a fresh FILE (same bytes, written now) with warm handle and warm rows
+    path2 = path + ".2"
+    with open(path, "rb") as fi, open(path2, "wb") as fo:
+        fo.write(fi.read())
+    for i in range(3):
+        t0 = time.perf_counter()
+        nf, ph = W2.run_wav(path2, rows2)
+        print("warm handle, warm rows, fresh file, call %d: %.2f ms  %s" % (i, (time.perf_counter() - t0) * 1e3, {k: round(v * 1e3, 2) if isinstance(v, float) else v for k, v in ph.items()}), flush=True)
+    os.unlink(path2)
+    W2.close()
 finally:
     os.unlink(path)
