@@ -642,11 +642,22 @@ int reserve_psd_ring(glfer_hip_plan *p, size_t chunk) {
   const size_t esz = sample_bytes(p->cfg.sample_format), hop = (size_t)p->hop, bins = (size_t)p->bins;
   const size_t halo_hops = (size_t)((p->keep + p->hop - 1) / p->hop) + (p->cfg.mode == GLFER_MODE_LMP ? (size_t)p->lmp_av - 1 : 0);
   const size_t in_bytes = (halo_hops + chunk + 1) * hop * esz, rows_cap = chunk + 1;
-  std::lock_guard<std::mutex> lock(g_ring_mu);
-  if (!p->ring) p->ring = glfer::ingest_ring_take(p->cfg.device);
-  if (!p->ring) p->ring = new glfer::IngestRing();
+  {
+    // (the ring is claimed under the lock and filled outside it: eight workers reserve theirs side by side)
+    std::lock_guard<std::mutex> lock(g_ring_mu);
+    if (!p->ring) p->ring = glfer::ingest_ring_take(p->cfg.device);
+    if (!p->ring) p->ring = new glfer::IngestRing();
+    if (p->ring->busy) return GLFER_OK;
+    p->ring->busy = true;
+  }
   glfer::IngestRing &R = *p->ring;
-  if (R.busy) return GLFER_OK;
+  struct Release {
+    glfer::IngestRing &r;
+    ~Release() {
+      std::lock_guard<std::mutex> lock(g_ring_mu);
+      r.busy = false;
+    }
+  } release{R};
   NodeBinding near_gpu(p->cfg.device);
   hipError_t e = hipSuccess;
   auto ensure = [&](void **ptr, size_t *cap, size_t bytes, int kind) {
