@@ -244,3 +244,33 @@ def test_workers_handle_keeps_plans_and_rings(lib, oracle, torch_cuda, tmp_path,
     got = lib.spectrogram_wav_workers(params, path, [0] * workers)
     assert np.array_equal(got, want)
     L.glfer_hip_scratch_trim(0, 0)
+
+
+@pytest.mark.parametrize("mode,n,overlap,sub_mean,workers", [("mtm", 16384, 0.0, 0, 4), ("fft", 4096, 0.75, 1, 3)])
+def test_c_program_over_a_workers_handle(lib, oracle, tmp_path, mode, n, overlap, sub_mean, workers):
+    """The round-5 entries from a C program (gcc, C99, only include/glfer_hip.h; no Python or ctypes in the data path): ABI check, glfer_hip_wav_probe,
+    glfer_hip_workers_create, three calls of glfer_hip_workers_spectrogram_wav into pinned rows -- against the ORACLE's rows for the same file."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "glfer_amd", "lib")
+    exe = tmp_path / "c_workers_demo"
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_workers_demo.c"),
+                    "-o", str(exe), "-L", libdir, "-lglfer_hip", "-Wl,-rpath," + libdir], check=True)
+    h = oracle.hop(n, overlap)
+    frames = 300 if n == 16384 else 1200
+    x = synth_stream(frames * h, seed=77) * 0.7 + np.float32(0.1)
+    pcm = np.clip(np.round(x * 30000), -32768, 32767).astype(np.int16)
+    _write_wav(str(tmp_path / "in.wav"), pcm)
+    r = subprocess.run([str(exe), mode, str(n), repr(overlap), str(sub_mean), str(workers), str(tmp_path / "in.wav"), str(tmp_path / "out.f32")],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    print(r.stdout.strip())
+    got = np.fromfile(tmp_path / "out.f32", np.float32).reshape(frames, n // 2 + 1)
+    xf = oracle.pcm_s16_to_float(pcm)
+    if mode == "mtm":
+        want = oracle.spectrogram_mtm(xf, n, overlap, 2.5, 4, sub_mean=sub_mean)
+    else:
+        want = oracle.spectrogram_fft(xf, n, overlap, oracle.WINDOWS["hanning"], 0.0, 0, sub_mean, 0)
+    for f in range(frames):
+        assert max(rel_err(got[f], want[f])) < TOL, f
