@@ -672,7 +672,9 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   // 256 .. 16384 through the 16-points-per-lane kernels, 32768 through spectro16w.hip alone, 65536 .. 1048576
   // through spectro_big.hip (sub-transforms and combine as two kernels around a scratch in HBM)
   if (!is_pow2(n) || n < 8 || n > (1 << 20)) return GLFER_E_ARG;
-  if (cfg->mode == GLFER_MODE_HPARMA && (n < 256 || n > 16384)) return GLFER_E_ARG;
+  // HP-ARMA: the frame, its autocorrelation's zero tail and the matrix live in one wavefront's LDS -- any power of two from 32 up to what
+  // fits 160 KB (N = 32768 with t = 128, p_e = 32: 137 KB, one frame in flight per CU); round 5 (it was 256 .. 16384)
+  if (cfg->mode == GLFER_MODE_HPARMA && (n < 32 || n > 32768)) return GLFER_E_ARG;
   const bool small = n < 256, huge = n > 16384;
   if (!(cfg->overlap >= 0.0f) || !(cfg->overlap < 1.0f)) return GLFER_E_ARG;   // g_options.c:1030
   if (cfg->mode != GLFER_MODE_FFT && cfg->mode != GLFER_MODE_MTM && cfg->mode != GLFER_MODE_HPARMA &&
@@ -682,7 +684,8 @@ int glfer_hip_plan_create(const glfer_hip_config *cfg, glfer_hip_plan **out) {
   if (cfg->mode == GLFER_MODE_HPARMA) {
     const int t = cfg->hparma_t, ncol = cfg->hparma_p_e + 1;
     if (t < 2 || ncol < 2 || ncol > t || t > n || ncol > 256 || t > 65535) return GLFER_E_ARG;   // p_e+1 <= t (hparma.c:107)
-    const size_t big = (size_t)n > (size_t)t * ncol ? (size_t)n : (size_t)t * ncol;
+    const size_t xlen = (size_t)n + (t <= 128 ? 128 : 0);          // (glfer_launch_hparma: the frame and its zero tail)
+    const size_t big = xlen > (size_t)t * ncol ? xlen : (size_t)t * ncol;
     if ((big + (size_t)ncol * ncol + t + 2 * ncol) * sizeof(float) > 160 * 1024) return GLFER_E_ARG;
   }
   if (cfg->sample_format < 0 || cfg->sample_format > 2) return GLFER_E_ARG;

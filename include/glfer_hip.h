@@ -77,7 +77,7 @@ extern "C" {
  * -> history_mode, fft.c:99). */
 typedef struct glfer_hip_config {
   int mode;            /* GLFER_MODE_*                                                  */
-  int n;               /* opt.data_block_size; power of two, 8..1048576 (HP-ARMA: 256..16384; the halfcomplex spectrum
+  int n;               /* opt.data_block_size; power of two, 8..1048576 (HP-ARMA: 32..32768; the halfcomplex spectrum
                           output up to 32768, the F-test up to 16384, the per-column stages up to 32769 bins)  */
   float overlap;       /* opt.data_blocks_overlap, [0,1)                                */
   int window_type;     /* opt.window_type (FFT mode; MTM forces rectangular, source.c:344) */
